@@ -1,0 +1,231 @@
+/*
+ * wbc.h — C-ABI of the MI355X batched whole-body-control hot path.
+ *
+ * This is the drop-in boundary for the per-tick hot loop of the reference
+ * (joey156/MECH5845M-WBC-for-Legged-Manipulator):
+ *
+ *   RobotModel.runWBC            wrappers/Robot_Wrapper4.py:1330-1412
+ *     -> updateState             wrappers/Robot_Wrapper4.py:387-428     (FK, joint Jacobians, frames)
+ *     -> qpA / qpb               wrappers/Robot_Wrapper4.py:1271-1294   (task stack A, b)
+ *     -> findConstraints         wrappers/Robot_Wrapper4.py:764-836     (C, Clb, Cub)
+ *     -> velDamperJointConstraints  wrappers/Robot_Wrapper4.py:572-637  (lb, ub)
+ *     -> QP.solveQP / solveQPHotstart  wrappers/QP_Wrapper.py:23-73     (H = A'A, g = -A'b, QP)
+ *     -> jointVelocitiestoConfig wrappers/Robot_Wrapper4.py:440-449     (pin.integrate)
+ *
+ * The reference has no FFI layer (it is pure Python calling pinocchio + qpOASES); the boundary is
+ * its two Python classes `QP` and `RobotModel`.  The Python mirrors in
+ * mech5845m-wbc-for-legged-manipulator_amd/{QP_Wrapper,Robot_Wrapper4}.py keep those signatures and
+ * bind the entry points below through ctypes.
+ *
+ * Conventions: plain C types only; all matrices row-major fp64; every per-instance array is
+ * [B][k] with an instance's k values contiguous; quaternions are (x, y, z, w) as in pinocchio,
+ * PyBullet and scipy; Jacobian rows are linear 0-2, angular 3-5 (pinocchio Motion order).
+ * Buffers are caller-allocated; `mem` says whether the pointers are host (the library stages them
+ * through its own device workspace) or device pointers (used in place, zero copies).
+ * Return value: 0 = ok, negative = API-level failure (message via wbc_last_error()).  Per-instance
+ * solver outcome goes to the `status` array.  No global state except the thread-local error string;
+ * handles are not thread-safe, independent handles may be used concurrently.
+ */
+#ifndef WBC_H_
+#define WBC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ limits */
+#define WBC_MAX_JOINTS 24  /* model joints incl. universe (a1_wx200: 22)                           */
+#define WBC_MAX_NQ 28      /* a1_wx200: 27                                                          */
+#define WBC_MAX_NV 26      /* a1_wx200: 26 = QP size n; one wavefront lane per DoF   */
+#define WBC_NEE 5          /* end effectors in reference order FR, FL, RR, RL, GRIP (sim3.py:56)    */
+#define WBC_MAX_FRAMES 16
+#define WBC_MAX_P 24       /* constraint rows: CoM 2 + trunk 4 + 5 EE x 3 = 21 max                  */
+#define WBC_MAX_M 96       /* task rows accepted by wbc_qp_solve_ls (A is m x n)                    */
+#define WBC_MAX_MODELS 4   /* morphologies interleaved in one batch (BASELINE config 5)             */
+
+/* joint types (pinocchio JointModel*) */
+enum { WBC_JT_UNIVERSE = 0, WBC_JT_FF = 1, WBC_JT_RX = 2, WBC_JT_RY = 3, WBC_JT_RZ = 4,
+       WBC_JT_PX = 5, WBC_JT_PY = 6, WBC_JT_PZ = 7 };
+
+/* controller frame roles: index into WbcModelBlob.frame_* */
+enum { WBC_FR_EE0 = 0 /* ..4: FR, FL, RR, RL foot_fixed, gripper_bar */, WBC_FR_TRUNK = 5,
+       WBC_FR_HIP0 = 6 /* ..10: FR/FL/RR/RL hip joint frames, waist */, WBC_FR_ARM_BASE = 11,
+       WBC_FR_NROLES = 12 };
+
+enum { WBC_MEM_HOST = 0, WBC_MEM_DEVICE = 1 };
+
+/* per-instance solver status */
+enum { WBC_QP_OPTIMAL = 0, WBC_QP_MAX_ITER = 1, WBC_QP_INFEASIBLE = 2, WBC_QP_NUMERICAL = 3 };
+
+/* posture-task mode = RobotModel.task_active_Joint (Robot_Wrapper4.py:1209-1268) */
+enum { WBC_JOINT_OFF = 0, WBC_JOINT_TIKHONOV = 1 /* True */, WBC_JOINT_PREV = 2 /* "PREV" */ };
+
+/* API return codes */
+enum { WBC_OK = 0, WBC_E_ARG = -1, WBC_E_HIP = -2, WBC_E_UNSUPPORTED = -3, WBC_E_STATE = -4 };
+
+/* ------------------------------------------------------------------ model
+ * What pin.buildModelFromUrdf(urdf, JointModelFreeFlyer()) holds that the path reads
+ * (Robot_Wrapper4.py:21); produced by tools/bake_model.py, SURVEY.md Appendix A. */
+typedef struct WbcModelBlob {
+  int32_t nq, nv, njoints;               /* njoints includes universe (index 0)                   */
+  int32_t jtype[WBC_MAX_JOINTS];
+  int32_t parent[WBC_MAX_JOINTS];
+  int32_t idx_q[WBC_MAX_JOINTS];
+  int32_t idx_v[WBC_MAX_JOINTS];
+  double place_R[WBC_MAX_JOINTS][9];     /* joint placement in parent joint frame                 */
+  double place_p[WBC_MAX_JOINTS][3];
+  double mass[WBC_MAX_JOINTS];           /* lumped body (fixed children merged), joint frame      */
+  double com[WBC_MAX_JOINTS][3];
+  double q_lo[WBC_MAX_NQ], q_hi[WBC_MAX_NQ]; /* model.lower/upperPositionLimit (nq-sized)         */
+  double v_max[WBC_MAX_NV];                  /* model.velocityLimit (nv-sized)                     */
+  int32_t nframes;                       /* >= WBC_FR_NROLES                                      */
+  int32_t frame_joint[WBC_MAX_FRAMES];   /* supporting joint                                      */
+  double frame_R[WBC_MAX_FRAMES][9];     /* placement in the supporting joint's frame             */
+  double frame_p[WBC_MAX_FRAMES][3];
+  int32_t ee_joint[WBC_NEE];             /* end_effector_index_list_joint (Robot_Wrapper4.py:49)  */
+} WbcModelBlob;
+
+/* ------------------------------------------------------------------ batch-uniform settings
+ * = the RobotModel attributes set by __init__/setTasks/setConstraints/staticReachMode
+ * (Robot_Wrapper4.py:72-125, 176-193, 1415-1464). 6x6 weights/gains are diagonal in every preset
+ * of the reference, so only the diagonals cross the ABI (the Python mirror refuses non-diagonal). */
+typedef struct WbcConfig {
+  int32_t task_ee[WBC_NEE];    /* task_active_{FR,FL,RR,RL}_foot, task_active_GRIP                */
+  int32_t task_trunk;          /* task_active_Trunk                                               */
+  int32_t task_com;            /* Robot_Wrapper2 taskActiveCoM (Robot_Wrapper2.py:600-603)        */
+  int32_t task_joint;          /* WBC_JOINT_*                                                     */
+  int32_t con_com, con_trunk;  /* const_active_CoM / _Trunk                                       */
+  int32_t con_ee[WBC_NEE];     /* const_active_{FR,FL,RR,RL}_foot, const_active_GRIP              */
+  int32_t use_bounds;          /* 1: velDamperJointConstraints box; 0: no box (equality-only QP)  */
+  int32_t lock_from;           /* DoF >= lock_from get lb = ub = 0 (Robot_Wrapper4.py:627-630)    */
+  int32_t damper_qidx[WBC_MAX_NV]; /* which q entry DoF i's damper looks at (quirk C.3)           */
+  double damper_lo[WBC_MAX_NV], damper_hi[WBC_MAX_NV], damper_vmax[WBC_MAX_NV];
+  double damper_coef, damper_qi, damper_qs;      /* 0.01, 0.026, 0.015 (Robot_Wrapper4.py:574-576) */
+  double ee_W[WBC_NEE][6];     /* diag(EE_weight[i])                                              */
+  double ee_w[WBC_NEE];        /* cart_task_weight_EE_list[i]                                     */
+  double ee_gain[WBC_NEE][6];  /* diag(EE_gains[i]), indexed by EE index as at Robot_Wrapper4.py:908 */
+  double trunk_W[6], trunk_w, trunk_gain[6];
+  double com_W[3], com_gain[3];
+  double joint_w;              /* joint_task_weight                                               */
+  double trunk_box_z_frac;     /* 0.25  (Robot_Wrapper4.py:719)                                   */
+  double trunk_box_ang;        /* 0.15  (Robot_Wrapper4.py:720-722)                               */
+  double trunk_box_scale;      /* 0.5   (Robot_Wrapper4.py:735-736)                               */
+  double com_box_scale;        /* 0.8   (Robot_Wrapper4.py:675-677)                               */
+} WbcConfig;
+
+/* ------------------------------------------------------------------ per-instance tick inputs
+ * (the arguments of runWBC plus the controller state it reads). NULL is allowed where noted. */
+typedef struct WbcTickIn {
+  const double* q;                 /* [B][WBC_MAX_NQ-1=27] current_joint_config (xyz, quat xyzw, joints) */
+  const double* ee_target;         /* [B][5][3] target_cartesian_pos_EE                               */
+  const double* prev_ee_target;    /* [B][5][3] prev_EE_pos                                           */
+  const double* trunk_target;      /* [B][3]    target_cartesian_pos_trunk     (NULL if no trunk task) */
+  const double* prev_trunk_target; /* [B][3]    prev_trunk_ref                 (NULL if no trunk task) */
+  const double* trunk_box_center;  /* [B][4]    initial_trunk_pos[2], initial_trunk_ori_euler (NULL if no trunk constraint) */
+  const double* ee_ref_rot;        /* [B][5][9] R* = from_euler('xyz', default_EE_ori_list[i]); NULL => R* == R*_prev (omega_ref = 0) */
+  const double* ee_prev_rot;       /* [B][5][9] prev_EE_CoM_rot                                       */
+  const double* trunk_ref_euler;   /* [B][3]    default_trunk_ori              (NULL if no trunk task) */
+  const double* trunk_prev_rot;    /* [B][9]    old_ref_trunk_rot_matrix       (NULL if no trunk task) */
+  const double* com_target;        /* [B][3]    Robot_Wrapper2 target_cartesian_pos_CoM (NULL if no CoM task) */
+  const double* com_target_vel;    /* [B][3]    Robot_Wrapper2 target_cartesian_vel_CoM               */
+  const int32_t* model_id;         /* [B] index into the batch's models; NULL => all model 0          */
+} WbcTickIn;
+
+#define WBC_Q_STRIDE 27   /* doubles per instance in q / q_next (nq of the largest model)           */
+#define WBC_V_STRIDE 26   /* doubles per instance in qdot, g, lb, ub; row length of H, C, A         */
+
+/* the QP data of one tick, as the reference hands it to QP(...) (all optional outputs, [B][...]) */
+typedef struct WbcQpData {
+  double* A;    /* [B][m][26]  qpA()  (m = wbc_task_rows())          */
+  double* b;    /* [B][m]      qpb()                                  */
+  double* H;    /* [B][26][26] A'A   (QP_Wrapper.py:17)               */
+  double* g;    /* [B][26]     -A'b  (QP_Wrapper.py:18)               */
+  double* C;    /* [B][p][26]  findConstraints() before its final .T  */
+  double* Clb;  /* [B][p]                                             */
+  double* Cub;  /* [B][p]                                             */
+  double* lb;   /* [B][26]     velDamperJointConstraints()            */
+  double* ub;   /* [B][26]                                            */
+} WbcQpData;
+
+typedef struct WbcTickOut {
+  double* qdot;     /* [B][26] xOpt                                                       */
+  int32_t* status;  /* [B] WBC_QP_*                                                       */
+  int32_t* iters;   /* [B] working-set changes (may be NULL)                              */
+  double* q_next;   /* [B][27] pin.integrate(q, qdot*dt) (may be NULL)                    */
+} WbcTickOut;
+
+/* forward-kinematics outputs of updateState (all optional) */
+typedef struct WbcFkOut {
+  double* oMi;     /* [B][njoints][12]  R (9, row-major) then p (3); joint 0 = identity       */
+  double* oMf;     /* [B][nframes][12]  controller frames (WbcModelBlob.frame_*)              */
+  double* J;       /* [B][6][26] data.J of computeJointJacobians (WORLD)                      */
+  double* com;     /* [B][3]     data.com[0]                                                  */
+  double* Jcom;    /* [B][3][26] jacobianCenterOfMass                                         */
+} WbcFkOut;
+
+typedef struct WbcModel WbcModel;
+typedef struct WbcBatch WbcBatch;
+
+/* ------------------------------------------------------------------ entry points */
+
+/* replaces pin.buildModelFromUrdf + createData (Robot_Wrapper4.py:21-23); validates the blob. */
+int wbc_model_create(const WbcModelBlob* blob, WbcModel** out);
+void wbc_model_destroy(WbcModel* m);
+
+/* one handle per device/stream: device workspace for up to max_batch instances. */
+int wbc_batch_create(const WbcModel* const* models, int n_models, int max_batch, int device_id, WbcBatch** out);
+void wbc_batch_destroy(WbcBatch* b);
+
+/* replaces setTasks / setConstraints / staticReachMode and the weight attributes
+ * (Robot_Wrapper4.py:176-193, 1415-1464); cfg applies to model `model_index` of the batch. */
+int wbc_batch_configure(WbcBatch* b, int model_index, const WbcConfig* cfg);
+int wbc_task_rows(const WbcBatch* b);       /* m of qpA() under the current switches        */
+int wbc_constraint_rows(const WbcBatch* b); /* p of findConstraints()                        */
+
+/* replaces the pinocchio calls of updateState (Robot_Wrapper4.py:400-405) and
+ * pin.jacobianCenterOfMass (Robot_Wrapper4.py:670). */
+int wbc_fk_jacobians(WbcBatch* b, int B, const double* q, const int32_t* model_id, int mem,
+                     const WbcFkOut* out, void* stream);
+
+/* replaces qpA/qpb/findConstraints/velDamperJointConstraints + QP.__init__'s H, g
+ * (Robot_Wrapper4.py:1348-1361, QP_Wrapper.py:17-18). */
+int wbc_assemble(WbcBatch* b, int B, const WbcTickIn* in, double dt, int mem, const WbcQpData* out, void* stream);
+
+/* replaces QP.solveQP / solveQPHotstart given H, g (QP_Wrapper.py:23-73):
+ * argmin 1/2 x'Hx + g'x  s.t. lb <= x <= ub, Clb <= C x <= Cub.
+ * n <= 26, p <= WBC_MAX_P; H is [B][n][n], C is [B][p][n] (row-major, NOT the reference's C.T view —
+ * SURVEY.md C.1); lb/ub/C may be NULL (no box / no rows). */
+int wbc_qp_solve(WbcBatch* b, int B, int n, int p, const double* H, const double* g, const double* C,
+                 const double* lb, const double* ub, const double* Clb, const double* Cub, int mem,
+                 double* x, int32_t* status, int32_t* iters, void* stream);
+
+/* replaces QP(A, b, ...) + solveQP(): forms H = A'A, g = -A'b on the device (QP_Wrapper.py:17-18)
+ * and solves. A is [B][m][n]. H_out/g_out optional. use_mfma: 1 = fp64 MFMA contraction, 0 = VALU. */
+int wbc_qp_solve_ls(WbcBatch* b, int B, int m, int n, int p, const double* A, const double* bvec, const double* C,
+                    const double* lb, const double* ub, const double* Clb, const double* Cub, int mem, int use_mfma,
+                    double* x, int32_t* status, int32_t* iters, double* H_out, double* g_out, void* stream);
+
+/* the fused hot path = one runWBC tick up to and including the QP (+ optional integrate):
+ * FK -> Jacobians -> task stack -> H, g, C, bounds -> QP -> qdot [-> q_next]. */
+int wbc_tick(WbcBatch* b, int B, const WbcTickIn* in, double dt, int mem, const WbcTickOut* out, void* stream);
+
+/* replaces jointVelocitiestoConfig / pin.integrate (Robot_Wrapper4.py:440-441): q_next = q (+) v*dt */
+int wbc_integrate(WbcBatch* b, int B, const double* q, const double* v, const int32_t* model_id, double dt, int mem,
+                  double* q_next, void* stream);
+
+/* knobs: 0 = default. "jtj_mfma": use v_mfma_f64_16x16x4_f64 for the J'J contraction in wbc_tick/wbc_assemble. */
+int wbc_batch_set_option(WbcBatch* b, const char* name, int value);
+
+/* wait for everything queued by this handle on `stream`. */
+int wbc_batch_synchronize(WbcBatch* b, void* stream);
+
+const char* wbc_last_error(void);
+const char* wbc_version(void);
+int wbc_abi_sizes(int32_t* sizeof_blob, int32_t* sizeof_config); /* ctypes layout self-check */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WBC_H_ */

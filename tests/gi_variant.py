@@ -1,0 +1,146 @@
+"""numpy model of the QP algorithm VARIANT the HIP kernel runs (test infrastructure).
+
+The CPU oracle (oracle/wbc_oracle.c) is the textbook Goldfarb–Idnani dual active-set: Givens rotations to add a
+constraint, an explicit triangular factor R with back-substitution. The wavefront kernel uses forms that map to
+64 lanes without sequential triangular solves:
+  * add:  ONE Householder reflector on the trailing columns of J (J2 <- J2 P), using z = J2 d2 already at hand;
+  * T = R^-1 is kept explicitly, so r = T d1 is a mat-vec; adding a constraint appends the column (-r/delta, 1/delta);
+  * drop: the Givens sequence is read off the removed ROW l of T (it is orthogonal to range(R without column l)),
+          applied to adjacent columns of T and of J1.
+This file states that variant in plain numpy so its algebra is checked against the oracle on the CPU, lane
+mapping aside; tests/test_qp_variant.py runs it. Decision rules and tolerances are the oracle's.
+"""
+import numpy as np
+
+INF = 1e20
+EPS2 = 2.220446049250313e-16 ** 2
+
+
+def solve(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, max_iter=None):
+    n = len(g)
+    p = 0 if C is None else C.shape[0]
+    ncon = n + p
+
+    def lo(c):
+        return (lb[c] if lb is not None else -1e30) if c < n else Clb[c - n]
+
+    def hi(c):
+        return (ub[c] if ub is not None else 1e30) if c < n else Cub[c - n]
+
+    def normal(c, side):
+        s = -1.0 if side else 1.0
+        if c < n:
+            e = np.zeros(n)
+            e[c] = s
+            return e
+        return s * C[c - n]
+
+    def value(c, x):
+        return x[c] if c < n else C[c - n] @ x
+
+    try:
+        L = np.linalg.cholesky(H)
+    except np.linalg.LinAlgError:
+        return np.zeros(n), 3, 0
+    J = np.linalg.inv(L).T.copy()
+    jf2 = (J * J).sum()
+    x = -J @ (J.T @ g)
+    T = np.zeros((n, n))
+    u = np.zeros(n + 1)
+    act, act_eq, active = [], [], np.zeros(ncon, bool)
+    q = 0
+    iters = 0
+    max_iter = max_iter or 10 * (n + p) + 20
+    eqs = [c for c in range(ncon) if lo(c) == hi(c) and abs(lo(c)) < INF]
+    eqi = 0
+    while True:
+        ip = -1
+        if eqi < len(eqs):
+            ip, side, is_eq = eqs[eqi], 0, True
+            eqi += 1
+            b_ip = lo(ip)
+            s_ip = value(ip, x) - b_ip
+        else:
+            is_eq = False
+            worst = 0.0
+            for c in range(ncon):
+                if active[c] or (lo(c) == hi(c) and abs(lo(c)) < INF):
+                    continue
+                v = value(c, x)
+                if lo(c) > -INF:
+                    s = v - lo(c)
+                    if s < -1e-9 * max(1.0, abs(lo(c))) and s < worst:
+                        worst, ip, side, b_ip = s, c, 0, lo(c)
+                if hi(c) < INF:
+                    s = hi(c) - v
+                    if s < -1e-9 * max(1.0, abs(hi(c))) and s < worst:
+                        worst, ip, side, b_ip = s, c, 1, -hi(c)
+            if ip < 0:
+                return x, 0, iters
+            s_ip = worst
+        npv = normal(ip, side)
+        np2 = npv @ npv
+        u_ip = 0.0
+        while True:
+            iters += 1
+            if iters > max_iter:
+                return x, 1, iters
+            d = J.T @ npv
+            zn = d[q:] @ d[q:]
+            z = J[:, q:] @ d[q:]
+            r = T[:q, :q] @ d[:q]
+            have_step = zn > 100.0 * n * EPS2 * jf2 * np2
+            t1, l = np.inf, -1
+            for k in range(q):
+                if not act_eq[k] and r[k] > 0 and u[k] / r[k] < t1:
+                    t1, l = u[k] / r[k], k
+            t2 = -s_ip / zn if have_step else np.inf
+            if is_eq and not have_step:
+                if abs(s_ip) <= 1e-9 * max(1.0, abs(b_ip)):
+                    break
+                return x, 2, iters
+            t = t2 if is_eq else min(t1, t2)
+            if not np.isfinite(t):
+                return x, 2, iters
+            if have_step:
+                x = x + t * z
+            u[:q] -= t * r
+            u_ip += t
+            if have_step and t == t2:
+                # --- add with one Householder reflector: P d2 = delta e1, J2 <- J2 P
+                dq = d[q]
+                delta = -np.sqrt(zn) if dq >= 0 else np.sqrt(zn)
+                v = d[q:].copy()
+                v[0] -= delta
+                vv = 2.0 * (zn - delta * dq)           # v'v
+                if vv > 0:
+                    w = z - delta * J[:, q]            # J2 v
+                    J[:, q:] -= np.outer(w, (2.0 / vv) * v)
+                T[:q, q] = -r / delta
+                T[q, q] = 1.0 / delta
+                u[q] = u_ip
+                act.append(ip)
+                act_eq.append(is_eq)
+                active[ip] = True
+                q += 1
+                break
+            # --- drop blocking constraint l: rotations from the removed row of T
+            trow = T[l, l:q].copy()
+            active[act[l]] = False
+            del act[l], act_eq[l]
+            u[l:q - 1] = u[l + 1:q].copy()
+            Tt = np.delete(T[:q, :q], l, axis=0)       # (q-1) x q
+            h = trow[0]
+            for k in range(l, q - 1):
+                a, b = h, trow[k - l + 1]
+                rho = np.hypot(a, b)
+                c_, s_ = (b / rho, -a / rho) if rho > 0 else (1.0, 0.0)
+                h = rho
+                ck, ck1 = Tt[:, k].copy(), Tt[:, k + 1].copy()
+                Tt[:, k], Tt[:, k + 1] = c_ * ck + s_ * ck1, -s_ * ck + c_ * ck1
+                jk, jk1 = J[:, k].copy(), J[:, k + 1].copy()
+                J[:, k], J[:, k + 1] = c_ * jk + s_ * jk1, -s_ * jk + c_ * jk1
+            T[:, :] = np.triu(T) * 0
+            T[:q - 1, :q - 1] = np.triu(Tt[:, :q - 1])
+            q -= 1
+            s_ip = (-1.0 if side else 1.0) * value(ip, x) - b_ip
