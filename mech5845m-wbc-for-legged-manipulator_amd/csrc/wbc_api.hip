@@ -1,0 +1,426 @@
+// wbc_api.hip — the C-ABI of include/wbc.h on top of the gfx950 kernels (handles, validation, host staging).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <vector>
+#include "wbc_device.h"
+
+using namespace wbc;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(WBC_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+
+struct WbcModel {
+  WbcModelBlob blob;
+  DevModel dev;
+};
+
+struct WbcBatch {
+  int device_id, n_models, max_batch, grid;
+  const WbcModel* models[WBC_MAX_MODELS];
+  WbcConfig cfg_host[WBC_MAX_MODELS];
+  bool configured[WBC_MAX_MODELS];
+  DevModel* d_models;
+  WbcConfig* d_cfgs;
+  void* ws;
+  size_t ws_bytes;
+  int mrows, prows, mcart;
+  int jtj_mfma;
+};
+
+// ---------------------------------------------------------------------------------------------- model
+static bool is_identity(const double* R) {
+  static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 9; ++i)
+    if (R[i] != I[i]) return false;
+  return true;
+}
+
+extern "C" int wbc_model_create(const WbcModelBlob* b, WbcModel** out) {
+  if (!b || !out) return fail(WBC_E_ARG, "wbc_model_create: null argument");
+  if (b->njoints < 2 || b->njoints > WBC_MAX_JOINTS || b->nv < 6 || b->nv > WBC_MAX_NV || b->nq != b->nv + 1 || b->nq > WBC_Q_STRIDE)
+    return fail(WBC_E_ARG, "wbc_model_create: sizes out of range (njoints %d, nq %d, nv %d)", b->njoints, b->nq, b->nv);
+  if (b->jtype[1] != WBC_JT_FF || b->parent[1] != 0 || b->idx_q[1] != 0 || b->idx_v[1] != 0)
+    return fail(WBC_E_UNSUPPORTED, "wbc_model_create: joint 1 must be the free-flyer root (Robot_Wrapper4.py:21)");
+  if (b->nframes < WBC_FR_NROLES || b->nframes > WBC_MAX_FRAMES) return fail(WBC_E_ARG, "wbc_model_create: nframes %d", b->nframes);
+  WbcModel* m = new (std::nothrow) WbcModel;
+  if (!m) return fail(WBC_E_ARG, "out of memory");
+  m->blob = *b;
+  DevModel& d = m->dev;
+  memset(&d, 0, sizeof d);
+  d.nq = b->nq; d.nv = b->nv; d.njoints = b->njoints; d.nframes = b->nframes;
+  int depth[WBC_MAX_JOINTS] = {0};
+  double total = 0;
+  for (int j = 1; j < b->njoints; ++j) {
+    const int t = b->jtype[j];
+    if (b->parent[j] < 0 || b->parent[j] >= j) { delete m; return fail(WBC_E_ARG, "joint %d: parent %d not before it", j, b->parent[j]); }
+    if (j > 1 && !(t >= WBC_JT_RX && t <= WBC_JT_PZ)) { delete m; return fail(WBC_E_UNSUPPORTED, "joint %d: type %d unsupported on device", j, t); }
+    if (!is_identity(b->place_R[j])) { delete m; return fail(WBC_E_UNSUPPORTED, "joint %d: rotated joint placement unsupported on device", j); }
+    if (j > 1 && b->parent[j] < 1) { delete m; return fail(WBC_E_UNSUPPORTED, "joint %d: only one root joint supported", j); }
+    if (j == 1 && (b->place_p[1][0] != 0 || b->place_p[1][1] != 0 || b->place_p[1][2] != 0)) { delete m; return fail(WBC_E_UNSUPPORTED, "root joint placement must be identity"); }
+    depth[j] = depth[b->parent[j]] + 1;
+    if (depth[j] > d.maxdepth) d.maxdepth = depth[j];
+    d.parent[j] = b->parent[j]; d.depth[j] = depth[j]; d.jtype[j] = t; d.idx_q[j] = b->idx_q[j];
+    const int a = (t >= WBC_JT_RX && t <= WBC_JT_RZ) ? t - WBC_JT_RX : (t >= WBC_JT_PX ? t - WBC_JT_PX : 0);
+    d.ax0[j] = a; d.ax1[j] = (a + 1) % 3; d.ax2[j] = (a + 2) % 3;
+    d.tp[j][0] = b->place_p[j][d.ax0[j]]; d.tp[j][1] = b->place_p[j][d.ax1[j]]; d.tp[j][2] = b->place_p[j][d.ax2[j]];
+    d.mass[j] = b->mass[j];
+    for (int i = 0; i < 3; ++i) d.com[j][i] = b->com[j][i];
+    total += b->mass[j];
+    // velocity columns of this joint
+    const int nvj = (t == WBC_JT_FF) ? 6 : 1;
+    if (b->idx_v[j] < 0 || b->idx_v[j] + nvj > b->nv) { delete m; return fail(WBC_E_ARG, "joint %d: idx_v out of range", j); }
+    for (int c = 0; c < nvj; ++c) {
+      const int k = b->idx_v[j] + c;
+      d.col_joint[k] = j; d.col_lin[k] = -1; d.col_ang[k] = -1; d.col_q[k] = b->idx_q[j] + c;
+      if (t == WBC_JT_FF) { if (c < 3) d.col_lin[k] = c; else d.col_ang[k] = c - 3; }
+      else if (t <= WBC_JT_RZ) d.col_ang[k] = a;
+      else d.col_lin[k] = a;
+    }
+  }
+  d.total_mass = total;
+  auto on_path = [&](int anc, int j) { while (j > 0) { if (j == anc) return true; j = b->parent[j]; } return false; };
+  for (int k = 0; k < b->nv; ++k) {
+    uint32_t mask = 0;
+    for (int j = 1; j < b->njoints; ++j) if (on_path(d.col_joint[k], j)) mask |= 1u << j;
+    d.col_subtree[k] = mask;
+  }
+  for (int f = 0; f < b->nframes; ++f) {
+    const int jf = b->frame_joint[f];
+    if (jf < 1 || jf >= b->njoints) { delete m; return fail(WBC_E_ARG, "frame %d: supporting joint %d out of range", f, jf); }
+    if (!is_identity(b->frame_R[f])) { delete m; return fail(WBC_E_UNSUPPORTED, "frame %d: rotated frame offset unsupported on device", f); }
+    d.frame_joint[f] = jf;
+    for (int i = 0; i < 3; ++i) d.frame_p[f][i] = b->frame_p[f][i];
+    uint32_t mask = 0;
+    for (int k = 0; k < b->nv; ++k) if (on_path(d.col_joint[k], jf)) mask |= 1u << k;
+    d.frame_support[f] = mask;
+  }
+  *out = m;
+  return WBC_OK;
+}
+
+extern "C" void wbc_model_destroy(WbcModel* m) { delete m; }
+
+// ---------------------------------------------------------------------------------------------- batch
+extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int max_batch, int device_id, WbcBatch** out) {
+  if (!models || !out || n_models < 1 || n_models > WBC_MAX_MODELS || max_batch < 1)
+    return fail(WBC_E_ARG, "wbc_batch_create: bad arguments (n_models %d, max_batch %d)", n_models, max_batch);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(WBC_E_HIP, "wbc_batch_create: no HIP device visible (this library has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(WBC_E_ARG, "wbc_batch_create: device %d of %d", device_id, ndev);
+  HIP_TRY(hipSetDevice(device_id));
+  WbcBatch* b = new (std::nothrow) WbcBatch;
+  if (!b) return fail(WBC_E_ARG, "out of memory");
+  memset(b, 0, sizeof *b);
+  b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch;
+  std::vector<DevModel> dm(n_models);
+  for (int i = 0; i < n_models; ++i) {
+    if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
+    b->models[i] = models[i];
+    dm[i] = models[i]->dev;
+  }
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  const int per_cu = (int)(prop.maxSharedMemoryPerMultiProcessor / (size_t)tick_lds_bytes());
+  b->grid = prop.multiProcessorCount * (per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu));
+  HIP_TRY(hipMalloc((void**)&b->d_models, sizeof(DevModel) * n_models));
+  HIP_TRY(hipMalloc((void**)&b->d_cfgs, sizeof(WbcConfig) * n_models));
+  HIP_TRY(hipMemcpy(b->d_models, dm.data(), sizeof(DevModel) * n_models, hipMemcpyHostToDevice));
+  *out = b;
+  return WBC_OK;
+}
+
+extern "C" void wbc_batch_destroy(WbcBatch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device_id);
+  if (b->d_models) (void)hipFree(b->d_models);
+  if (b->d_cfgs) (void)hipFree(b->d_cfgs);
+  if (b->ws) (void)hipFree(b->ws);
+  delete b;
+}
+
+static int rows_task(const WbcConfig& c, int* mcart) {
+  int m = 0;
+  for (int i = 0; i < WBC_NEE; ++i) m += c.task_ee[i] ? 6 : 0;
+  m += c.task_trunk ? 6 : 0;
+  m += c.task_com ? 3 : 0;
+  *mcart = m;
+  return m + (c.task_joint ? WBC_V_STRIDE : 0);
+}
+static int rows_con(const WbcConfig& c) {
+  int p = (c.con_com ? 2 : 0) + (c.con_trunk ? 4 : 0);
+  for (int i = 0; i < WBC_NEE; ++i) p += c.con_ee[i] ? 3 : 0;
+  return p;
+}
+
+extern "C" int wbc_batch_configure(WbcBatch* b, int mi, const WbcConfig* cfg) {
+  if (!b || !cfg || mi < 0 || mi >= b->n_models) return fail(WBC_E_ARG, "wbc_batch_configure: bad arguments");
+  const int nv = b->models[mi]->blob.nv, nq = b->models[mi]->blob.nq;
+  if (cfg->task_joint < 0 || cfg->task_joint > WBC_JOINT_PREV) return fail(WBC_E_UNSUPPORTED, "posture mode %d not on the device path", cfg->task_joint);
+  if (!cfg->task_joint) return fail(WBC_E_UNSUPPORTED, "the posture task must be on: without it H = J'J is singular (Robot_Wrapper4.py:1199-1206)");
+  for (int i = 0; i < nv; ++i)
+    if (cfg->use_bounds && (cfg->damper_qidx[i] < 0 || cfg->damper_qidx[i] >= nq)) return fail(WBC_E_ARG, "damper_qidx[%d] = %d out of range", i, cfg->damper_qidx[i]);
+  int mcart = 0;
+  const int m = rows_task(*cfg, &mcart), p = rows_con(*cfg);
+  if (p > WBC_MAX_P) return fail(WBC_E_ARG, "too many constraint rows (%d)", p);
+  for (int j = 0; j < b->n_models; ++j)
+    if (j != mi && b->configured[j]) {
+      int mc2 = 0;
+      if (rows_task(b->cfg_host[j], &mc2) != m || rows_con(b->cfg_host[j]) != p || mc2 != mcart)
+        return fail(WBC_E_ARG, "all models of a batch must share the task/constraint switches");
+    }
+  HIP_TRY(hipSetDevice(b->device_id));
+  b->cfg_host[mi] = *cfg;
+  b->configured[mi] = true;
+  b->mrows = m; b->prows = p; b->mcart = mcart;
+  HIP_TRY(hipMemcpy(b->d_cfgs + mi, cfg, sizeof *cfg, hipMemcpyHostToDevice));
+  return WBC_OK;
+}
+
+extern "C" int wbc_task_rows(const WbcBatch* b) { return b ? b->mrows : WBC_E_ARG; }
+extern "C" int wbc_constraint_rows(const WbcBatch* b) { return b ? b->prows : WBC_E_ARG; }
+
+extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
+  if (!b || !name) return fail(WBC_E_ARG, "wbc_batch_set_option: null");
+  if (!strcmp(name, "jtj_mfma")) { b->jtj_mfma = value; return WBC_OK; }
+  if (!strcmp(name, "grid")) { if (value < 1) return fail(WBC_E_ARG, "grid must be >= 1"); b->grid = value; return WBC_OK; }
+  return fail(WBC_E_ARG, "unknown option %s", name);
+}
+
+extern "C" int wbc_batch_synchronize(WbcBatch* b, void* stream) {
+  if (!b) return fail(WBC_E_ARG, "null batch");
+  HIP_TRY(hipSetDevice(b->device_id));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return WBC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- staging
+// mem == WBC_MEM_HOST: inputs are copied into the batch workspace, outputs copied back after the launch.
+// mem == WBC_MEM_DEVICE: pointers pass through untouched (no copies, no synchronisation).
+struct Stager {
+  WbcBatch* b; int mem; hipStream_t s;
+  struct Item { void** slot; const void* host; size_t bytes; bool out; };
+  std::vector<Item> items;
+  template <class T> void in(const T** slot, size_t count) { add((void**)slot, count * sizeof(T), false); }
+  template <class T> void out(T** slot, size_t count) { add((void**)slot, count * sizeof(T), true); }
+  void add(void** slot, size_t bytes, bool is_out) {
+    if (mem == WBC_MEM_DEVICE || !*slot || !bytes) return;
+    items.push_back({slot, *slot, bytes, is_out});
+  }
+  int stage() {
+    if (mem == WBC_MEM_DEVICE) return WBC_OK;
+    size_t total = 0;
+    for (auto& it : items) total += (it.bytes + 255) & ~(size_t)255;
+    if (total > b->ws_bytes) {
+      if (b->ws) HIP_TRY(hipFree(b->ws));
+      b->ws = nullptr; b->ws_bytes = 0;
+      HIP_TRY(hipMalloc(&b->ws, total));
+      b->ws_bytes = total;
+    }
+    size_t off = 0;
+    for (auto& it : items) {
+      void* d = (char*)b->ws + off;
+      off += (it.bytes + 255) & ~(size_t)255;
+      if (!it.out) HIP_TRY(hipMemcpyAsync(d, it.host, it.bytes, hipMemcpyHostToDevice, s));
+      *it.slot = d;
+    }
+    return WBC_OK;
+  }
+  int finish() {
+    if (mem == WBC_MEM_DEVICE) return WBC_OK;
+    for (auto& it : items)
+      if (it.out) HIP_TRY(hipMemcpyAsync((void*)it.host, *it.slot, it.bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return WBC_OK;
+  }
+};
+
+static int check_batch(WbcBatch* b, int B, const char* who, bool need_cfg) {
+  if (!b) return fail(WBC_E_ARG, "%s: null batch", who);
+  if (B < 1 || B > b->max_batch) return fail(WBC_E_ARG, "%s: B = %d outside [1, max_batch = %d]", who, B, b->max_batch);
+  if (need_cfg)
+    for (int i = 0; i < b->n_models; ++i)
+      if (!b->configured[i]) return fail(WBC_E_STATE, "%s: model %d has no configuration (wbc_batch_configure)", who, i);
+  return WBC_OK;
+}
+static int grid_for(const WbcBatch* b, int B) { return B < b->grid ? B : b->grid; }
+
+static void stage_tick_in(Stager& st, WbcTickIn& in, int B, const WbcBatch* b) {
+  const size_t n = (size_t)B;
+  st.in(&in.q, n * WBC_Q_STRIDE);
+  st.in(&in.ee_target, n * 15); st.in(&in.prev_ee_target, n * 15);
+  st.in(&in.trunk_target, n * 3); st.in(&in.prev_trunk_target, n * 3);
+  st.in(&in.trunk_box_center, n * 4);
+  st.in(&in.ee_ref_rot, n * 45); st.in(&in.ee_prev_rot, n * 45);
+  st.in(&in.trunk_ref_euler, n * 3); st.in(&in.trunk_prev_rot, n * 9);
+  st.in(&in.com_target, n * 3); st.in(&in.com_target_vel, n * 3);
+  st.in(&in.model_id, n);
+  (void)b;
+}
+
+static int validate_tick_in(const WbcBatch* b, const WbcTickIn* in, const char* who) {
+  const WbcConfig& c = b->cfg_host[0];
+  if (!in || !in->q) return fail(WBC_E_ARG, "%s: q is required", who);
+  bool any_ee = false;
+  for (int i = 0; i < WBC_NEE; ++i) any_ee |= c.task_ee[i] != 0;
+  if (any_ee && (!in->ee_target || !in->prev_ee_target)) return fail(WBC_E_ARG, "%s: EE tasks need ee_target and prev_ee_target", who);
+  if ((in->ee_ref_rot != nullptr) != (in->ee_prev_rot != nullptr)) return fail(WBC_E_ARG, "%s: ee_ref_rot and ee_prev_rot go together", who);
+  if (c.task_trunk && (!in->trunk_target || !in->prev_trunk_target || !in->trunk_ref_euler || !in->trunk_prev_rot))
+    return fail(WBC_E_ARG, "%s: the trunk task needs trunk_target, prev_trunk_target, trunk_ref_euler, trunk_prev_rot", who);
+  if (c.con_trunk && !in->trunk_box_center) return fail(WBC_E_ARG, "%s: the trunk constraint needs trunk_box_center", who);
+  if (c.task_com && (!in->com_target || !in->com_target_vel)) return fail(WBC_E_ARG, "%s: the CoM task needs com_target and com_target_vel", who);
+  if (b->n_models > 1 && !in->model_id) return fail(WBC_E_ARG, "%s: model_id is required with %d models", who, b->n_models);
+  return WBC_OK;
+}
+
+static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
+  memset(&a, 0, sizeof a);
+  a.models = b->d_models; a.cfgs = b->d_cfgs;
+  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma; a.dt = dt;
+}
+
+// ---------------------------------------------------------------------------------------------- entry points
+extern "C" int wbc_fk_jacobians(WbcBatch* b, int B, const double* q, const int32_t* model_id, int mem,
+                                const WbcFkOut* out, void* stream) {
+  int rc = check_batch(b, B, "wbc_fk_jacobians", false);
+  if (rc) return rc;
+  if (!q || !out) return fail(WBC_E_ARG, "wbc_fk_jacobians: null argument");
+  if (b->n_models > 1 && !model_id) return fail(WBC_E_ARG, "wbc_fk_jacobians: model_id is required with %d models", b->n_models);
+  HIP_TRY(hipSetDevice(b->device_id));
+  KernelArgs a;
+  fill_args(a, b, B, 0.0);
+  if (!b->configured[0]) {   // FK needs no settings; give the kernel a zeroed config to read its (unused) switches from
+    WbcConfig z;
+    memset(&z, 0, sizeof z);
+    for (int i = 0; i < b->n_models; ++i)
+      if (!b->configured[i]) HIP_TRY(hipMemcpy(b->d_cfgs + i, &z, sizeof z, hipMemcpyHostToDevice));
+  }
+  a.in.q = q; a.in.model_id = model_id; a.fk = *out;
+  const int nj = b->models[0]->blob.njoints, nf = b->models[0]->blob.nframes;
+  Stager st{b, mem, (hipStream_t)stream, {}};
+  st.in(&a.in.q, (size_t)B * WBC_Q_STRIDE); st.in(&a.in.model_id, (size_t)B);
+  st.out(&a.fk.oMi, (size_t)B * nj * 12); st.out(&a.fk.oMf, (size_t)B * nf * 12);
+  st.out(&a.fk.J, (size_t)B * 6 * WBC_V_STRIDE); st.out(&a.fk.com, (size_t)B * 3); st.out(&a.fk.Jcom, (size_t)B * 3 * WBC_V_STRIDE);
+  if ((rc = st.stage())) return rc;
+  if (int e = launch_tick(a, MODE_FK, grid_for(b, B), stream)) return fail(WBC_E_HIP, "fk kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  return st.finish();
+}
+
+extern "C" int wbc_assemble(WbcBatch* b, int B, const WbcTickIn* in, double dt, int mem, const WbcQpData* out, void* stream) {
+  int rc = check_batch(b, B, "wbc_assemble", true);
+  if (rc) return rc;
+  if (!out || !(dt > 0)) return fail(WBC_E_ARG, "wbc_assemble: null output or dt <= 0");
+  if ((rc = validate_tick_in(b, in, "wbc_assemble"))) return rc;
+  HIP_TRY(hipSetDevice(b->device_id));
+  KernelArgs a;
+  fill_args(a, b, B, dt);
+  a.in = *in; a.qp = *out;
+  Stager st{b, mem, (hipStream_t)stream, {}};
+  stage_tick_in(st, a.in, B, b);
+  const size_t n = (size_t)B, m = b->mrows, p = b->prows, V = WBC_V_STRIDE;
+  st.out(&a.qp.A, n * m * V); st.out(&a.qp.b, n * m); st.out(&a.qp.H, n * V * V); st.out(&a.qp.g, n * V);
+  st.out(&a.qp.C, n * p * V); st.out(&a.qp.Clb, n * p); st.out(&a.qp.Cub, n * p); st.out(&a.qp.lb, n * V); st.out(&a.qp.ub, n * V);
+  if ((rc = st.stage())) return rc;
+  if (int e = launch_tick(a, MODE_ASSEMBLE, grid_for(b, B), stream)) return fail(WBC_E_HIP, "assemble kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  return st.finish();
+}
+
+extern "C" int wbc_tick(WbcBatch* b, int B, const WbcTickIn* in, double dt, int mem, const WbcTickOut* out, void* stream) {
+  int rc = check_batch(b, B, "wbc_tick", true);
+  if (rc) return rc;
+  if (!out || !out->qdot || !(dt > 0)) return fail(WBC_E_ARG, "wbc_tick: qdot output required and dt > 0");
+  if ((rc = validate_tick_in(b, in, "wbc_tick"))) return rc;
+  HIP_TRY(hipSetDevice(b->device_id));
+  KernelArgs a;
+  fill_args(a, b, B, dt);
+  a.in = *in; a.out = *out;
+  Stager st{b, mem, (hipStream_t)stream, {}};
+  stage_tick_in(st, a.in, B, b);
+  const size_t n = (size_t)B;
+  st.out(&a.out.qdot, n * WBC_V_STRIDE); st.out(&a.out.status, n); st.out(&a.out.iters, n); st.out(&a.out.q_next, n * WBC_Q_STRIDE);
+  if ((rc = st.stage())) return rc;
+  if (int e = launch_tick(a, MODE_TICK, grid_for(b, B), stream)) return fail(WBC_E_HIP, "tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  return st.finish();
+}
+
+static int qp_common(WbcBatch* b, int B, QpArgs& a, int mem, void* stream, const char* who) {
+  int rc = check_batch(b, B, who, false);
+  if (rc) return rc;
+  const int n = a.n, p = a.p, m = a.m;
+  if (n < 1 || n > WBC_MAX_NV || p < 0 || p > WBC_MAX_P || m < 0 || m > WBC_MAX_M) return fail(WBC_E_ARG, "%s: n = %d, p = %d, m = %d out of range", who, n, p, m);
+  if (!a.x) return fail(WBC_E_ARG, "%s: x output required", who);
+  if (p > 0 && (!a.C || !a.Clb || !a.Cub)) return fail(WBC_E_ARG, "%s: C, Clb, Cub required when p > 0", who);
+  if ((a.lb != nullptr) != (a.ub != nullptr)) return fail(WBC_E_ARG, "%s: lb and ub go together", who);
+  HIP_TRY(hipSetDevice(b->device_id));
+  Stager st{b, mem, (hipStream_t)stream, {}};
+  const size_t N = (size_t)B;
+  st.in(&a.H, N * n * n); st.in(&a.g, N * n); st.in(&a.A, N * m * n); st.in(&a.bvec, N * m);
+  st.in(&a.C, N * p * n); st.in(&a.lb, N * n); st.in(&a.ub, N * n); st.in(&a.Clb, N * p); st.in(&a.Cub, N * p);
+  st.out(&a.x, N * n); st.out(&a.status, N); st.out(&a.iters, N); st.out(&a.H_out, N * n * n); st.out(&a.g_out, N * n);
+  if ((rc = st.stage())) return rc;
+  if (int e = launch_qp(a, grid_for(b, B), stream)) return fail(WBC_E_HIP, "qp kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  return st.finish();
+}
+
+extern "C" int wbc_qp_solve(WbcBatch* b, int B, int n, int p, const double* H, const double* g, const double* C,
+                            const double* lb, const double* ub, const double* Clb, const double* Cub, int mem,
+                            double* x, int32_t* status, int32_t* iters, void* stream) {
+  if (!H || !g) return fail(WBC_E_ARG, "wbc_qp_solve: H and g required");
+  QpArgs a;
+  memset(&a, 0, sizeof a);
+  a.B = B; a.n = n; a.p = p; a.m = 0;
+  a.H = H; a.g = g; a.C = C; a.lb = lb; a.ub = ub; a.Clb = Clb; a.Cub = Cub; a.x = x; a.status = status; a.iters = iters;
+  return qp_common(b, B, a, mem, stream, "wbc_qp_solve");
+}
+
+extern "C" int wbc_qp_solve_ls(WbcBatch* b, int B, int m, int n, int p, const double* A, const double* bvec, const double* C,
+                               const double* lb, const double* ub, const double* Clb, const double* Cub, int mem, int use_mfma,
+                               double* x, int32_t* status, int32_t* iters, double* H_out, double* g_out, void* stream) {
+  if (!A || !bvec || m < 1) return fail(WBC_E_ARG, "wbc_qp_solve_ls: A, b and m >= 1 required");
+  QpArgs a;
+  memset(&a, 0, sizeof a);
+  a.B = B; a.n = n; a.p = p; a.m = m; a.use_mfma = use_mfma;
+  a.A = A; a.bvec = bvec; a.C = C; a.lb = lb; a.ub = ub; a.Clb = Clb; a.Cub = Cub;
+  a.x = x; a.status = status; a.iters = iters; a.H_out = H_out; a.g_out = g_out;
+  return qp_common(b, B, a, mem, stream, "wbc_qp_solve_ls");
+}
+
+extern "C" int wbc_integrate(WbcBatch* b, int B, const double* q, const double* v, const int32_t* model_id, double dt, int mem,
+                             double* q_next, void* stream) {
+  int rc = check_batch(b, B, "wbc_integrate", false);
+  if (rc) return rc;
+  if (!q || !v || !q_next) return fail(WBC_E_ARG, "wbc_integrate: null argument");
+  if (b->n_models > 1 && !model_id) return fail(WBC_E_ARG, "wbc_integrate: model_id is required with %d models", b->n_models);
+  HIP_TRY(hipSetDevice(b->device_id));
+  IntegrateArgs a;
+  memset(&a, 0, sizeof a);
+  a.models = b->d_models; a.B = B; a.dt = dt; a.q = q; a.v = v; a.model_id = model_id; a.q_next = q_next;
+  Stager st{b, mem, (hipStream_t)stream, {}};
+  st.in(&a.q, (size_t)B * WBC_Q_STRIDE); st.in(&a.v, (size_t)B * WBC_V_STRIDE); st.in(&a.model_id, (size_t)B);
+  st.out(&a.q_next, (size_t)B * WBC_Q_STRIDE);
+  if ((rc = st.stage())) return rc;
+  if (int e = launch_integrate(a, grid_for(b, B), stream)) return fail(WBC_E_HIP, "integrate kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  return st.finish();
+}
+
+extern "C" const char* wbc_last_error(void) { return g_err; }
+extern "C" const char* wbc_version(void) { return "wbc-hip 0.1 (gfx950)"; }
+extern "C" int wbc_abi_sizes(int32_t* sb, int32_t* sc) {
+  if (sb) *sb = (int32_t)sizeof(WbcModelBlob);
+  if (sc) *sc = (int32_t)sizeof(WbcConfig);
+  return WBC_OK;
+}

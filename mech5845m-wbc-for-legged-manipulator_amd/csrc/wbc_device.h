@@ -1,0 +1,68 @@
+// wbc_device.h — host-visible description of what the gfx950 kernels consume (internal, C++).
+#pragma once
+#include <stdint.h>
+#include "../../include/wbc.h"
+
+namespace wbc {
+
+constexpr int NV = WBC_V_STRIDE;   // 26: QP size, lanes 0..25 of the wavefront carry one DoF each
+constexpr int NQ = WBC_Q_STRIDE;   // 27
+constexpr int NL = 32;             // per-lane model tables are padded to 32 entries
+
+// One kinematic model, flattened for "lane j = joint j" and "lane k = velocity column k" access.
+// Built by wbc_model_create from WbcModelBlob; lives in device global memory (tiny, L2 resident).
+struct DevModel {
+  int32_t nq, nv, njoints, maxdepth, nframes, pad_[3];
+  // joint lanes
+  int32_t parent[NL], depth[NL], jtype[NL], idx_q[NL];
+  int32_t ax0[NL], ax1[NL], ax2[NL];   // rotation axis a and its cyclic successors (columns 3*a of the stored R)
+  double tp[NL][3];                    // placement translation permuted to (a, a1, a2) order
+  double mass[NL], com[NL][3];
+  // column lanes
+  int32_t col_joint[NL], col_lin[NL], col_ang[NL], col_q[NL];   // local axis index (-1: none); q index of 1-DoF joints
+  uint32_t col_subtree[NL];            // joints in the subtree of the column's joint (CoM Jacobian)
+  // controller frames (role order WBC_FR_*)
+  int32_t frame_joint[WBC_MAX_FRAMES];
+  double frame_p[WBC_MAX_FRAMES][3];
+  uint32_t frame_support[WBC_MAX_FRAMES];  // bit k: column k moves the frame
+  double total_mass;
+};
+
+enum Mode : int { MODE_TICK = 0, MODE_ASSEMBLE = 1, MODE_FK = 2 };
+
+struct KernelArgs {
+  const DevModel* models;
+  const WbcConfig* cfgs;
+  int32_t B, mrows, prows, mcart;   // mcart = Cartesian task rows (excludes the diagonal posture block)
+  int32_t jtj_mfma, pad0;
+  double dt;
+  WbcTickIn in;
+  WbcTickOut out;
+  WbcQpData qp;
+  WbcFkOut fk;
+};
+
+struct QpArgs {
+  int32_t B, n, p, m;               // m > 0: least-squares form (A, b given)
+  int32_t use_mfma, pad0;
+  const double *H, *g, *A, *bvec, *C, *lb, *ub, *Clb, *Cub;
+  double *x, *H_out, *g_out;
+  int32_t *status, *iters;
+};
+
+struct IntegrateArgs {
+  const DevModel* models;
+  int32_t B, pad0;
+  double dt;
+  const double *q, *v;
+  const int32_t* model_id;
+  double* q_next;
+};
+
+// launchers (wbc_kernels.hip); grid = min(B, waves) persistent single-wave workgroups
+int launch_tick(const KernelArgs& a, int mode, int grid, void* stream);
+int launch_qp(const QpArgs& a, int grid, void* stream);
+int launch_integrate(const IntegrateArgs& a, int grid, void* stream);
+int tick_lds_bytes();
+
+}  // namespace wbc

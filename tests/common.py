@@ -1,0 +1,96 @@
+"""Shared helpers for the tests: models, configurations of BASELINE.json, oracle-backed FK for input generation."""
+import numpy as np
+
+import oracle
+import wbc_capi as capi
+import wbc_model
+import wbc_workload
+
+
+class OracleFK:
+    """fk callable for wbc_workload.make_tick_inputs backed by the CPU oracle."""
+
+    def __init__(self, models, model_id=None):
+        self.models, self.model_id = models, model_id
+
+    def __call__(self, q):
+        return oracle.fk(self.models, q, self.model_id, want_com=False)["oMf"]
+
+    def com(self, q):
+        return oracle.fk(self.models, q, self.model_id)["com"]
+
+
+def models():
+    return wbc_model.load_model("a1_wx200"), wbc_model.load_model("a1_px100_pin_ver")
+
+
+def config(name, model):
+    """BASELINE.json configs: c1/c3 = sim3 switch set, c2 = equality-only, full = every task on."""
+    if name in ("c1", "c3"):
+        return wbc_model.sim3_config(model)
+    if name == "c2":
+        return wbc_model.equality_only_config(model)
+    if name == "full":   # the warm-up problem of setInitialState: all 6 Cartesian tasks + Tikhonov, bounds only
+        return wbc_model.make_config(model, Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=True)
+    if name == "everything":  # every task and every constraint type at once (coverage, not a reference preset)
+        return wbc_model.make_config(model, Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint="PREV",
+                                     task_com=True, cCoM=True, cTrunk=True, cFR=True, cFL=True, cRR=True, cRL=True,
+                                     mode="static_reach")
+    raise KeyError(name)
+
+
+def tick_inputs(model, cfg, B, seed, stress=True, with_rot=False):
+    d = wbc_workload.make_tick_inputs(model, cfg, B, seed, OracleFK([model]), stress=stress)
+    if with_rot:   # exercise the orientation feed-forward terms with a moving reference
+        rng = np.random.default_rng(seed + 1000)
+        from scipy.spatial.transform import Rotation as R
+        e = rng.uniform(-0.3, 0.3, (B, 5, 3))
+        de = rng.normal(0, 1e-3, (B, 5, 3))
+        d["ee_ref_rot"] = R.from_euler("xyz", e.reshape(-1, 3)).as_matrix().reshape(B, 5, 9)
+        d["ee_prev_rot"] = R.from_euler("xyz", (e - de).reshape(-1, 3)).as_matrix().reshape(B, 5, 9)
+        d["trunk_ref_euler"] = d["trunk_ref_euler"] + rng.normal(0, 0.02, (B, 3))
+        d["trunk_prev_rot"] = R.from_euler("xyz", d["trunk_ref_euler"] - rng.normal(0, 1e-3, (B, 3))).as_matrix().reshape(B, 9)
+    return d
+
+
+def kkt_residuals(H, g, C, lb, ub, cl, cu, x, act_tol=1e-7):
+    """Solver-independent optimality certificate: (primal violation, stationarity residual with sign-correct multipliers)."""
+    from scipy.optimize import lsq_linear
+    n = len(g)
+    viol = 0.0
+    if lb is not None:
+        viol = max(viol, (lb - x).max(), (x - ub).max())
+    if C is not None and len(cl):
+        v = C @ x
+        viol = max(viol, (cl - v).max(), (v - cu).max())
+    r = H @ x + g
+    rows, free_sign = [], []
+    if lb is not None:
+        for k in range(n):
+            e = np.zeros(n)
+            e[k] = 1
+            if lb[k] == ub[k]:
+                rows.append(e), free_sign.append(True)
+            else:
+                if abs(x[k] - lb[k]) < act_tol * max(1, abs(lb[k])):
+                    rows.append(e), free_sign.append(False)
+                if abs(x[k] - ub[k]) < act_tol * max(1, abs(ub[k])):
+                    rows.append(-e), free_sign.append(False)
+    if C is not None and len(cl):
+        v = C @ x
+        for i in range(len(cl)):
+            if cl[i] == cu[i]:
+                rows.append(C[i]), free_sign.append(True)
+            else:
+                if abs(v[i] - cl[i]) < act_tol * max(1, abs(cl[i])):
+                    rows.append(C[i]), free_sign.append(False)
+                if abs(v[i] - cu[i]) < act_tol * max(1, abs(cu[i])):
+                    rows.append(-C[i]), free_sign.append(False)
+    if rows:
+        N = np.array(rows).T
+        lo = [-np.inf if f else 0.0 for f in free_sign]
+        res = lsq_linear(N, r, bounds=(lo, np.inf), tol=1e-14)
+        stat = np.abs(N @ res.x - r).max()
+    else:
+        stat = np.abs(r).max()
+    return viol, stat

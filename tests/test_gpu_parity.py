@@ -1,0 +1,208 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (ctypes), against the CPU oracle on identical inputs.
+
+Tolerances: fp64 throughout. Kinematics / assembly agree to rounding (1e-11 relative); the QP solution is compared at
+the 1e-5 max-abs bound BASELINE.json states for q̇ (cond(H) ~ 3e9 makes ~1e-7 the realistic floor between two
+different but exact solvers: textbook Givens/R on the CPU vs Householder/R^-1 on the wavefront).
+"""
+import numpy as np
+import pytest
+
+import common
+import oracle
+import wbc_capi as capi
+import wbc_model
+from wbc_batch import WbcBatch
+
+pytestmark = pytest.mark.gpu
+DT = 0.002
+QDOT_TOL = 1e-5          # north_star: "within 1e-5 max-abs on identical inputs"
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+@pytest.fixture(scope="module")
+def wx200():
+    return wbc_model.load_model("a1_wx200")
+
+
+@pytest.fixture(scope="module")
+def px100():
+    return wbc_model.load_model("a1_px100_pin_ver")
+
+
+def test_library_reports_gfx950_build():
+    lib = capi.load_library()
+    assert b"gfx950" in lib.wbc_version()
+
+
+@pytest.mark.parametrize("name", ["a1_wx200", "a1_px100_pin_ver"])
+def test_fk_jacobians_parity(name):
+    m = wbc_model.load_model(name)
+    rng = np.random.default_rng(3)
+    import wbc_workload
+    q = wbc_workload.sample_q(m, 300, rng)
+    q[0] = m.neutral()
+    ref = oracle.fk([m], q)
+    bt = WbcBatch(m, 512)
+    got = bt.fk(q)
+    for k in ("oMi", "oMf", "J", "com", "Jcom"):
+        assert np.abs(got[k] - ref[k]).max() < 1e-12, k
+    bt.close()
+
+
+@pytest.mark.parametrize("cfg_name,with_rot", [("c1", False), ("c2", False), ("full", True), ("everything", True)])
+def test_assemble_parity(wx200, cfg_name, with_rot):
+    cfg = common.config(cfg_name, wx200)
+    B = 200
+    d = common.tick_inputs(wx200, cfg, B, seed=11, with_rot=with_rot)
+    ref = oracle.assemble([wx200], [cfg], d, DT, B)
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    assert bt.task_rows == ref["A"].shape[1] and bt.constraint_rows == ref["C"].shape[1]
+    got = bt.assemble(d, DT)
+    for k in ("A", "b", "H", "g", "C", "Clb", "Cub", "lb", "ub"):
+        assert got[k].shape == ref[k].shape, k
+        assert relerr(got[k], ref[k]) < 1e-11, (k, relerr(got[k], ref[k]))
+    bt.close()
+
+
+def _random_qps(rng, B, n, p, n_eq):
+    A = rng.normal(size=(B, n + 6, n))
+    H = np.einsum("bmi,bmj->bij", A, A) + 1e-3 * np.eye(n)
+    g = rng.normal(size=(B, n)) * 4
+    C = rng.normal(size=(B, p, n))
+    lb, ub = -rng.uniform(0.02, 0.8, (B, n)), rng.uniform(0.02, 0.8, (B, n))
+    lb[:, -2:] = 0.0
+    ub[:, -2:] = 0.0
+    cl, cu = -rng.uniform(0.02, 0.8, (B, p)), rng.uniform(0.02, 0.8, (B, p))
+    cl[:, :n_eq] = cu[:, :n_eq] = rng.normal(size=(B, n_eq)) * 0.1
+    return H, g, C, lb, ub, cl, cu
+
+
+@pytest.mark.parametrize("n,p,n_eq", [(26, 16, 12), (25, 10, 4), (12, 6, 2), (26, 0, 0), (3, 2, 0)])
+def test_qp_parity_random(wx200, n, p, n_eq):
+    rng = np.random.default_rng(100 + n)
+    B = 300
+    H, g, C, lb, ub, cl, cu = _random_qps(rng, B, n, p, n_eq)
+    bt = WbcBatch(wx200, B)
+    if p:
+        x, st, it = bt.qp_solve(H, g, C, lb, ub, cl, cu)
+        xr, sr, ir = oracle.qp_solve(H, g, C, lb, ub, cl, cu)
+    else:
+        x, st, it = bt.qp_solve(H, g, None, lb, ub)
+        xr, sr, ir = oracle.qp_solve(H, g, None, lb, ub)
+    assert (st == sr).all(), np.nonzero(st != sr)
+    ok = sr == 0
+    assert ok.sum() > B // 2
+    assert np.abs(x[ok] - xr[ok]).max() < 1e-9
+    bt.close()
+
+
+def test_qp_ls_forms_H_and_g(wx200):
+    """QP(A, b, ...) boundary: H = A'A and g = -A'b formed on the device equal numpy's (QP_Wrapper.py:17-18)."""
+    rng = np.random.default_rng(5)
+    B, m, n, p = 64, 32, 26, 16
+    A = rng.normal(size=(B, m, n))
+    A[:, 6:, :] = 0
+    A[:, 6:, :] += np.eye(n)[None] * 0.03
+    b = rng.normal(size=(B, m))
+    C = rng.normal(size=(B, p, n))
+    lb, ub = -np.ones((B, n)), np.ones((B, n))
+    cl, cu = -np.ones((B, p)) * 0.3, np.ones((B, p)) * 0.3
+    bt = WbcBatch(wx200, B)
+    for mfma in (False, True):
+        x, st, it, Ho, go = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu, use_mfma=mfma, want_Hg=True)
+        Hr = np.einsum("bmi,bmj->bij", A, A)
+        gr = -np.einsum("bmi,bm->bi", A, b)
+        assert relerr(Ho, Hr) < 1e-13 and relerr(go, gr) < 1e-13
+        xr, sr, _ = oracle.qp_solve(Hr, gr, C, lb, ub, cl, cu)
+        assert (st == sr).all()
+        assert np.abs(x - xr)[sr == 0].max() < 1e-7
+    bt.close()
+
+
+@pytest.mark.parametrize("cfg_name,B,with_rot", [("c1", 1, False), ("c2", 1024, False), ("c3", 4096, False),
+                                                 ("full", 512, True), ("everything", 512, True)])
+def test_tick_parity(wx200, cfg_name, B, with_rot):
+    cfg = common.config(cfg_name, wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=21, with_rot=with_rot)
+    ref = oracle.tick([wx200], [cfg], d, DT, B, nthreads=8)
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    got = bt.tick(d, DT, want_q_next=True)
+    assert (got["status"] == ref["status"]).all()
+    ok = ref["status"] == 0
+    assert ok.mean() > 0.9
+    err = np.abs(got["qdot"] - ref["qdot"])[ok].max()
+    print("%s: qdot max-abs err %.3e, iters gpu mean %.2f / oracle %.2f" % (cfg_name, err, got["iters"].mean(), ref["iters"].mean()))
+    assert err < QDOT_TOL
+    assert np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    bt.close()
+
+
+def test_tick_mixed_morphology(wx200, px100):
+    """BASELINE config 5: wx200 (nv 26) and px100 (nv 25, padded DoF) interleaved lane by lane."""
+    B = 1024
+    models = [wx200, px100]
+    cfgs = [common.config("c3", m) for m in models]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=31 + i) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    got = bt.tick(d, DT, want_q_next=True)
+    assert (got["status"] == ref["status"]).all()
+    ok = ref["status"] == 0
+    assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+    assert (got["qdot"][mid == 1, 25] == 0).all()
+    assert np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    bt.close()
+
+
+def test_integrate_parity(wx200):
+    rng = np.random.default_rng(9)
+    import wbc_workload
+    B = 256
+    q = wbc_workload.sample_q(wx200, B, rng)
+    v = rng.normal(size=(B, 26)) * 2
+    v[:8, 3:6] = 0                       # exercise the small-angle branch
+    ref = oracle.integrate([wx200], q, v, DT)
+    bt = WbcBatch(wx200, B)
+    got = bt.integrate(q, v, DT)
+    assert np.abs(got - ref).max() < 1e-13
+    big = rng.normal(size=(B, 26)) * 300  # large rotations per step: exercises every quaternion branch
+    assert np.abs(bt.integrate(q, big, DT) - oracle.integrate([wx200], q, big, DT)).max() < 1e-12
+    bt.close()
+
+
+def test_full_size_properties(wx200):
+    """BASELINE's full single-GPU size (B = 65536, config 3): size-independent certificates on every instance
+    (contact rows satisfied, bounds and box rows respected) + oracle parity on a random subsample."""
+    B = 65536
+    cfg = common.config("c3", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=41)
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    got = bt.tick(d, DT)
+    a = bt.assemble(d, DT, want=("C", "Clb", "Cub", "lb", "ub"))
+    ok = got["status"] == 0
+    assert ok.mean() > 0.98
+    x = got["qdot"]
+    Cx = np.einsum("bpn,bn->bp", a["C"], x)
+    scale = 1 + np.abs(x).max(axis=1, keepdims=True)
+    assert (np.abs(Cx[:, 4:])[ok] / scale[ok]).max() < 1e-8                     # 12 contact equalities
+    assert ((a["Clb"] - Cx)[ok] / scale[ok]).max() < 1e-8 and ((Cx - a["Cub"])[ok] / scale[ok]).max() < 1e-8
+    assert ((a["lb"] - x)[ok]).max() < 1e-8 and ((x - a["ub"])[ok]).max() < 1e-8
+    rng = np.random.default_rng(0)
+    idx = rng.choice(B, 1024, replace=False)
+    sub = {k: v[idx] for k, v in d.items()}
+    ref = oracle.tick([wx200], [cfg], sub, DT, len(idx), nthreads=8)
+    assert (ref["status"] == got["status"][idx]).all()
+    good = ref["status"] == 0
+    assert np.abs(ref["qdot"] - x[idx])[good].max() < QDOT_TOL
+    bt.close()
