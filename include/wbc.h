@@ -174,7 +174,8 @@ typedef struct WbcBatch WbcBatch;
 int wbc_model_create(const WbcModelBlob* blob, WbcModel** out);
 void wbc_model_destroy(WbcModel* m);
 
-/* one handle per device/stream: device workspace for up to max_batch instances. */
+/* one handle per device/stream: device workspace for up to max_batch instances.
+ * n_models == 0 gives a QP-only handle (wbc_qp_solve / wbc_qp_solve_ls), as QP_Wrapper.QP needs no robot model. */
 int wbc_batch_create(const WbcModel* const* models, int n_models, int max_batch, int device_id, WbcBatch** out);
 void wbc_batch_destroy(WbcBatch* b);
 

@@ -116,7 +116,7 @@ extern "C" void wbc_model_destroy(WbcModel* m) { delete m; }
 
 // ---------------------------------------------------------------------------------------------- batch
 extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int max_batch, int device_id, WbcBatch** out) {
-  if (!models || !out || n_models < 1 || n_models > WBC_MAX_MODELS || max_batch < 1)
+  if (!out || n_models < 0 || n_models > WBC_MAX_MODELS || (n_models > 0 && !models) || max_batch < 1)
     return fail(WBC_E_ARG, "wbc_batch_create: bad arguments (n_models %d, max_batch %d)", n_models, max_batch);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -137,9 +137,11 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   HIP_TRY(hipGetDeviceProperties(&prop, device_id));
   const int per_cu = (int)(prop.maxSharedMemoryPerMultiProcessor / (size_t)tick_lds_bytes());
   b->grid = prop.multiProcessorCount * (per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu));
-  HIP_TRY(hipMalloc((void**)&b->d_models, sizeof(DevModel) * n_models));
-  HIP_TRY(hipMalloc((void**)&b->d_cfgs, sizeof(WbcConfig) * n_models));
-  HIP_TRY(hipMemcpy(b->d_models, dm.data(), sizeof(DevModel) * n_models, hipMemcpyHostToDevice));
+  if (n_models > 0) {   // n_models == 0: a QP-only handle (wbc_qp_solve / wbc_qp_solve_ls)
+    HIP_TRY(hipMalloc((void**)&b->d_models, sizeof(DevModel) * n_models));
+    HIP_TRY(hipMalloc((void**)&b->d_cfgs, sizeof(WbcConfig) * n_models));
+    HIP_TRY(hipMemcpy(b->d_models, dm.data(), sizeof(DevModel) * n_models, hipMemcpyHostToDevice));
+  }
   *out = b;
   return WBC_OK;
 }
@@ -249,8 +251,9 @@ struct Stager {
   }
 };
 
-static int check_batch(WbcBatch* b, int B, const char* who, bool need_cfg) {
+static int check_batch(WbcBatch* b, int B, const char* who, bool need_cfg, bool need_model = true) {
   if (!b) return fail(WBC_E_ARG, "%s: null batch", who);
+  if (need_model && b->n_models < 1) return fail(WBC_E_STATE, "%s: this handle was created without a model", who);
   if (B < 1 || B > b->max_batch) return fail(WBC_E_ARG, "%s: B = %d outside [1, max_batch = %d]", who, B, b->max_batch);
   if (need_cfg)
     for (int i = 0; i < b->n_models; ++i)
@@ -358,7 +361,7 @@ extern "C" int wbc_tick(WbcBatch* b, int B, const WbcTickIn* in, double dt, int 
 }
 
 static int qp_common(WbcBatch* b, int B, QpArgs& a, int mem, void* stream, const char* who) {
-  int rc = check_batch(b, B, who, false);
+  int rc = check_batch(b, B, who, false, false);
   if (rc) return rc;
   const int n = a.n, p = a.p, m = a.m;
   if (n < 1 || n > WBC_MAX_NV || p < 0 || p > WBC_MAX_P || m < 0 || m > WBC_MAX_M) return fail(WBC_E_ARG, "%s: n = %d, p = %d, m = %d out of range", who, n, p, m);

@@ -1,0 +1,142 @@
+"""GPU: the reference-shaped Python classes (QP_Wrapper.QP, Robot_Wrapper4.RobotModel) at B = 1 against the oracle,
+and the HIP path against the committed golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+import oracle
+import wbc_capi as capi
+import wbc_model
+
+pytestmark = pytest.mark.gpu
+DT = 0.002
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_qp_class_matches_reference_surface_and_oracle():
+    from QP_Wrapper import QP
+    wx = wbc_model.load_model("a1_wx200")
+    cfg = common.config("c1", wx)
+    d = common.tick_inputs(wx, cfg, 3, seed=50)
+    a = oracle.assemble([wx], [cfg], d, DT, 3)
+    ref = oracle.tick([wx], [cfg], d, DT, 3)
+    A, b, C = a["A"][0], a["b"][0], a["C"][0]
+    Cview = C.T                                        # what findConstraints returns (Robot_Wrapper4.py:836)
+    qp = QP(A, b, a["lb"][0], a["ub"][0], Cview, a["Clb"][0], a["Cub"][0], n_of_velocity_dimensions=26)
+    x = qp.solveQP()
+    assert x is qp.xOpt and x.shape == (26,) and qp.status == 0
+    assert np.abs(x - ref["qdot"][0]).max() < 1e-5
+    assert np.abs(qp.H - A.T @ A).max() < 1e-12 and np.abs(qp.g + A.T @ b).max() < 1e-12      # QP_Wrapper.py:17-18
+    for k in (1, 2):                                   # hotstart: new H, g, C each call; the same ndarray comes back
+        y = qp.solveQPHotstart(a["A"][k], a["b"][k], a["lb"][k], a["ub"][k], a["C"][k].T, a["Clb"][k], a["Cub"][k])
+        assert y is x
+        assert np.abs(y - ref["qdot"][k]).max() < 1e-5
+        assert int(qp.nWSR[0]) == int(ref["iters"][k])
+    # bounds-only problem (QProblemB branch, QP_Wrapper.py:25-26) and the 2n-long bound vectors of Robot_Wrapper2
+    qb = QP(A, b, np.concatenate([a["lb"][0], a["lb"][0]]), np.concatenate([a["ub"][0], a["ub"][0]]), n_of_velocity_dimensions=26)
+    xb = qb.solveQP()
+    xr, st, _ = oracle.qp_solve(A.T @ A, -A.T @ b, None, a["lb"][0], a["ub"][0])
+    assert st == 0 and np.abs(xb - xr).max() < 1e-5
+    qm = QP(A, b, a["lb"][0], a["ub"][0], Cview, a["Clb"][0], a["Cub"][0], n_of_velocity_dimensions=26)
+    qm.use_mfma = True                                  # J'J on the fp64 matrix cores: same answer
+    assert np.abs(qm.solveQP() - ref["qdot"][0]).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", ["tick_c1", "tick_c2", "tick_c3", "tick_c5_mixed", "tick_everything"])
+def test_hip_path_reproduces_golden_fixtures(name):
+    from wbc_batch import WbcBatch
+    z = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    wx, px = common.models()
+    d = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    B = d["q"].shape[0]
+    mixed = "model_id" in d
+    models = [wx, px] if mixed else [wx]
+    cfg_name = {"tick_c1": "c1", "tick_c2": "c2", "tick_c3": "c3", "tick_c5_mixed": "c3", "tick_everything": "everything"}[name]
+    bt = WbcBatch(models, B)
+    for i, m in enumerate(models):
+        bt.configure(common.config(cfg_name, m), i)
+    out = bt.tick(d, DT)
+    assert (out["status"] == z["out_status"]).all()
+    assert np.abs(out["qdot"] - z["out_qdot"]).max() < 1e-5
+    if not mixed:
+        a = bt.assemble(d, DT)
+        for k in ("H", "g", "C", "lb", "ub"):
+            assert np.abs(a[k] - z["asm_" + k]).max() < 1e-11 * max(1, np.abs(z["asm_" + k]).max())
+    bt.close()
+
+
+@pytest.fixture(scope="module")
+def robot():
+    from Robot_Wrapper4 import RobotModel
+    r = wbc_model.A1_ROLES
+    return RobotModel("/any/where/a1_wx200.urdf", "/unused/meshes", r["EE_frame_names"], r["EE_joint_names"], r["G_base"],
+                      r["imu"], "FR_hip_joint", r["hip_waist_joint_names"], foot_offset=True)
+
+
+def test_robot_model_warm_up_reaches_the_crouched_stance(robot):
+    """setInitialState (Robot_Wrapper4.py:196-351): 2000 bounds-only QPs drag the neutral pose to the stance."""
+    rm = robot
+    assert rm.initialised and rm.foot_radius == 0.02
+    q = rm.current_joint_config
+    assert q.shape == (27,) and abs(np.linalg.norm(q[3:7]) - 1) < 1e-6 and np.abs(q[3:6]).max() == 0
+    feet_z = [rm.EE_frame_pos[i][2] for i in range(4)]
+    assert max(feet_z) - min(feet_z) < 5e-3                      # all four feet on one plane
+    assert abs(np.mean(feet_z) + 0.02 - 0.0) < 1e-9              # trunk height = -mean(foot z) + foot radius (:336-337)
+    assert 0.25 < q[2] < 0.40                                    # 0.9 x the neutral leg length
+    assert (q[7:19] > rm.robot_model.lowerPositionLimit[7:19] - 1e-6).all() and (q[7:19] < rm.robot_model.upperPositionLimit[7:19] + 1e-6).all()
+    assert len(rm.FL_leg) == 3 and len(rm.grip) == 8
+    # the gripper went up and forward of its neutral position (multiplier_G, :240-241, :252-261)
+    assert rm.EE_frame_pos[4][2] - q[2] > 0.15
+
+
+def test_robot_model_tick_matches_oracle(robot):
+    """sim3's call sequence (sim3.py:145-148, 197, 269, 314) on the mirror; every quantity re-derived by the oracle."""
+    rm = robot
+    rm.setTasks(Grip=True, Joint="PREV")
+    rm.setConstraints(Trunk=True, FR=True, FL=True, RR=True, RL=True)
+    rm.staticReachMode()
+    imu = np.array([0.01, -0.02, 0.005, 1.0])
+    imu /= np.linalg.norm(imu)
+    rm.initialiseWBC(imu)
+    wx = rm._model
+    EE_target = [rm.prev_EE_pos[i].reshape(3, 1).copy() for i in range(5)]
+    trunk_target = rm.robot_data.oMf[rm.trunk_frame_index].translation.reshape(3, 1).copy()
+    for tick in range(3):
+        EE_target[4] = EE_target[4] + np.array([[0.0005], [0.0002], [0.0004]])
+        cfg = rm._config()
+        d = rm._tick_inputs(EE_target, trunk_target)
+        a = oracle.assemble([wx], [cfg], d, rm.step_time, 1)
+        ref = oracle.tick([wx], [cfg], d, rm.step_time, 1)
+        # accessors = what the reference's runWBC gathers (:1348-1361)
+        A = rm.qpA()
+        Ct, Clb, Cub = rm.findConstraints()
+        lb, ub = rm.velDamperJointConstraints()
+        assert A.shape == (32, 26) and Ct.shape == (26, 16)
+        assert np.abs(A - a["A"][0]).max() < 1e-12 and np.abs(Ct.T - a["C"][0]).max() < 1e-12
+        assert np.abs(Clb - a["Clb"][0]).max() < 1e-9 and np.abs(lb - a["lb"][0]).max() < 1e-12 and np.abs(ub - a["ub"][0]).max() < 1e-12
+        FL, FR, RL, RR, grip = rm.runWBC(imu, target_cartesian_pos_EE=EE_target, target_cartesian_pos_trunk=trunk_target)
+        assert rm.solver_status == 0
+        assert np.abs(rm.q_vel - ref["qdot"][0]).max() < 1e-5
+        joints = ref["q_next"][0, 7:]
+        assert np.abs(np.concatenate([FL, FR, RL, RR, grip]) - joints).max() < 1e-7
+        assert (len(FL), len(FR), len(RL), len(RR), len(grip)) == (3, 3, 3, 3, 8)
+        # updateState(running=True): base xyz re-estimated from the stance feet (:414-415, :1297-1327), quaternion = IMU
+        q = rm.current_joint_config
+        assert np.abs(q[3:7] - imu).max() == 0 and np.abs(q[7:] - joints).max() == 0
+        feet = np.array([rm.EE_frame_pos[i] for i in range(4)])
+        tgt = np.array([np.asarray(EE_target[i]).reshape(3) for i in range(4)])
+        assert np.abs(feet.mean(0) - tgt.mean(0)).max() < 1e-9
+        assert np.abs(np.asarray(rm.prev_EE_pos[4]).reshape(3) - EE_target[4].reshape(3)).max() == 0
+    # single-block accessors
+    rm.endEffectorA2(4)
+    Jg = oracle.frame_jacobian(wx, np.concatenate([rm.current_joint_config]), frame=4, rf=2)
+    assert np.abs(rm.EE_A_list[4] - Jg).max() < 1e-12
+    C, l, u = rm.EEConstraint(1)
+    assert np.abs(C - oracle.frame_jacobian(wx, rm.current_joint_config, frame=1, rf=0)[:3]).max() < 1e-12 and not l.any() and not u.any()
+    C, l, u = rm.CoMConstraint()
+    assert np.abs(C - oracle.fk([wx], rm.current_joint_config[None])["Jcom"][0, :2]).max() < 1e-12
+    with pytest.raises(NotImplementedError):
+        rm.setTasks(Grip=True, Joint="HYBRID")
+        rm.qpA()

@@ -1,0 +1,132 @@
+"""CPU: certifies the oracle's QP (Goldfarb–Idnani restatement) independently of how it iterates: KKT residuals with
+sign-correct multipliers, scipy.optimize cross-solves, the toy problem of the reference's tests_NOT_FOR_USE/qp_tests.py,
+infeasibility detection; and checks the algebra of the wavefront variant (tests/gi_variant.py) against it."""
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+import common
+import gi_variant
+import oracle
+
+DT = 0.002
+
+
+def _random_qp(rng, n=None, p=None):
+    n = n or int(rng.integers(3, 27))
+    p = int(rng.integers(0, 16)) if p is None else p
+    A = rng.normal(size=(n + int(rng.integers(0, 10)), n))
+    H = A.T @ A + 1e-3 * np.eye(n)
+    g = rng.normal(size=n) * 4
+    C = rng.normal(size=(p, n)) if p else None
+    lb, ub = -rng.uniform(0.02, 0.8, n), rng.uniform(0.02, 0.8, n)
+    k = rng.integers(0, n, 2)
+    lb[k] = ub[k] = 0
+    if p:
+        cl, cu = -rng.uniform(0.02, 0.8, p), rng.uniform(0.02, 0.8, p)
+        ne = min(p, max(0, (n - 3) // 3))
+        cl[:ne] = cu[:ne] = rng.normal(size=ne) * 0.1
+    else:
+        cl = cu = None
+    return H, g, C, lb, ub, cl, cu
+
+
+def test_kkt_certificate_on_random_qps():
+    rng = np.random.default_rng(0)
+    solved = 0
+    for _ in range(300):
+        H, g, C, lb, ub, cl, cu = _random_qp(rng)
+        x, st, it = oracle.qp_solve(H, g, C, lb, ub, cl, cu)
+        if st != 0:
+            continue
+        solved += 1
+        viol, stat = common.kkt_residuals(H, g, C, lb, ub, cl, cu, x)
+        assert viol < 1e-8 and stat < 1e-8
+    assert solved > 280
+
+
+def test_against_scipy_slsqp():
+    rng = np.random.default_rng(1)
+    agreed = 0
+    for _ in range(40):
+        H, g, C, lb, ub, cl, cu = _random_qp(rng, n=8, p=4)
+        x, st, _ = oracle.qp_solve(H, g, C, lb, ub, cl, cu)
+        if st != 0:
+            continue
+        cons = []
+        for i in range(4):
+            if cl[i] == cu[i]:
+                cons.append({"type": "eq", "fun": lambda z, i=i: C[i] @ z - cl[i]})
+            else:
+                cons.append({"type": "ineq", "fun": lambda z, i=i: C[i] @ z - cl[i]})
+                cons.append({"type": "ineq", "fun": lambda z, i=i: cu[i] - C[i] @ z})
+        res = minimize(lambda z: 0.5 * z @ H @ z + g @ z, np.zeros(8), jac=lambda z: H @ z + g, bounds=list(zip(lb, ub)),
+                       constraints=cons, method="SLSQP", options={"ftol": 1e-13, "maxiter": 500})
+        if not res.success:      # SLSQP's line search gives up on some instances (fixed variables): not a verdict on the oracle
+            continue
+        agreed += 1
+        f_or, f_sp = 0.5 * x @ H @ x + g @ x, res.fun
+        assert f_or <= f_sp + 1e-9            # the oracle is at least as good as SLSQP ...
+        assert np.abs(x - res.x).max() < 1e-5  # ... and they agree on the unique minimiser
+    assert agreed >= 15
+
+
+def test_reference_toy_qp():
+    """tests_NOT_FOR_USE/qp_tests.py:4-13, restated literally: P = M'M, q = [3,2,3] M, G x <= [1,1,1], x1+x2+x3 = 1.
+    The reference holds no expected output for it; SURVEY.md §8c computed x* ~ [0, 0, 1] with scipy. Certified here by
+    KKT residuals and an SLSQP cross-solve."""
+    M = np.array([[1.0, 2.0, 0.0], [-8.0, 3.0, 2.0], [0.0, 1.0, 1.0]])
+    P, qv = M.T @ M, np.array([3.0, 2.0, 3.0]) @ M
+    G = np.array([[1.0, 2.0, 1.0], [2.0, 0.0, 1.0], [-1.0, 2.0, -1.0]])
+    C = np.vstack([G, np.ones((1, 3))])
+    cl = np.array([-1e30, -1e30, -1e30, 1.0])
+    cu = np.array([1.0, 1.0, 1.0, 1.0])
+    x, st, _ = oracle.qp_solve(P, qv, C, None, None, cl, cu)
+    assert st == 0
+    viol, stat = common.kkt_residuals(P, qv, C, np.full(3, -1e30), np.full(3, 1e30), cl, cu, x)
+    assert viol < 1e-9 and stat < 1e-9
+    cons = [{"type": "eq", "fun": lambda z: z.sum() - 1}] + [{"type": "ineq", "fun": lambda z, i=i: 1 - G[i] @ z} for i in range(3)]
+    res = minimize(lambda z: 0.5 * z @ P @ z + qv @ z, np.zeros(3), jac=lambda z: P @ z + qv, constraints=cons, method="SLSQP",
+                   options={"ftol": 1e-14})
+    assert np.abs(res.x - x).max() < 1e-6      # (SLSQP may flag its line search at the vertex; its point is what is compared)
+    assert np.abs(x - np.array([0.0, 0.0, 1.0])).max() < 0.05
+
+
+def test_infeasible_and_nonconvex_are_reported():
+    H, g = np.eye(3), np.zeros(3)
+    C = np.array([[1.0, 0, 0], [1.0, 0, 0]])
+    x, st, _ = oracle.qp_solve(H, g, C, -np.ones(3), np.ones(3), np.array([0.5, -2.0]), np.array([2.0, 0.0]))
+    assert st == 2                                                     # 0.5 <= x0 and x0 <= 0
+    x, st, _ = oracle.qp_solve(np.diag([1.0, -1.0, 1.0]), g, None, -np.ones(3), np.ones(3))
+    assert st == 3
+
+
+def test_wavefront_variant_algebra_matches_oracle():
+    """Householder add / explicit R^-1 / row-of-T drop (what the HIP kernel runs) == textbook Givens + R."""
+    rng = np.random.default_rng(2)
+    n_ok = 0
+    for _ in range(150):
+        H, g, C, lb, ub, cl, cu = _random_qp(rng)
+        x, st, it = oracle.qp_solve(H, g, C, lb, ub, cl, cu)
+        x2, st2, it2 = gi_variant.solve(H, g, C, lb, ub, cl, cu)
+        assert st == st2
+        if st == 0:
+            n_ok += 1
+            assert np.abs(x - x2).max() < 1e-10 and it == it2
+    assert n_ok > 130
+
+
+def test_tick_problems_satisfy_kkt():
+    """The actual WBC problems (cond(H) ~ 3e9): certificate on the oracle's tick outputs for configs 2 and 3."""
+    wx, _ = common.models()
+    for name, B in (("c3", 48), ("c2", 16), ("everything", 16)):
+        cfg = common.config(name, wx)
+        d = common.tick_inputs(wx, cfg, B, seed=5, with_rot=(name == "everything"))
+        a = oracle.assemble([wx], [cfg], d, DT, B)
+        out = oracle.tick([wx], [cfg], d, DT, B)
+        assert (out["status"] == 0).mean() > 0.9
+        for b in np.nonzero(out["status"] == 0)[0]:
+            x = out["qdot"][b]
+            viol, stat = common.kkt_residuals(a["H"][b], a["g"][b], a["C"][b], a["lb"][b], a["ub"][b], a["Clb"][b], a["Cub"][b], x, act_tol=1e-6)
+            scale = 1 + np.abs(a["g"][b]).max()
+            assert viol < 1e-7 and stat / scale < 1e-7, (name, b, viol, stat)

@@ -154,7 +154,15 @@ def bake(urdf_path):
     def enc(v):
         return [("inf" if x == math.inf else "-inf" if x == -math.inf else x) for x in v]
 
-    return dict(name=root.get("name"), source=urdf_path.split("/Robot_Descriptions/")[-1],
+    # collision spheres (the reference reads the foot radius from the collision geometry, Robot_Wrapper4.py:55-58)
+    spheres = {}
+    for lname, l in links.items():
+        for col in l.findall("collision"):
+            sph = col.find("geometry/sphere")
+            if sph is not None:
+                spheres[lname] = float(sph.get("radius"))
+
+    return dict(name=root.get("name"), source=urdf_path.split("/Robot_Descriptions/")[-1], collision_spheres=spheres,
                 nq=nq, nv=nv, njoints=len(out_joints), joints=out_joints, frames=frames,
                 q_lo=enc(q_lo), q_hi=enc(q_hi), v_max=enc(v_max),
                 total_mass=sum(j["mass"] for j in out_joints))
