@@ -222,6 +222,11 @@ int wbc_batch_set_option(WbcBatch* b, const char* name, int value);
 /* wait for everything queued by this handle on `stream`. */
 int wbc_batch_synchronize(WbcBatch* b, void* stream);
 
+/* diagnostics: per-phase shader-cycle sums of wbc_tick since the last call, filled only by the -DWBC_PROFILE build of
+ * the library (zeros otherwise): [0] ticks, [1] FK+Jacobians, [2] task stack, [3] Cholesky, [4] L^-1 and x0,
+ * [5] equality phase, [6] inequality phase, [7] output/integrate, [8] working-set changes. */
+int wbc_debug_cycles(WbcBatch* b, uint64_t* out16);
+
 const char* wbc_last_error(void);
 const char* wbc_version(void);
 int wbc_abi_sizes(int32_t* sizeof_blob, int32_t* sizeof_config); /* ctypes layout self-check */

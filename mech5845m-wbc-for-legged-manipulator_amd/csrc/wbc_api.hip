@@ -39,6 +39,7 @@ struct WbcBatch {
   size_t ws_bytes;
   int mrows, prows, mcart;
   int jtj_mfma;
+  unsigned long long* d_prof;
 };
 
 // ---------------------------------------------------------------------------------------------- model
@@ -152,6 +153,7 @@ extern "C" void wbc_batch_destroy(WbcBatch* b) {
   if (b->d_models) (void)hipFree(b->d_models);
   if (b->d_cfgs) (void)hipFree(b->d_cfgs);
   if (b->ws) (void)hipFree(b->ws);
+  if (b->d_prof) (void)hipFree(b->d_prof);
   delete b;
 }
 
@@ -294,6 +296,7 @@ static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
   memset(&a, 0, sizeof a);
   a.models = b->d_models; a.cfgs = b->d_cfgs;
   a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma; a.dt = dt;
+  a.prof = b->d_prof;
 }
 
 // ---------------------------------------------------------------------------------------------- entry points
@@ -420,8 +423,25 @@ extern "C" int wbc_integrate(WbcBatch* b, int B, const double* q, const double* 
   return st.finish();
 }
 
+extern "C" int wbc_debug_cycles(WbcBatch* b, uint64_t* out16) {
+  if (!b || !out16) return fail(WBC_E_ARG, "wbc_debug_cycles: null argument");
+  HIP_TRY(hipSetDevice(b->device_id));
+  if (!b->d_prof) {   // first call arms the counters (they stay zero in non-profile builds)
+    HIP_TRY(hipMalloc((void**)&b->d_prof, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(b->d_prof, 0, 16 * sizeof(unsigned long long)));
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out16, b->d_prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(b->d_prof, 0, 16 * sizeof(unsigned long long)));
+  return WBC_OK;
+}
+
 extern "C" const char* wbc_last_error(void) { return g_err; }
+#ifdef WBC_PROFILE
+extern "C" const char* wbc_version(void) { return "wbc-hip 0.1 (gfx950, PROFILE build)"; }
+#else
 extern "C" const char* wbc_version(void) { return "wbc-hip 0.1 (gfx950)"; }
+#endif
 extern "C" int wbc_abi_sizes(int32_t* sb, int32_t* sc) {
   if (sb) *sb = (int32_t)sizeof(WbcModelBlob);
   if (sc) *sc = (int32_t)sizeof(WbcConfig);

@@ -37,6 +37,15 @@ constexpr int OFF_AT = 0;               // At[26][mtp] aliases T|Cm (dead before
 
 #define WSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
+// Diagnostic build (-DWBC_PROFILE): s_memtime stamps at phase boundaries, summed per phase into KernelArgs.prof.
+// Never compiled into the shipped library; its run time is not quoted (the stamps serialise the phases).
+#ifdef WBC_PROFILE
+#define STAMP(ts, i) do { __builtin_amdgcn_sched_barrier(0); (ts)[i] = (unsigned long long)clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(ts, i) do { } while (0)
+#endif
+enum { T_START = 0, T_FK = 1, T_ASM = 2, T_CHOL = 3, T_INV = 4, T_EQ = 5, T_INEQ = 6, T_END = 7, T_N = 8 };
+
 __device__ __forceinline__ double rfl(double v) {
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
   const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
@@ -151,7 +160,8 @@ __device__ __forceinline__ void integrate_ff(const Smem& S, const int lane, cons
 struct QpResult { double x; int status; int iters; };
 
 __device__ __forceinline__ QpResult qp_core(Smem& S, double (&h)[NV], const double g, const double lb, const double ub,
-                                         const double clb, const double cub, const int n, const int p, const int lane) {
+                                         const double clb, const double cub, const int n, const int p, const int lane,
+                                         unsigned long long* ts) {
   const int li = lane < NV ? lane : NV - 1;           // clamped lane for LDS reads
   double* Jm = S.Jm;
   double* T = S.U + OFF_T;
@@ -182,6 +192,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, double (&h)[NV], const doub
 #pragma unroll
     for (int k = j + 1; k < NV; ++k) PIN(h[k]);
   }
+  STAMP(ts, T_CHOL);
   if (!(pmin > 0.0)) { res.status = WBC_QP_NUMERICAL; res.x = 0.0; return res; }
   // L rows -> LDS (zero above the diagonal)
   if (lane < NV) {
@@ -218,6 +229,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, double (&h)[NV], const doub
 #pragma unroll
   for (int k = 0; k < NV; ++k) x = fma(-y[k], S.dv[k], x);
   if (lane >= n) x = 0.0;
+  STAMP(ts, T_INV);
   // ---- T = 0
   for (int k = lane; k < NV * LDJ; k += 64) T[k] = 0.0;
 
@@ -230,6 +242,9 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, double (&h)[NV], const doub
   double u = 0.0;                         // multiplier of working-set slot `lane`
   int a_code = 0;                         // slot `lane`: constraint id | side << 8 | eq << 9
   int q = 0, iters = 0;
+#ifdef WBC_PROFILE
+  bool eq_done = false;
+#endif
   const int max_iter = 10 * (n + p) + 20;
   double cn2 = 0.0;                       // |C_r|^2 for row = lane
   if (has_r) {
@@ -251,6 +266,9 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, double (&h)[NV], const doub
       b_ip = rdl(clb, r);
       s_ip = wsum(lane < n ? Cm[r * LDJ + li] * x : 0.0) - b_ip;
     } else {                                            // most violated inactive inequality
+#ifdef WBC_PROFILE
+      if (!eq_done) { eq_done = true; STAMP(ts, T_EQ); }
+#endif
       if (lane < 32) S.xv[lane] = (lane < n) ? x : 0.0;
       WSYNC();
       double best = 0.0; int code = -1;
@@ -398,9 +416,46 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, double (&h)[NV], const doub
     }
   }
 done:
+  STAMP(ts, T_INEQ);
   res.x = x;
   res.iters = iters;
   return res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// J'J on the fp64 matrix cores: H = A'A with v_mfma_f64_16x16x4_f64 (QP_Wrapper.py:17: np.dot(A.T, A)).
+// A is m x n (n <= 26, padded to 32 = 2 x 16 columns); k-step s contracts task rows 4s..4s+3.
+// Operand maps (cdna_hip_programming.md §3): lane l feeds A_op[i = l&15][k = l>>4] and B_op[k = l>>4][j = l&15], so
+// for tile (I, J) both operands are one double per lane: A[4s + (l>>4)][16 I/J + (l&15)]. D: lane l, reg r holds
+// D[(l>>4) + 4r][l&15]. Tiles 00, 01, 11 are computed (10 = 01'). `load(r, c)` returns A[r][c] (0 outside);
+// column 26 may carry b so that -A'b falls out of the same MFMAs (written to S.npv as +A'b).
+// The tiles go to S.Jm (row-major, stride LDJ); every lane then reads its row of H into h[].
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+template <class LoadA>
+__device__ __forceinline__ void jtj_mfma(Smem& S, const int lane, const int m, LoadA load, double (&h)[NV]) {
+  v4f64 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+  const int kq = lane >> 4, c0 = lane & 15;
+  for (int s4 = 0; s4 < m; s4 += 4) {
+    const double a0 = load(s4 + kq, c0);
+    const double a1 = load(s4 + kq, 16 + c0);
+    acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc00, 0, 0, 0);
+    acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, acc01, 0, 0, 0);
+    acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc11, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = kq + 4 * r, col = c0;
+    S.Jm[row * LDJ + col] = acc00[r];
+    if (16 + col < NV) { S.Jm[row * LDJ + 16 + col] = acc01[r]; S.Jm[(16 + col) * LDJ + row] = acc01[r]; }
+    if (16 + row < NV && 16 + col < NV) S.Jm[(16 + row) * LDJ + 16 + col] = acc11[r];
+    if (16 + col == NV) { S.npv[row] = acc01[r]; if (16 + row < NV) S.npv[16 + row] = acc11[r]; }
+  }
+  WSYNC();
+  const int li = li_clamp(lane);
+#pragma unroll
+  for (int k = 0; k < NV; k += 2) { const double2a v = lds2(S.Jm + li * LDJ + k); h[k] = v.x; h[k + 1] = v.y; }
+  WSYNC();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -456,6 +511,9 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
   const int nv = M.nv, nq = M.nq, nj = M.njoints;
   const double dt = A.dt;
   double* oMi = S.U + OFF_OMI;          // [joint][12]: R column-major (3 columns), then p
+  unsigned long long ts[T_N];
+  (void)ts;
+  STAMP(ts, T_START);
   const int ll = lane & 31;             // index into the 32-entry per-lane model tables
 
   // ---- P0: q (coalesced), updateState's config (Robot_Wrapper4.py:389-402)
@@ -591,6 +649,7 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     return;
   }
 
+  STAMP(ts, T_FK);
   // ---- P4/P5: task stack. qpA/qpb (Robot_Wrapper4.py:1271-1294) feeding H = A'A, g = -A'b (QP_Wrapper.py:17-18)
   WSYNC();   // every lane is done reading oMi / mc: the region is reused for At from here on
   double h[NV];
@@ -706,8 +765,13 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     row += 3;
   }
   WSYNC();
-  // pass 2: H[lane][i] += sum_r At[i][r] At[lane][r], block by block over each block's DoF support
-  {
+  // pass 2: H[lane][i] += sum_r At[i][r] At[lane][r]
+  if (A.jtj_mfma) {
+    // dense contraction on the fp64 matrix cores (the operand comes straight from the At image in LDS)
+    const int mc = A.mcart;
+    jtj_mfma(S, lane, mc, [&](int r, int c) -> double { return (r < mc && c < NV) ? At[c * mtp + r] : 0.0; }, h);
+  } else {
+    // vector units, block by block over each block's DoF support (skips the structural zeros of the Jacobians)
     int r0 = 0;
     for (int e = 0; e < WBC_NEE; ++e) {
       if (!cfg.task_ee[e]) continue;
@@ -843,8 +907,9 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     return;
   }
 
+  STAMP(ts, T_ASM);
   // ---- P7/P8: the QP (QP_Wrapper.py:23-73). Padded DoF (lane >= nv) carry no constraint and stay 0.
-  const QpResult res = qp_core(S, h, g, lb, ub, clb, cub, nv, A.prows, lane);
+  const QpResult res = qp_core(S, h, g, lb, ub, clb, cub, nv, A.prows, lane, ts);
   if (A.out.qdot && lane < NV) A.out.qdot[(size_t)b * NV + lane] = (lane < nv) ? res.x : 0.0;
   if (lane == 0) {
     if (A.out.status) A.out.status[b] = res.status;
@@ -864,6 +929,14 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     if (lane >= nq && lane < NQ) qn[lane] = 0.0;
     WSYNC();
   }
+#ifdef WBC_PROFILE
+  STAMP(ts, T_END);
+  if (A.prof && lane == 0 && res.status == WBC_QP_OPTIMAL) {
+    for (int i = 1; i < T_N; ++i) atomicAdd(A.prof + i, ts[i] - ts[i - 1]);
+    atomicAdd(A.prof + 0, 1ull);
+    atomicAdd(A.prof + 8, (unsigned long long)res.iters);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -887,17 +960,31 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
     asm volatile("" : "+v"(lane), "+s"(n), "+s"(p), "+s"(m));   // no LICM of lane/n-derived masks
     double h[NV];
     double g = 0.0;
+    unsigned long long nullptr_ts[T_N];
+    (void)nullptr_ts;
     if (m > 0) {
-      // H = A'A, g = -A'b (QP_Wrapper.py:17-18): lane k owns column k; row r of A is broadcast by uniform loads
+      // H = A'A, g = -A'b (QP_Wrapper.py:17-18)
       const double* Ab = A.A + (size_t)b * m * n;
       const double* bb = A.bvec + (size_t)b * m;
+      if (A.use_mfma) {
+        // matrix-core path: column 26 of the padded operand carries b, so A'b comes out of the same MFMAs
+        jtj_mfma(S, lane, m, [&](int r, int c) -> double {
+          if (r >= m) return 0.0;
+          if (c < n) return Ab[(size_t)r * n + c];
+          return (c == NV) ? bb[r] : 0.0;
+        }, h);
+        g = (lane < n) ? -S.npv[li_clamp(lane)] : 0.0;
+        WSYNC();
+      } else {
+        // vector path: lane k owns column k; row r of A is broadcast by uniform loads
 #pragma unroll
-      for (int i = 0; i < NV; ++i) h[i] = 0.0;
-      for (int r = 0; r < m; ++r) {
-        const double ak = (lane < n) ? Ab[(size_t)r * n + lane] : 0.0;
-        g = fma(-ak, bb[r], g);
+        for (int i = 0; i < NV; ++i) h[i] = 0.0;
+        for (int r = 0; r < m; ++r) {
+          const double ak = (lane < n) ? Ab[(size_t)r * n + lane] : 0.0;
+          g = fma(-ak, bb[r], g);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) h[i] = fma((i < n) ? Ab[(size_t)r * n + i] : 0.0, ak, h[i]);
+          for (int i = 0; i < NV; ++i) h[i] = fma((i < n) ? Ab[(size_t)r * n + i] : 0.0, ak, h[i]);
+        }
       }
 #pragma unroll
       for (int i = 0; i < NV; ++i) if (i == lane && lane >= n) h[i] = 1.0;
@@ -921,7 +1008,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
     const double clb = (lane < p) ? A.Clb[(size_t)b * p + lane] : 0.0;
     const double cub = (lane < p) ? A.Cub[(size_t)b * p + lane] : 0.0;
     WSYNC();
-    const QpResult res = qp_core(S, h, g, lb, ub, clb, cub, n, p, lane);
+    const QpResult res = qp_core(S, h, g, lb, ub, clb, cub, n, p, lane, nullptr_ts);
     if (lane < n) A.x[(size_t)b * n + lane] = res.x;
     if (lane == 0) {
       if (A.status) A.status[b] = res.status;

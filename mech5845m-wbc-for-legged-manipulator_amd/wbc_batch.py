@@ -93,6 +93,12 @@ class WbcBatch:
     def constraint_rows(self):
         return self.lib.wbc_constraint_rows(self._h)
 
+    def debug_cycles(self):
+        """per-phase cycle sums since the last call (profile build only; see include/wbc.h)."""
+        out = (C.c_uint64 * 16)()
+        capi.check(self.lib.wbc_debug_cycles(self._h, out), self.lib)
+        return [int(v) for v in out]
+
     def synchronize(self, stream=None):
         capi.check(self.lib.wbc_batch_synchronize(self._h, stream), self.lib)
 

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "build", "libwbc_hip.so")
+LIB_PATH = os.environ.get("WBC_HIP_LIB") or os.path.join(HERE, "csrc", "build", "libwbc_hip.so")   # WBC_HIP_LIB: e.g. the profile build
 
 # ---- limits (include/wbc.h)
 MAX_JOINTS, MAX_NQ, MAX_NV, NEE, MAX_FRAMES, MAX_P, MAX_M, MAX_MODELS = 24, 28, 26, 5, 16, 24, 96, 4
@@ -93,6 +93,7 @@ SIGNATURES = {
     "wbc_integrate": (_i, [_vp, _i, _vp, _vp, _vp, _d, _i, _vp, _vp]),
     "wbc_batch_set_option": (_i, [_vp, C.c_char_p, _i]),
     "wbc_batch_synchronize": (_i, [_vp, _vp]),
+    "wbc_debug_cycles": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "wbc_last_error": (C.c_char_p, []),
     "wbc_version": (C.c_char_p, []),
     "wbc_abi_sizes": (_i, [c_int32_p, c_int32_p]),
