@@ -475,7 +475,11 @@ class RobotModel:
     def setInitialState(self, iterations_per_segment=1000):
         """Drag the neutral pose to the crouched stance with the bounds-only QP (all six Cartesian tasks + Tikhonov
         posture), one device tick per step of the straight-line foot/gripper trajectories, then fix the base."""
-        self.updateState(self._model.neutral()[:self._model.nq], feedback=False)
+        q0 = self._model.neutral()[:self._model.nq]
+        for i in range(self.n_velocity_dimensions):          # reference :201-208: only the upper clamp has an effect
+            if q0[i] > self.robot_model.upperPositionLimit[i]:   # (this is what bends the knees: calf upper limit < 0)
+                q0[i] = self.robot_model.upperPositionLimit[i]
+        self.updateState(q0, feedback=False)
         self._log_previous_state()
         self._capture_default_orientations()
         Trunk_target_pos = np.copy(self.trunk_frame_pos)

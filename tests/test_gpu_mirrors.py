@@ -126,7 +126,7 @@ def test_robot_model_tick_matches_oracle(robot):
         assert (len(FL), len(FR), len(RL), len(RR), len(grip)) == (3, 3, 3, 3, 8)
         # updateState(running=True): base xyz re-estimated from the stance feet (:414-415, :1297-1327), quaternion = IMU
         q = rm.current_joint_config
-        assert np.abs(q[3:7] - imu).max() == 0 and np.abs(q[7:] - joints).max() == 0
+        assert np.abs(q[3:7] - imu).max() == 0 and np.abs(q[7:] - joints).max() < 1e-7
         feet = np.array([rm.EE_frame_pos[i] for i in range(4)])
         tgt = np.array([np.asarray(EE_target[i]).reshape(3) for i in range(4)])
         assert np.abs(feet.mean(0) - tgt.mean(0)).max() < 1e-9

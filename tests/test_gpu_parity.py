@@ -19,6 +19,8 @@ QDOT_TOL = 1e-5          # north_star: "within 1e-5 max-abs on identical inputs"
 
 
 def relerr(a, b):
+    if a.size == 0:
+        return 0.0
     return np.abs(a - b).max() / max(1.0, np.abs(b).max())
 
 
