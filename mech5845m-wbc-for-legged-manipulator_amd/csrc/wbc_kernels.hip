@@ -4,36 +4,45 @@
 //   lane j  <-> joint j          during forward kinematics (level-synchronous over the tree depth),
 //   lane k  <-> velocity DoF k   everywhere else (column k of every Jacobian, row/column k of H, J, T).
 // All per-instance matrices live in LDS (row stride 26 doubles: 26 ≡ 2 mod 4 makes both the "lane = row,
-// ds_read_b128 along the row" and the "lane = column, ds_read_b64 down the column" patterns bank-conflict
-// free on the 64-bank LDS of CDNA4), all lane-distributed vectors in VGPRs, wave-uniform scalars in SGPRs
-// via readfirstlane. HBM traffic per tick is the instance's own inputs/outputs only (~0.6-0.8 KB, coalesced).
+// ds_read_b128 along the row" and the "lane = column, ds_read_b64 down the column" patterns bank-conflict free on
+// the 64-bank LDS of CDNA4); lane-distributed vectors live in VGPRs, wave-uniform scalars in SGPRs. Every loop
+// over the matrix dimension is a real loop with a compact body: the whole tick is a few thousand instructions of
+// code, so the waves of a CU, each in a different phase, share the 64 KB instruction cache without evicting each
+// other (the first, fully unrolled register-resident version was 82 KB of code and instruction-fetch bound:
+// profiles/r01_*_v1.*). Wave reductions use DPP row operations + v_readlane, never the LDS crossbar.
+// HBM traffic per tick is the instance's own inputs/outputs (~0.7 KB, coalesced), prefetched one tick ahead.
 //
-// Reference semantics (file:line relative to the reference repo) are cited at each stage; the CPU restatement
-// the tests compare against is oracle/wbc_oracle.c (never linked here).
+// Reference semantics (file:line relative to the reference repo) are cited at each stage; the CPU restatement the
+// tests compare against is oracle/wbc_oracle.c (never linked here); the algebra of the QP variant is stated in
+// plain numpy in tests/gi_variant.py (solve_v2).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "wbc_device.h"
 
 namespace wbc {
 
-constexpr int LDJ = 26;                 // LDS row stride (doubles) of Jm, T, Cm
+constexpr int LDJ = 26;                 // LDS row stride (doubles) of the n x n matrices and of Cm
 constexpr int PMAX = WBC_MAX_P;         // 24
-constexpr int MTP_MAX = 42;             // Cartesian task rows (<= 39) padded to ≡ 2 mod 4
 constexpr double QP_INF = 1e20;
 constexpr double EPS2 = 2.220446049250313e-16 * 2.220446049250313e-16;
 
+// staging image of one instance's inputs (doubles)
+constexpr int IN_Q = 0, IN_EET = 28, IN_EEP = 43, IN_BOX = 58;                       // group 1 (lanes 0..61)
+constexpr int IN_TT = 64, IN_TP = 67, IN_TRE = 70, IN_TPR = 73, IN_CT = 82, IN_CV = 85;  // group 2 (24 values)
+constexpr int IN_ERR = 96, IN_EPR = 141;                                              // group 3 (2 x 45 values)
+constexpr int IN_SIZE = 192;
+
 struct __attribute__((aligned(16))) Smem {
-  double Jm[NV * LDJ];                  // H -> L -> J = L^-T Q (n x n)
-  double U[NV * LDJ + PMAX * LDJ];      // [T = R^-1 (26x26) | Cm (p x 26)]; during assembly: oMi, m*c, At
-  double qv[32];
+  double RA[NV * LDJ];                  // H -> L (Cholesky) -> T = R^-1 of the inequality slots; early: oMi, m*c
+  double RB[NV * LDJ];                  // J = L^-T Q ; during assembly (with RC): At, the task stack by DoF
+  double RC[PMAX * LDJ];                // Cm: constraint rows (p x 26)
+  double in[IN_SIZE];                   // this instance's inputs (q, targets, controller state)
   double pf[WBC_MAX_FRAMES * 3];        // frame origins
-  double dv[32], xv[32], npv[32], lv[32], dinv[32];
+  double dv[32], xv[32], npv[32], lv[32], dinv[32], yv[32];
   double bt[48];                        // Cartesian task targets (b of qpb), uniform values
 };
-constexpr int OFF_T = 0, OFF_CM = NV * LDJ;
-constexpr int OFF_OMI = OFF_CM;         // oMi[24][12] aliases Cm (dead before Cm is written)
-constexpr int OFF_MC = 0;               // m*c per joint [32][4] aliases T (dead before T is used)
-constexpr int OFF_AT = 0;               // At[26][mtp] aliases T|Cm (dead before either is written)
+constexpr int OFF_OMI = 0;              // RA: oMi[24][12] (dead before H is accumulated)
+constexpr int OFF_MC = 24 * 12;         // RA: m*c per joint [32][4]
 
 #define WSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
@@ -46,6 +55,7 @@ constexpr int OFF_AT = 0;               // At[26][mtp] aliases T|Cm (dead before
 #endif
 enum { T_START = 0, T_FK = 1, T_ASM = 2, T_CHOL = 3, T_INV = 4, T_EQ = 5, T_INEQ = 6, T_END = 7, T_N = 8 };
 
+// ---------------------------------------------------------------------------------------------- lane helpers
 __device__ __forceinline__ double rfl(double v) {
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
   const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
@@ -57,22 +67,37 @@ __device__ __forceinline__ double rdl(double v, int lane) {  // lane must be wav
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int rdli(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-// reductions over lanes 0..31 (the 26 DoF lanes live there); result is wave-uniform
+__device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll((long long)m) - 1; }
+
+// DPP move of a double (both halves) with a compile-time control word (gfx9 row operations)
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+// sum / min over lanes 0..31 (the DoF lanes): butterfly inside each 16-lane row, rows 0 and 1 joined by readlane.
+// The result is wave-uniform. Lanes 26..31 must carry the neutral element.
 __device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-  for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-  return rfl(v);
+  v += dpp<DPP_XOR1>(v);
+  v += dpp<DPP_XOR2>(v);
+  v += dpp<DPP_HALF_MIRROR>(v);
+  v += dpp<DPP_MIRROR>(v);
+  return rdl(v, 0) + rdl(v, 16);
 }
 __device__ __forceinline__ double wmin(double v) {
-#pragma unroll
-  for (int m = 16; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m));
-  return rfl(v);
+  v = fmin(v, dpp<DPP_XOR1>(v));
+  v = fmin(v, dpp<DPP_XOR2>(v));
+  v = fmin(v, dpp<DPP_HALF_MIRROR>(v));
+  v = fmin(v, dpp<DPP_MIRROR>(v));
+  return fmin(rdl(v, 0), rdl(v, 16));
 }
-__device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll((long long)m) - 1; }
 
 struct double2a { double x, y; } __attribute__((aligned(16)));
 __device__ __forceinline__ double2a lds2(const double* p) { return *reinterpret_cast<const double2a*>(p); }
-
+__device__ __forceinline__ void sts2(double* p, double x, double y) { double2a v; v.x = x; v.y = y; *reinterpret_cast<double2a*>(p) = v; }
 
 __device__ __forceinline__ int li_clamp(int lane) { return lane < NV ? lane : NV - 1; }
 
@@ -80,6 +105,27 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
   c[0] = a[1] * b[2] - a[2] * b[1];
   c[1] = a[2] * b[0] - a[0] * b[2];
   c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// sin (.x) and cos (.y) for |x| up to a few thousand: Cody–Waite reduction by pi/2 (exact products through FMA) +
+// the fdlibm kernel polynomials on [-pi/4, pi/4]; < 1 ulp (ocml's sincos drags in a Payne–Hanek path, ~10x the code).
+struct SinCos { double s, c; };
+__device__ __forceinline__ SinCos sincos_cw(double x) {
+  const double k = rint(x * 0.63661977236758134308);
+  double r = fma(-k, 1.5707963267948966, x);
+  r = fma(-k, 6.123233995736766e-17, r);
+  const double z = r * r;
+  const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  const double s = fma(r * z, ps, r);
+  const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int n = ((int)k) & 3;
+  SinCos o;
+  o.s = (n == 0) ? s : (n == 1) ? c : (n == 2) ? -s : -c;
+  o.c = (n == 0) ? c : (n == 1) ? -s : (n == 2) ? -c : s;
+  return o;
 }
 
 // Eigen::Quaternion::toRotationMatrix without normalisation (what pinocchio's free-flyer uses); q = (x, y, z, w)
@@ -93,15 +139,18 @@ __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
   R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
 }
 
-// Free-flyer part of pin.integrate (Robot_Wrapper4.py:441): M+ = M exp6(v), v = S.xv[0..5] (body twist * dt).
-// R0 (row-major) / p0 = current base placement, quaternion continuity + first-order renormalisation as in
+// Free-flyer part of pin.integrate (Robot_Wrapper4.py:441): M+ = M exp6(v), v = S.xv[0..5] (body twist * dt), current
+// placement from the quaternion / xyz staged in S.in; quaternion continuity + first-order renormalisation as in
 // pinocchio's SpecialEuclideanOperationTpl<3>::integrate_impl. Uniform arithmetic; lanes 0..6 store.
-__device__ __forceinline__ void integrate_ff(const Smem& S, const int lane, const double* R0, const double* p0, double* qn) {
+__device__ __forceinline__ void integrate_ff(const Smem& S, const int lane, double* qn) {
+  double R0[9];
+  quat_to_R(S.in + IN_Q + 3, R0);
+  const double p0[3] = {S.in[IN_Q], S.in[IN_Q + 1], S.in[IN_Q + 2]};
   const double vl[3] = {S.xv[0], S.xv[1], S.xv[2]}, w[3] = {S.xv[3], S.xv[4], S.xv[5]};
   const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], t = sqrt(t2);
   double a, bq, c;
   if (t < 1e-4) { a = 1 - t2 / 6; bq = 0.5 - t2 / 24; c = 1.0 / 6 - t2 / 120; }
-  else { double sn, cs; sincos(t, &sn, &cs); a = sn / t; bq = (1 - cs) / t2; c = (1 - a) / t2; }
+  else { const SinCos sc = sincos_cw(t); a = sc.s / t; bq = (1 - sc.c) / t2; c = (1 - a) / t2; }
   const double wx = w[0], wy = w[1], wz = w[2];
   double Re[9];
   Re[0] = 1 - bq * (wy * wy + wz * wz); Re[1] = -a * wz + bq * wx * wy;       Re[2] = a * wy + bq * wx * wz;
@@ -119,236 +168,276 @@ __device__ __forceinline__ void integrate_ff(const Smem& S, const int lane, cons
     for (int j = 0; j < 3; ++j) R1[3 * i + j] = R0[3 * i] * Re[j] + R0[3 * i + 1] * Re[3 + j] + R0[3 * i + 2] * Re[6 + j];
     pn[i] = p0[i] + (R0[3 * i] * pe[0] + R0[3 * i + 1] * pe[1] + R0[3 * i + 2] * pe[2]);
   }
-  double qq[4];
+  double q0, q1, q2, q3;   // Eigen's quaternion-from-matrix
   const double tr = R1[0] + R1[4] + R1[8];
   if (tr > 0) {
     double s = sqrt(tr + 1.0);
-    qq[3] = 0.5 * s; s = 0.5 / s;
-    qq[0] = (R1[7] - R1[5]) * s; qq[1] = (R1[2] - R1[6]) * s; qq[2] = (R1[3] - R1[1]) * s;
-  } else if (R1[0] >= R1[4] && R1[0] >= R1[8]) {   // i = 0 (Eigen: i=0; if m11>m00 i=1; if m22>m_ii i=2)
+    q3 = 0.5 * s; s = 0.5 / s;
+    q0 = (R1[7] - R1[5]) * s; q1 = (R1[2] - R1[6]) * s; q2 = (R1[3] - R1[1]) * s;
+  } else if (R1[0] >= R1[4] && R1[0] >= R1[8]) {
     double s = sqrt(R1[0] - R1[4] - R1[8] + 1.0);
-    qq[0] = 0.5 * s; s = 0.5 / s;
-    qq[3] = (R1[7] - R1[5]) * s; qq[1] = (R1[3] + R1[1]) * s; qq[2] = (R1[6] + R1[2]) * s;
-  } else if (R1[4] > R1[0] && R1[4] >= R1[8]) {    // i = 1
+    q0 = 0.5 * s; s = 0.5 / s;
+    q3 = (R1[7] - R1[5]) * s; q1 = (R1[3] + R1[1]) * s; q2 = (R1[6] + R1[2]) * s;
+  } else if (R1[4] > R1[0] && R1[4] >= R1[8]) {
     double s = sqrt(R1[4] - R1[8] - R1[0] + 1.0);
-    qq[1] = 0.5 * s; s = 0.5 / s;
-    qq[3] = (R1[2] - R1[6]) * s; qq[2] = (R1[7] + R1[5]) * s; qq[0] = (R1[1] + R1[3]) * s;
-  } else {                                         // i = 2
+    q1 = 0.5 * s; s = 0.5 / s;
+    q3 = (R1[2] - R1[6]) * s; q2 = (R1[7] + R1[5]) * s; q0 = (R1[1] + R1[3]) * s;
+  } else {
     double s = sqrt(R1[8] - R1[0] - R1[4] + 1.0);
-    qq[2] = 0.5 * s; s = 0.5 / s;
-    qq[3] = (R1[3] - R1[1]) * s; qq[0] = (R1[2] + R1[6]) * s; qq[1] = (R1[5] + R1[7]) * s;
+    q2 = 0.5 * s; s = 0.5 / s;
+    q3 = (R1[3] - R1[1]) * s; q0 = (R1[2] + R1[6]) * s; q1 = (R1[5] + R1[7]) * s;
   }
-  if (qq[0] * S.qv[3] + qq[1] * S.qv[4] + qq[2] * S.qv[5] + qq[3] * S.qv[6] < 0) { qq[0] = -qq[0]; qq[1] = -qq[1]; qq[2] = -qq[2]; qq[3] = -qq[3]; }
-  const double f = (3 - (qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3])) / 2;
+  if (q0 * S.in[IN_Q + 3] + q1 * S.in[IN_Q + 4] + q2 * S.in[IN_Q + 5] + q3 * S.in[IN_Q + 6] < 0) { q0 = -q0; q1 = -q1; q2 = -q2; q3 = -q3; }
+  const double f = (3 - (q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3)) / 2;
   double outv = 0.0;
   if (lane == 0) outv = pn[0];
   if (lane == 1) outv = pn[1];
   if (lane == 2) outv = pn[2];
-  if (lane == 3) outv = qq[0] * f;
-  if (lane == 4) outv = qq[1] * f;
-  if (lane == 5) outv = qq[2] * f;
-  if (lane == 6) outv = qq[3] * f;
+  if (lane == 3) outv = q0 * f;
+  if (lane == 4) outv = q1 * f;
+  if (lane == 5) outv = q2 * f;
+  if (lane == 6) outv = q3 * f;
   if (lane < 7) qn[lane] = outv;
 }
 
 // ------------------------------------------------------------------------------------------------
-// QP core: Goldfarb–Idnani dual active set, wavefront form (algebra: tests/gi_variant.py).
-//   in : h[26]  row `lane` of H (registers), g, lb, ub per lane; Cm (p x 26) in LDS, clb/cub per lane (row = lane)
-//   out: x per lane; returns status; iters
-// replaces qpOASES init/hotstart as called at QP_Wrapper.py:45-48, 70 (unique minimiser since H > 0).
+// QP: Goldfarb–Idnani dual active set, wavefront form (algebra: tests/gi_variant.py solve_v2).
+//   in : H in S.RA (rows 0..25, padded rows = identity), g / lb / ub per lane, Cm in S.RC (p x 26), clb / cub per lane
+//   out: x per lane, status, iters.  Replaces qpOASES init/hotstart as called at QP_Wrapper.py:45-48, 70.
+// Steps: Cholesky of H in place (RA); J = L^-T into RB (lane c solves L y = e_c); the equalities are absorbed by a
+// Householder QR of J'N_e that only updates J; x_eq = J1 y1 - J2 J2'g; then dual active-set iterations for the
+// inequalities with T = R^-1 kept (in RA) only for the inequality slots.
 // ------------------------------------------------------------------------------------------------
 struct QpResult { double x; int status; int iters; };
 
-__device__ __forceinline__ QpResult qp_core(Smem& S, double (&h)[NV], const double g, const double lb, const double ub,
-                                         const double clb, const double cub, const int n, const int p, const int lane,
-                                         unsigned long long* ts) {
-  const int li = lane < NV ? lane : NV - 1;           // clamped lane for LDS reads
-  double* Jm = S.Jm;
-  double* T = S.U + OFF_T;
-  const double* Cm = S.U + OFF_CM;
+__device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const double lb, const double ub,
+                                            const double clb, const double cub, const int n, const int p, const int lane,
+                                            unsigned long long* ts) {
+  const int li = li_clamp(lane);
+  double* const L = S.RA;
+  double* const J = S.RB;
+  double* const T = S.RA;
+  const double* const Cm = S.RC;
   QpResult res;
   res.status = WBC_QP_OPTIMAL;
   res.iters = 0;
+  res.x = 0.0;
 
-  // ---- Cholesky H = L L' (right-looking, lane i owns row i in registers; column j broadcast through LDS)
-  // PIN(): zero-instruction use/def that stops the compiler from sinking a step's arithmetic below later steps
-  // (it otherwise keeps every broadcast column alive at once and spills hundreds of registers).
-#define PIN(v) asm volatile("" : "+v"(v))
+  // ---- Cholesky H = L L' in place, right-looking; lane i owns row i, column j is broadcast through S.lv
   double pmin = 1.0;
-#pragma unroll
+#pragma unroll 1
   for (int j = 0; j < NV; ++j) {
-    if (lane < NV) S.lv[lane] = h[j];
-    WSYNC();
-    const double pj = S.lv[j];
+    const double pj = L[j * LDJ + j];
     pmin = fmin(pmin, pj);
     const double rinv = rsqrt(pj);
+    const double lij = L[li * LDJ + j] * rinv;
+    if (lane < NV) { L[lane * LDJ + j] = lij; S.lv[lane] = lij; }
     if (lane == 0) S.dinv[j] = rinv;
-    const double lij = h[j] * rinv;
-    h[j] = lij;
-#pragma unroll
-    for (int k = j + 1; k < NV; ++k) h[k] = fma(-lij, S.lv[k] * rinv, h[k]);
     WSYNC();
-    PIN(pmin);
-#pragma unroll
-    for (int k = j + 1; k < NV; ++k) PIN(h[k]);
+#pragma unroll 1
+    for (int k = (j + 1) & ~1; k < NV; k += 2) {
+      const double2a l2 = lds2(S.lv + k);
+      double2a h2 = lds2(L + li * LDJ + k);
+      if (k > j) h2.x = fma(-lij, l2.x, h2.x);
+      h2.y = fma(-lij, l2.y, h2.y);
+      if (lane < NV) sts2(L + lane * LDJ + k, h2.x, h2.y);
+    }
+    WSYNC();
   }
   STAMP(ts, T_CHOL);
-  if (!(pmin > 0.0)) { res.status = WBC_QP_NUMERICAL; res.x = 0.0; return res; }
-  // L rows -> LDS (zero above the diagonal)
-  if (lane < NV) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) Jm[lane * LDJ + k] = (k <= lane) ? h[k] : 0.0;
-  }
-  WSYNC();
-  // ---- J = L^-T: lane c solves L y = e_c; y = column c of L^-1 = row c of J
-  double y[NV];
-#pragma unroll
+  if (!(pmin > 0.0)) { res.status = WBC_QP_NUMERICAL; return res; }
+
+  // ---- J = L^-T: lane c solves L y = e_c by forward substitution; y_i is stored as J[c][i]
+  double sq = 0.0;
+#pragma unroll 1
   for (int i = 0; i < NV; ++i) {
     double s = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < i; ++k) s = fma(-Jm[i * LDJ + k], y[k], s);
-    y[i] = s * S.dinv[i];
-    if ((i & 3) == 3) asm volatile("" : "+v"(y[i]) : : "memory");   // bound how far row loads are hoisted
-  }
-  WSYNC();
-  double sq = 0.0;
-  if (lane < NV) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) { Jm[lane * LDJ + k] = y[k]; sq = fma(y[k], y[k], sq); }
+#pragma unroll 1
+    for (int k = 0; k < i; k += 2) {
+      const double2a l2 = lds2(L + i * LDJ + k);
+      const double2a y2 = lds2(J + li * LDJ + k);
+      s = fma(-l2.x, y2.x, s);
+      if (k + 1 < i) s = fma(-l2.y, y2.y, s);
+    }
+    const double y = s * S.dinv[i];
+    sq = fma(y, y, sq);
+    if (lane < NV) J[lane * LDJ + i] = y;
+    WSYNC();
   }
   const double jf2 = wsum(lane < NV ? sq : 0.0);
-  // ---- x = -J J' g
-  if (lane < 32) S.npv[lane] = (lane < NV) ? g : 0.0;
-  WSYNC();
-  double dg = 0.0;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) dg = fma(Jm[i * LDJ + li], S.npv[i], dg);
-  if (lane < 32) S.dv[lane] = (lane < NV) ? dg : 0.0;
-  WSYNC();
-  double x = 0.0;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) x = fma(-y[k], S.dv[k], x);
-  if (lane >= n) x = 0.0;
-  STAMP(ts, T_INV);
-  // ---- T = 0
+  // T = 0 (RA is free now)
   for (int k = lane; k < NV * LDJ; k += 64) T[k] = 0.0;
+  STAMP(ts, T_INV);
 
-  // ---- active-set state
+  // ---- constraint bookkeeping
   const bool has_b = lane < n, has_r = lane < p;
   const bool eq_b = has_b && (lb == ub) && (fabs(lb) < QP_INF);
   const bool eq_r = has_r && (clb == cub) && (fabs(clb) < QP_INF);
   unsigned long long eqm_b = __ballot(eq_b), eqm_r = __ballot(eq_r);
   bool act_b = false, act_r = false;      // bound `lane` / row `lane` in the working set
-  double u = 0.0;                         // multiplier of working-set slot `lane`
-  int a_code = 0;                         // slot `lane`: constraint id | side << 8 | eq << 9
+  double u = 0.0;                         // multiplier of working-set slot `lane` (inequality slots only)
+  int a_code = 0;                         // slot `lane`: constraint id | side << 8
   int q = 0, iters = 0;
-#ifdef WBC_PROFILE
-  bool eq_done = false;
-#endif
   const int max_iter = 10 * (n + p) + 20;
   double cn2 = 0.0;                       // |C_r|^2 for row = lane
-  if (has_r) {
-#pragma unroll
-    for (int k = 0; k < NV; k += 2) { const double2a c2 = lds2(Cm + lane * LDJ + k); cn2 = fma(c2.x, c2.x, fma(c2.y, c2.y, cn2)); }
+  if (p > 0) {
+#pragma unroll 1
+    for (int k = 0; k < NV; k += 2) { const double2a c2 = lds2(Cm + (has_r ? lane : 0) * LDJ + k); cn2 = fma(c2.x, c2.x, fma(c2.y, c2.y, cn2)); }
   }
   WSYNC();
 
-  for (;;) {
-    // ---------------- choose the constraint to add
-    int ip, ip_side = 0, ip_eq = 0;
-    double s_ip, b_ip;
-    if (eqm_b) {                                        // equalities in index order: bounds first
-      ip = ctz64(eqm_b); eqm_b &= eqm_b - 1; ip_eq = 1;
-      b_ip = rdl(lb, ip);
-      s_ip = rdl(x, ip) - b_ip;
-    } else if (eqm_r) {
-      const int r = ctz64(eqm_r); eqm_r &= eqm_r - 1; ip_eq = 1; ip = n + r;
-      b_ip = rdl(clb, r);
-      s_ip = wsum(lane < n ? Cm[r * LDJ + li] * x : 0.0) - b_ip;
-    } else {                                            // most violated inactive inequality
-#ifdef WBC_PROFILE
-      if (!eq_done) { eq_done = true; STAMP(ts, T_EQ); }
-#endif
-      if (lane < 32) S.xv[lane] = (lane < n) ? x : 0.0;
-      WSYNC();
-      double best = 0.0; int code = -1;
-      if (has_b && !act_b && !eq_b) {
-        if (lb > -QP_INF) { const double s = x - lb; if (s < -1e-9 * fmax(1.0, fabs(lb)) && s < best) { best = s; code = lane; } }
-        if (ub < QP_INF) { const double s = ub - x; if (s < -1e-9 * fmax(1.0, fabs(ub)) && s < best) { best = s; code = lane | 256; } }
+  // ---- equality block: Householder QR of J'N_e (updates J only); y1 solves R'y1 = b_e incrementally
+  double y1 = 0.0;                        // lane k < q: y1_k
+#pragma unroll 1
+  while (eqm_b | eqm_r) {
+    int c, is_row;
+    double b_e, np2;
+    if (eqm_b) { c = ctz64(eqm_b); eqm_b &= eqm_b - 1; is_row = 0; b_e = rdl(lb, c); np2 = 1.0; }
+    else { c = ctz64(eqm_r); eqm_r &= eqm_r - 1; is_row = 1; b_e = rdl(clb, c); np2 = rdl(cn2, c); }
+    ++iters;
+    double d = 0.0;                       // d = J' n  (lane k: column k of J)
+    if (is_row) {
+#pragma unroll 2
+      for (int i = 0; i < NV; i += 2) {
+        const double2a c2 = lds2(Cm + c * LDJ + i);
+        d = fma(J[i * LDJ + li], c2.x, fma(J[(i + 1) * LDJ + li], c2.y, d));
       }
-      if (p > 0) {
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < NV; k += 2) {
-          const double2a c2 = lds2(Cm + (has_r ? lane : 0) * LDJ + k); const double2a x2 = lds2(S.xv + k);
-          v = fma(c2.x, x2.x, fma(c2.y, x2.y, v));
-        }
-        if (has_r && !act_r && !eq_r) {
-          if (clb > -QP_INF) { const double s = v - clb; if (s < -1e-9 * fmax(1.0, fabs(clb)) && s < best) { best = s; code = n + lane; } }
-          if (cub < QP_INF) { const double s = cub - v; if (s < -1e-9 * fmax(1.0, fabs(cub)) && s < best) { best = s; code = (n + lane) | 256; } }
-        }
-      }
-      const double worst = wmin(lane < 32 ? best : 0.0);
-      if (!(worst < 0.0)) break;                        // primal feasible -> optimal
-      const int wl = ctz64(__ballot(lane < 32 && best == worst));
-      const int wc = rdli(code, wl);
-      ip = wc & 255; ip_side = (wc >> 8) & 1;
-      s_ip = worst;
-      const double bl = (ip < n) ? rdl(ip_side ? -ub : lb, ip) : rdl(ip_side ? -cub : clb, ip - n);
-      b_ip = bl;
+    } else {
+      d = J[c * LDJ + li];
     }
+    if (lane >= n) d = 0.0;
+    const double zn = wsum((lane >= q && lane < n) ? d * d : 0.0);
+    const double dy = wsum((lane < q) ? d * y1 : 0.0);
+    if (!(zn > 100.0 * n * EPS2 * jf2 * np2)) {          // dependent on the equalities already absorbed
+      if (fabs(dy - b_e) <= 1e-9 * fmax(1.0, fabs(b_e))) continue;
+      res.status = WBC_QP_INFEASIBLE; res.iters = iters; return res;
+    }
+    const double dq = rdl(d, q);
+    const double sz = sqrt(zn);
+    const double delta = (dq >= 0.0) ? -sz : sz;
+    const double vv = 2.0 * (zn - delta * dq);
+    const double v = (lane == q) ? d - delta : ((lane > q) ? d : 0.0);   // Householder vector, zero below slot q
+    if (lane < 32) S.dv[lane] = v;
+    WSYNC();
+    if (vv > 0.0) {
+      const double beta = 2.0 / vv;
+      const int k0 = q & ~1;
+      double w = 0.0;                     // w = J2 v  (lane i: row i of J)
+#pragma unroll 1
+      for (int k = k0; k < NV; k += 2) {
+        const double2a j2 = lds2(J + li * LDJ + k); const double2a v2 = lds2(S.dv + k);
+        w = fma(j2.x, v2.x, fma(j2.y, v2.y, w));
+      }
+      w *= beta;
+#pragma unroll 1
+      for (int k = k0; k < NV; k += 2) {
+        double2a j2 = lds2(J + li * LDJ + k); const double2a v2 = lds2(S.dv + k);
+        j2.x = fma(-w, v2.x, j2.x); j2.y = fma(-w, v2.y, j2.y);
+        if (lane < n) sts2(J + lane * LDJ + k, j2.x, j2.y);
+      }
+    }
+    const double yq = (b_e - dy) / delta;
+    if (lane == q) y1 = yq;
+    if (is_row) { if (lane == c) act_r = true; } else { if (lane == c) act_b = true; }
+    ++q;
+    WSYNC();
+  }
+  const int qe = q;
+  // ---- x_eq = J1 y1 - J2 J2' g
+  if (lane < 32) S.npv[lane] = (lane < n) ? g : 0.0;
+  WSYNC();
+  double dg = 0.0;
+#pragma unroll 2
+  for (int i = 0; i < NV; i += 2) {
+    const double2a g2 = lds2(S.npv + i);
+    dg = fma(J[i * LDJ + li], g2.x, fma(J[(i + 1) * LDJ + li], g2.y, dg));
+  }
+  if (lane < 32) S.dv[lane] = (lane < qe) ? y1 : ((lane < n) ? -dg : 0.0);
+  WSYNC();
+  double x = 0.0;
+#pragma unroll 2
+  for (int k = 0; k < NV; k += 2) {
+    const double2a j2 = lds2(J + li * LDJ + k); const double2a v2 = lds2(S.dv + k);
+    x = fma(j2.x, v2.x, fma(j2.y, v2.y, x));
+  }
+  if (lane >= n) x = 0.0;
+  STAMP(ts, T_EQ);
+
+  // ---- inequality phase
+#pragma unroll 1
+  for (;;) {
+    // most violated inactive inequality
+    if (lane < 32) S.xv[lane] = x;
+    WSYNC();
+    double best = 0.0; int code = -1;
+    if (has_b && !act_b && !eq_b) {
+      if (lb > -QP_INF) { const double s = x - lb; if (s < -1e-9 * fmax(1.0, fabs(lb)) && s < best) { best = s; code = lane; } }
+      if (ub < QP_INF) { const double s = ub - x; if (s < -1e-9 * fmax(1.0, fabs(ub)) && s < best) { best = s; code = lane | 256; } }
+    }
+    if (p > 0) {
+      double v = 0.0;
+#pragma unroll 2
+      for (int k = 0; k < NV; k += 2) {
+        const double2a c2 = lds2(Cm + (has_r ? lane : 0) * LDJ + k); const double2a x2 = lds2(S.xv + k);
+        v = fma(c2.x, x2.x, fma(c2.y, x2.y, v));
+      }
+      if (has_r && !act_r && !eq_r) {
+        if (clb > -QP_INF) { const double s = v - clb; if (s < -1e-9 * fmax(1.0, fabs(clb)) && s < best) { best = s; code = n + lane; } }
+        if (cub < QP_INF) { const double s = cub - v; if (s < -1e-9 * fmax(1.0, fabs(cub)) && s < best) { best = s; code = (n + lane) | 256; } }
+      }
+    }
+    const double worst = wmin(lane < 32 ? best : 0.0);
+    if (!(worst < 0.0)) break;                          // primal feasible -> optimal
+    const int wl = ctz64(__ballot(lane < 32 && best == worst));
+    const int wc = rdli(code, wl);
+    const int ip = wc & 255, ip_side = (wc >> 8) & 1;
+    double s_ip = worst;
+    const double b_ip = (ip < n) ? rdl(ip_side ? -ub : lb, ip) : rdl(ip_side ? -cub : clb, ip - n);
     const double sgn = ip_side ? -1.0 : 1.0;
     const bool is_row = ip >= n;
     const int rr = is_row ? ip - n : 0;
     const double np2 = is_row ? rdl(cn2, rr) : 1.0;
     double u_ip = 0.0;
-    bool added_or_skipped = false;
 
-    while (!added_or_skipped) {
+#pragma unroll 1
+    for (;;) {
       if (++iters > max_iter) { res.status = WBC_QP_MAX_ITER; goto done; }
-      // d = J' np  (lane k: column k of J)
       double d = 0.0;
       if (is_row) {
-#pragma unroll
+#pragma unroll 2
         for (int i = 0; i < NV; i += 2) {
           const double2a c2 = lds2(Cm + rr * LDJ + i);
-          d = fma(Jm[i * LDJ + li], c2.x, fma(Jm[(i + 1) * LDJ + li], c2.y, d));
+          d = fma(J[i * LDJ + li], c2.x, fma(J[(i + 1) * LDJ + li], c2.y, d));
         }
         d *= sgn;
       } else {
-        d = sgn * Jm[ip * LDJ + li];
+        d = sgn * J[ip * LDJ + li];
       }
       if (lane >= n) d = 0.0;
       if (lane < 32) S.dv[lane] = d;
       WSYNC();
       const double zn = wsum((lane >= q && lane < n) ? d * d : 0.0);
-      // z = J2 d2 (lane i: row i of J), r = T d1 (lane i < q: row i of T)
+      // z = J2 d2 (lane i: row i of J), r = T d1 over the inequality slots (lane i in [qe, q): row i of T)
       double z = 0.0, r = 0.0;
-      {
-        const int k0 = q & ~1;
-        for (int k = k0; k < NV; k += 2) {
-          const double2a j2 = lds2(Jm + li * LDJ + k); const double2a d2 = lds2(S.dv + k);
-          z = fma(j2.x, (k >= q) ? d2.x : 0.0, fma(j2.y, d2.y, z));
-        }
-        for (int k = 0; k < q; k += 2) {
-          const double2a t2 = lds2(T + li * LDJ + k); const double2a d2 = lds2(S.dv + k);
-          r = fma(t2.x, d2.x, fma(t2.y, (k + 1 < q) ? d2.y : 0.0, r));
-        }
-        if (lane >= q) r = 0.0;
-        if (lane >= n) z = 0.0;
+#pragma unroll 1
+      for (int k = q & ~1; k < NV; k += 2) {
+        const double2a j2 = lds2(J + li * LDJ + k); const double2a d2 = lds2(S.dv + k);
+        z = fma(j2.x, (k >= q) ? d2.x : 0.0, fma(j2.y, d2.y, z));
       }
+#pragma unroll 1
+      for (int k = qe & ~1; k < q; k += 2) {
+        const double2a t2 = lds2(T + li * LDJ + k); const double2a d2 = lds2(S.dv + k);
+        r = fma(t2.x, (k >= qe) ? d2.x : 0.0, fma(t2.y, (k + 1 < q) ? d2.y : 0.0, r));
+      }
+      if (lane < qe || lane >= q) r = 0.0;
+      if (lane >= n) z = 0.0;
       const bool have_step = zn > 100.0 * n * EPS2 * jf2 * np2;
-      // dual step length t1 = min u_k / r_k over inequality slots with r_k > 0
-      const bool cand = (lane < q) && !((a_code >> 9) & 1) && (r > 0.0);
+      const bool cand = (lane >= qe) && (lane < q) && (r > 0.0);
       const double ratio = cand ? u / r : INFINITY;
       const double t1 = wmin(lane < 32 ? ratio : INFINITY);
       const int l = (t1 < INFINITY) ? ctz64(__ballot(cand && ratio == t1)) : -1;
       const double t2 = have_step ? -s_ip / zn : INFINITY;
-      if (ip_eq && !have_step) {                        // dependent equality
-        if (fabs(s_ip) <= 1e-9 * fmax(1.0, fabs(b_ip))) { added_or_skipped = true; break; }
-        res.status = WBC_QP_INFEASIBLE; goto done;
-      }
-      const double t = ip_eq ? t2 : fmin(t1, t2);
+      const double t = fmin(t1, t2);
       if (!(t < INFINITY)) { res.status = WBC_QP_INFEASIBLE; goto done; }
       if (have_step) x = fma(t, z, x);
       u = fma(-t, r, u);
@@ -360,35 +449,37 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, double (&h)[NV], const doub
         const double delta = (dq >= 0.0) ? -sz : sz;
         const double vv = 2.0 * (zn - delta * dq);
         if (vv > 0.0) {
-          const double beta = 2.0 / vv;
-          const double w = (z - delta * Jm[li * LDJ + q]) * beta;
-          if (lane < n) {
-            for (int k = q; k < n; ++k) {
-              const double vk = S.dv[k] - ((k == q) ? delta : 0.0);
-              Jm[lane * LDJ + k] = fma(-w, vk, Jm[lane * LDJ + k]);
-            }
+          const double w = (z - delta * J[li * LDJ + q]) * (2.0 / vv);
+#pragma unroll 1
+          for (int k = q & ~1; k < NV; k += 2) {
+            double2a j2 = lds2(J + li * LDJ + k); const double2a d2 = lds2(S.dv + k);
+            const double v0 = (k > q) ? d2.x : ((k == q) ? d2.x - delta : 0.0);
+            const double v1 = (k + 1 > q) ? d2.y : d2.y - delta;       // k + 1 >= q always holds here
+            j2.x = fma(-w, v0, j2.x); j2.y = fma(-w, v1, j2.y);
+            if (lane < n) sts2(J + lane * LDJ + k, j2.x, j2.y);
           }
         }
         const double idel = 1.0 / delta;
-        if (lane < q) T[lane * LDJ + q] = -r * idel;
-        if (lane == q) { T[lane * LDJ + q] = idel; u = u_ip; a_code = ip | (ip_side << 8) | (ip_eq << 9); }
+        if (lane >= qe && lane < q) T[lane * LDJ + q] = -r * idel;
+        if (lane == q) { T[lane * LDJ + q] = idel; u = u_ip; a_code = wc; }
         if (is_row) { if (lane == rr) act_r = true; } else { if (lane == ip) act_b = true; }
         ++q;
-        added_or_skipped = true;
         WSYNC();
-      } else {
-        // ---- drop slot l: Givens sequence read off the removed row of T, applied to columns of T and J
+        break;
+      }
+      // ---- drop slot l: Givens sequence read off the removed row of T, applied to columns of T and J
+      {
         const int lc = rdli(a_code, l) & 255;
         if (lc >= n) { if (lane == lc - n) act_r = false; } else { if (lane == lc) act_b = false; }
-        {
-          const double un = __shfl_down(u, 1); const int an = __shfl_down(a_code, 1);
-          if (lane >= l && lane < q - 1) { u = un; a_code = an; }
-          if (lane == q - 1) { u = 0.0; a_code = 0; }
-        }
+        if (lane < 32) { S.yv[lane] = u; S.lv[lane] = (double)a_code; }     // shift slots l+1.. down by one (rare path)
+        WSYNC();
+        if (lane >= l && lane < q - 1) { u = S.yv[lane + 1]; a_code = (int)S.lv[lane + 1]; }
+        if (lane == q - 1) { u = 0.0; a_code = 0; }
         const int srow = (li >= l) ? ((li + 1 < NV) ? li + 1 : li) : li;   // old row feeding new row `lane`
         double tx = T[srow * LDJ + l];
-        double jx = Jm[li * LDJ + l];
+        double jx = J[li * LDJ + l];
         double hrun = T[l * LDJ + l];
+#pragma unroll 1
         for (int k = l; k < q - 1; ++k) {
           const double tb = T[l * LDJ + k + 1];
           const double nrm2 = fma(hrun, hrun, tb * tb);
@@ -396,20 +487,19 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, double (&h)[NV], const doub
           if (nrm2 > 0.0) { const double ri = rsqrt(nrm2); c_ = tb * ri; s_ = -hrun * ri; rho = nrm2 * ri; }
           hrun = rho;
           const double ty = T[srow * LDJ + k + 1];
-          const double jy = Jm[li * LDJ + k + 1];
+          const double jy = J[li * LDJ + k + 1];
           WSYNC();
-          if (lane < q - 1) T[lane * LDJ + k] = fma(c_, tx, s_ * ty);
-          if (lane < n) Jm[lane * LDJ + k] = fma(c_, jx, s_ * jy);
+          if (lane >= qe && lane < q - 1) T[lane * LDJ + k] = fma(c_, tx, s_ * ty);
+          if (lane < n) J[lane * LDJ + k] = fma(c_, jx, s_ * jy);
           tx = fma(-s_, tx, c_ * ty);
           jx = fma(-s_, jx, c_ * jy);
         }
         WSYNC();
         if (lane < q) T[lane * LDJ + q - 1] = 0.0;      // dropped last column, and the vacated last row
         if (lane < q) T[(q - 1) * LDJ + lane] = 0.0;
-        if (lane < n) Jm[lane * LDJ + q - 1] = jx;
+        if (lane < n) J[lane * LDJ + q - 1] = jx;
         --q;
         WSYNC();
-        // constraint ip's slack at the new x
         const double v = is_row ? wsum(lane < n ? Cm[rr * LDJ + li] * x : 0.0) : rdl(x, ip);
         s_ip = sgn * v - b_ip;
       }
@@ -428,14 +518,14 @@ done:
 // Operand maps (cdna_hip_programming.md §3): lane l feeds A_op[i = l&15][k = l>>4] and B_op[k = l>>4][j = l&15], so
 // for tile (I, J) both operands are one double per lane: A[4s + (l>>4)][16 I/J + (l&15)]. D: lane l, reg r holds
 // D[(l>>4) + 4r][l&15]. Tiles 00, 01, 11 are computed (10 = 01'). `load(r, c)` returns A[r][c] (0 outside);
-// column 26 may carry b so that -A'b falls out of the same MFMAs (written to S.npv as +A'b).
-// The tiles go to S.Jm (row-major, stride LDJ); every lane then reads its row of H into h[].
+// column 26 may carry b so that A'b falls out of the same MFMAs (written to S.npv). The tiles land in S.RA = H.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 template <class LoadA>
-__device__ __forceinline__ void jtj_mfma(Smem& S, const int lane, const int m, LoadA load, double (&h)[NV]) {
+__device__ __forceinline__ void jtj_mfma(Smem& S, const int lane, const int m, LoadA load) {
   v4f64 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
   const int kq = lane >> 4, c0 = lane & 15;
+#pragma unroll 1
   for (int s4 = 0; s4 < m; s4 += 4) {
     const double a0 = load(s4 + kq, c0);
     const double a1 = load(s4 + kq, 16 + c0);
@@ -446,39 +536,36 @@ __device__ __forceinline__ void jtj_mfma(Smem& S, const int lane, const int m, L
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = kq + 4 * r, col = c0;
-    S.Jm[row * LDJ + col] = acc00[r];
-    if (16 + col < NV) { S.Jm[row * LDJ + 16 + col] = acc01[r]; S.Jm[(16 + col) * LDJ + row] = acc01[r]; }
-    if (16 + row < NV && 16 + col < NV) S.Jm[(16 + row) * LDJ + 16 + col] = acc11[r];
+    S.RA[row * LDJ + col] = acc00[r];
+    if (16 + col < NV) { S.RA[row * LDJ + 16 + col] = acc01[r]; S.RA[(16 + col) * LDJ + row] = acc01[r]; }
+    if (16 + row < NV && 16 + col < NV) S.RA[(16 + row) * LDJ + 16 + col] = acc11[r];
     if (16 + col == NV) { S.npv[row] = acc01[r]; if (16 + row < NV) S.npv[16 + row] = acc11[r]; }
   }
   WSYNC();
-  const int li = li_clamp(lane);
-#pragma unroll
-  for (int k = 0; k < NV; k += 2) { const double2a v = lds2(S.Jm + li * LDJ + k); h[k] = v.x; h[k + 1] = v.y; }
-  WSYNC();
 }
 
-// ------------------------------------------------------------------------------------------------
-// H += A_t' A_t for one block of `nr` task rows [row0, row0+nr) over the DoF set `mask`.
-// lane k holds its own column a[] of the block; At[i][row] (LDS) supplies the other columns, uniform address.
+// H[lane][i] += sum_r At[i][row0 + r] At[lane][row0 + r] for the DoF i in `mask` (the block's support).
 template <int NR>
-__device__ __forceinline__ void jtj_block(const double* At, int mtp, int row0, unsigned mask, const double (&a)[NR],
-                                          double (&h)[NV]) {
+__device__ __forceinline__ void jtj_block(Smem& S, const double* At, const int mtp, const int row0, unsigned mask,
+                                          const int lane) {
+  const int li = li_clamp(lane);
+  double a[NR];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    if ((mask >> i) & 1u) {
-      double s = h[i];
+  for (int r = 0; r < NR; ++r) a[r] = At[li * mtp + row0 + r];
+#pragma unroll 1
+  while (mask) {
+    const int i = __ffs((int)mask) - 1;
+    mask &= mask - 1;
+    double s = S.RA[li * LDJ + i];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) s = fma(At[i * mtp + row0 + r], a[r], s);
-      h[i] = s;
-    }
+    for (int r = 0; r < NR; ++r) s = fma(At[i * mtp + row0 + r], a[r], s);
+    if (lane < NV) S.RA[lane * LDJ + i] = s;
   }
 }
 
-
 // scipy Rotation.from_matrix(M).as_quat() branch logic (Robot_Wrapper4.py:964-965); M row-major.
 // Written out per branch: a dynamically indexed M would be demoted to scratch memory.
-__device__ inline void R_to_quat(const double* M, double* q) {
+__device__ __forceinline__ void R_to_quat(const double* M, double* q) {
   const double tr = M[0] + M[4] + M[8];
   int c = 0;
   double best = M[0];
@@ -493,7 +580,7 @@ __device__ inline void R_to_quat(const double* M, double* q) {
   const double nn = sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
   q[0] = q0 / nn; q[1] = q1 / nn; q[2] = q2 / nn; q[3] = q3 / nn;
 }
-__device__ inline void quat_mul(const double* a, const double* b, double* r) {
+__device__ __forceinline__ void quat_mul(const double* a, const double* b, double* r) {
   r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
   r[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
   r[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
@@ -501,62 +588,125 @@ __device__ inline void quat_mul(const double* a, const double* b, double* r) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// per-lane constants of one model + configuration, kept in registers across the instances a wave processes
+// ------------------------------------------------------------------------------------------------
+struct LaneConst {
+  // joint lane
+  int par_off, depth, rev, pris, is_joint, q_idx, a0, a1, a2;
+  double t0, t1, t2;
+  double mass, c0, c1, c2;
+  // frame lane
+  int fj_off; double f0, f1, f2;
+  // column lane
+  int cj_off, col_lin, col_ang, col_q; unsigned subtree;
+  // damper (cfg)
+  int dq_idx; double d_lo, d_hi, d_vm;
+};
+
+__device__ __forceinline__ LaneConst load_lane_const(const DevModel& M, const WbcConfig& cfg, const int lane_true) {
+  LaneConst c;
+  const int ll = lane_true & 31;
+  const int jt = M.jtype[ll];
+  c.is_joint = (lane_true >= 2 && lane_true < M.njoints) ? 1 : 0;
+  c.rev = (c.is_joint && jt >= WBC_JT_RX && jt <= WBC_JT_RZ) ? 1 : 0;
+  c.pris = (c.is_joint && !c.rev) ? 1 : 0;
+  c.par_off = 12 * (c.is_joint ? M.parent[ll] : 1);
+  c.depth = c.is_joint ? M.depth[ll] : 0;
+  c.q_idx = c.is_joint ? M.idx_q[ll] : 0;
+  c.a0 = 3 * M.ax0[ll]; c.a1 = 3 * M.ax1[ll]; c.a2 = 3 * M.ax2[ll];
+  c.t0 = M.tp[ll][0]; c.t1 = M.tp[ll][1]; c.t2 = M.tp[ll][2];
+  c.mass = M.mass[ll]; c.c0 = M.com[ll][0]; c.c1 = M.com[ll][1]; c.c2 = M.com[ll][2];
+  const int lf = lane_true & 15;
+  c.fj_off = 12 * M.frame_joint[lf]; c.f0 = M.frame_p[lf][0]; c.f1 = M.frame_p[lf][1]; c.f2 = M.frame_p[lf][2];
+  c.cj_off = 12 * M.col_joint[ll]; c.col_lin = M.col_lin[ll]; c.col_ang = M.col_ang[ll]; c.col_q = M.col_q[ll];
+  c.subtree = (lane_true < M.nv) ? M.col_subtree[ll] : 0u;
+  const int ld = lane_true < NV ? lane_true : NV - 1;
+  c.dq_idx = cfg.damper_qidx[ld]; c.d_lo = cfg.damper_lo[ld]; c.d_hi = cfg.damper_hi[ld]; c.d_vm = cfg.damper_vmax[ld];
+  return c;
+}
+
+// the per-instance inputs, one value per lane per group (coalesced loads), staged into S.in
+struct InRegs { double g1, g2, g3a, g3b; };
+
+__device__ __forceinline__ InRegs load_inputs(const WbcTickIn& in, const int b, const int lane, const bool has2, const bool has3) {
+  InRegs r;
+  r.g1 = r.g2 = r.g3a = r.g3b = 0.0;
+  {
+    const double* p = nullptr;
+    if (lane < 27) p = in.q + (size_t)b * NQ + lane;
+    else if (lane >= IN_EET && lane < IN_EET + 15) { if (in.ee_target) p = in.ee_target + (size_t)b * 15 + (lane - IN_EET); }
+    else if (lane >= IN_EEP && lane < IN_EEP + 15) { if (in.prev_ee_target) p = in.prev_ee_target + (size_t)b * 15 + (lane - IN_EEP); }
+    else if (lane >= IN_BOX && lane < IN_BOX + 4) { if (in.trunk_box_center) p = in.trunk_box_center + (size_t)b * 4 + (lane - IN_BOX); }
+    if (p) r.g1 = *p;
+  }
+  if (has2) {
+    const double* p = nullptr;
+    const int l2 = lane + 64;
+    if (l2 < IN_TP) { if (in.trunk_target) p = in.trunk_target + (size_t)b * 3 + (l2 - IN_TT); }
+    else if (l2 < IN_TRE) { if (in.prev_trunk_target) p = in.prev_trunk_target + (size_t)b * 3 + (l2 - IN_TP); }
+    else if (l2 < IN_TPR) { if (in.trunk_ref_euler) p = in.trunk_ref_euler + (size_t)b * 3 + (l2 - IN_TRE); }
+    else if (l2 < IN_CT) { if (in.trunk_prev_rot) p = in.trunk_prev_rot + (size_t)b * 9 + (l2 - IN_TPR); }
+    else if (l2 < IN_CV) { if (in.com_target) p = in.com_target + (size_t)b * 3 + (l2 - IN_CT); }
+    else if (l2 < IN_CV + 3) { if (in.com_target_vel) p = in.com_target_vel + (size_t)b * 3 + (l2 - IN_CV); }
+    if (p) r.g2 = *p;
+  }
+  if (has3) {
+    if (lane < 45) { r.g3a = in.ee_ref_rot[(size_t)b * 45 + lane]; r.g3b = in.ee_prev_rot[(size_t)b * 45 + lane]; }
+  }
+  return r;
+}
+__device__ __forceinline__ void stage_inputs(Smem& S, const InRegs& r, const int lane, const bool has2, const bool has3) {
+  S.in[lane] = r.g1;
+  if (has2 && lane < 24) S.in[64 + lane] = r.g2;
+  if (has3 && lane < 45) { S.in[IN_ERR + lane] = r.g3a; S.in[IN_EPR + lane] = r.g3b; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // One instance: FK -> Jacobians -> task stack -> H, g, C, bounds [-> QP -> qdot -> q_next]
+// (inputs already staged in S.in)
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
-__device__ void process_instance(Smem& S, const KernelArgs& A, const int b, const int lane) {
-  const int mid = A.in.model_id ? A.in.model_id[b] : 0;
-  const DevModel& M = A.models[mid];
-  const WbcConfig& cfg = A.cfgs[mid];
+__device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
+                                                 const LaneConst& lc, const int b, const int lane) {
   const int nv = M.nv, nq = M.nq, nj = M.njoints;
   const double dt = A.dt;
-  double* oMi = S.U + OFF_OMI;          // [joint][12]: R column-major (3 columns), then p
+  double* const oMi = S.RA + OFF_OMI;   // [joint][12]: R column-major (3 columns), then p
+  const double* const qv = S.in + IN_Q;
   unsigned long long ts[T_N];
   (void)ts;
   STAMP(ts, T_START);
-  const int ll = lane & 31;             // index into the 32-entry per-lane model tables
-
-  // ---- P0: q (coalesced), updateState's config (Robot_Wrapper4.py:389-402)
-  const double* qg = A.in.q + (size_t)b * NQ;
-  if (lane < 32) S.qv[lane] = (lane < nq) ? qg[lane] : 0.0;
-  WSYNC();
 
   // ---- P1: forward kinematics, pin.forwardKinematics (Robot_Wrapper4.py:400)
-  // root free-flyer: R from the quaternion exactly as Eigen's toRotationMatrix, p = xyz (every lane, uniform)
+  // root free-flyer: R from the quaternion exactly as Eigen's toRotationMatrix, p = xyz
   if (lane == 1) {
     double Rt[9];
-    quat_to_R(S.qv + 3, Rt);
+    quat_to_R(qv + 3, Rt);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int r = 0; r < 3; ++r) oMi[12 + 3 * c + r] = Rt[3 * r + c];
-    oMi[12 + 9] = S.qv[0]; oMi[12 + 10] = S.qv[1]; oMi[12 + 11] = S.qv[2];
+    oMi[12 + 9] = qv[0]; oMi[12 + 10] = qv[1]; oMi[12 + 11] = qv[2];
   }
   {
-    const int jt = M.jtype[ll];
-    const bool is_joint = lane >= 2 && lane < nj;
-    const bool rev = jt >= WBC_JT_RX && jt <= WBC_JT_RZ;
-    const double th = is_joint ? S.qv[M.idx_q[ll]] : 0.0;
-    double sn = 0.0, cs = 1.0;
-    if (rev) sincos(th, &sn, &cs);
-    const double pris = (is_joint && !rev) ? th : 0.0;
-    const int a0 = 3 * M.ax0[ll], a1 = 3 * M.ax1[ll], a2 = 3 * M.ax2[ll];
-    const double t0 = M.tp[ll][0], t1 = M.tp[ll][1], t2 = M.tp[ll][2];
-    const int par = is_joint ? M.parent[ll] : 1, dep = is_joint ? M.depth[ll] : 0;
+    const double th = lc.is_joint ? qv[lc.q_idx] : 0.0;
+    const SinCos sc = sincos_cw(lc.rev ? th : 0.0);
+    const double sn = sc.s, cs = sc.c;
+    const double pris = lc.pris ? th : 0.0;
     WSYNC();
+#pragma unroll 1
     for (int lvl = 2; lvl <= M.maxdepth; ++lvl) {
-      if (dep == lvl) {
-        const double* Pp = oMi + 12 * par;
+      if (lc.depth == lvl) {
+        const double* Pp = oMi + lc.par_off;
         double Av[3], Bv[3], Cv[3], P[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { Av[r] = Pp[a0 + r]; Bv[r] = Pp[a1 + r]; Cv[r] = Pp[a2 + r]; P[r] = Pp[9 + r]; }
+        for (int r = 0; r < 3; ++r) { Av[r] = Pp[lc.a0 + r]; Bv[r] = Pp[lc.a1 + r]; Cv[r] = Pp[lc.a2 + r]; P[r] = Pp[9 + r]; }
         double* Po = oMi + 12 * lane;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-          Po[a0 + r] = Av[r];
-          Po[a1 + r] = cs * Bv[r] + sn * Cv[r];
-          Po[a2 + r] = cs * Cv[r] - sn * Bv[r];
-          Po[9 + r] = P[r] + Av[r] * (t0 + pris) + Bv[r] * t1 + Cv[r] * t2;
+          Po[lc.a0 + r] = Av[r];
+          Po[lc.a1 + r] = cs * Bv[r] + sn * Cv[r];
+          Po[lc.a2 + r] = cs * Cv[r] - sn * Bv[r];
+          Po[9 + r] = P[r] + Av[r] * (lc.t0 + pris) + Bv[r] * lc.t1 + Cv[r] * lc.t2;
         }
       }
       WSYNC();
@@ -564,40 +714,37 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
   }
   // ---- P2: frame origins, pin.updateFramePlacements (Robot_Wrapper4.py:405); frames carry no rotation offset
   if (lane < M.nframes) {
-    const double* Pj = oMi + 12 * M.frame_joint[lane];
-    const double f0 = M.frame_p[lane][0], f1 = M.frame_p[lane][1], f2 = M.frame_p[lane][2];
+    const double* Pj = oMi + lc.fj_off;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) S.pf[3 * lane + r] = Pj[9 + r] + Pj[r] * f0 + Pj[3 + r] * f1 + Pj[6 + r] * f2;
+    for (int r = 0; r < 3; ++r) S.pf[3 * lane + r] = Pj[9 + r] + Pj[r] * lc.f0 + Pj[3 + r] * lc.f1 + Pj[6 + r] * lc.f2;
   }
   const bool need_com = cfg.task_com || cfg.con_com || (MODE == MODE_FK && (A.fk.com || A.fk.Jcom));
   if (need_com) {   // m_j * c_j (world) per joint, pin.jacobianCenterOfMass's subtree pass (Robot_Wrapper4.py:670)
-    double* mc = S.U + OFF_MC;
+    double* mc = S.RA + OFF_MC;
     if (lane >= 1 && lane < nj) {
       const double* Pj = oMi + 12 * lane;
-      const double m = M.mass[ll], c0 = M.com[ll][0], c1 = M.com[ll][1], c2 = M.com[ll][2];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) mc[4 * lane + r] = m * (Pj[9 + r] + Pj[r] * c0 + Pj[3 + r] * c1 + Pj[6 + r] * c2);
-      mc[4 * lane + 3] = m;
+      for (int r = 0; r < 3; ++r) mc[4 * lane + r] = lc.mass * (Pj[9 + r] + Pj[r] * lc.c0 + Pj[3 + r] * lc.c1 + Pj[6 + r] * lc.c2);
+      mc[4 * lane + 3] = lc.mass;
     }
   }
   WSYNC();
   // ---- P3: column k of data.J, pin.computeJointJacobians (Robot_Wrapper4.py:403), WORLD frame
   double lin[3] = {0, 0, 0}, ang[3] = {0, 0, 0};
-  const int cj = M.col_joint[ll];
   if (lane < nv) {
-    const double* Pj = oMi + 12 * cj;
-    const int la = M.col_lin[ll], aa = M.col_ang[ll];
-    double pj[3] = {Pj[9], Pj[10], Pj[11]};
+    const double* Pj = oMi + lc.cj_off;
+    const int la = lc.col_lin, aa = lc.col_ang;
+    const double pj[3] = {Pj[9], Pj[10], Pj[11]};
     if (aa >= 0) { ang[0] = Pj[3 * aa]; ang[1] = Pj[3 * aa + 1]; ang[2] = Pj[3 * aa + 2]; cross3(pj, ang, lin); }
     if (la >= 0) { lin[0] = Pj[3 * la]; lin[1] = Pj[3 * la + 1]; lin[2] = Pj[3 * la + 2]; }
   }
   double com[3] = {0, 0, 0}, jc[3] = {0, 0, 0};   // whole-body CoM (uniform) and column k of Jcom
   if (need_com) {
-    const double* mc = S.U + OFF_MC;
-    const unsigned sub = (lane < nv) ? M.col_subtree[ll] : 0u;
+    const double* mc = S.RA + OFF_MC;
     double ms = 0, s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll 1
     for (int j = 1; j < nj; ++j) {
-      const double f = ((sub >> j) & 1u) ? 1.0 : 0.0;
+      const double f = ((lc.subtree >> j) & 1u) ? 1.0 : 0.0;
       s0 = fma(f, mc[4 * j], s0); s1 = fma(f, mc[4 * j + 1], s1); s2 = fma(f, mc[4 * j + 2], s2); ms = fma(f, mc[4 * j + 3], ms);
     }
     const double Mt = rdl(ms, 0);
@@ -635,7 +782,7 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     }
     if (A.fk.oMf && lane < M.nframes) {
       double* o = A.fk.oMf + ((size_t)b * A.models[0].nframes + lane) * 12;
-      const double* Pj = oMi + 12 * M.frame_joint[lane];
+      const double* Pj = oMi + lc.fj_off;
       for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o[3 * r + c] = Pj[3 * c + r];
       o[9] = S.pf[3 * lane]; o[10] = S.pf[3 * lane + 1]; o[11] = S.pf[3 * lane + 2];
     }
@@ -648,19 +795,20 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     WSYNC();
     return;
   }
-
   STAMP(ts, T_FK);
+
   // ---- P4/P5: task stack. qpA/qpb (Robot_Wrapper4.py:1271-1294) feeding H = A'A, g = -A'b (QP_Wrapper.py:17-18)
-  WSYNC();   // every lane is done reading oMi / mc: the region is reused for At from here on
-  double h[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) h[i] = 0.0;
+  WSYNC();   // every lane is done reading oMi / mc: RA becomes H from here on
   double g = 0.0;
-  double* At = S.U + OFF_AT;
-  const int mtp = (A.mcart + 3) / 4 * 4 + 2;     // ≡ 2 mod 4
+  double* const At = S.RB;                         // At[dof][row], spills over into RC (both free until P6)
+  const int mtp = (A.mcart + 3) / 4 * 4 + 2;       // ≡ 2 mod 4
   int row = 0;
-  const bool out_A = (MODE == MODE_ASSEMBLE) && A.qp.A != nullptr;
+  if (lane < NV) {
+#pragma unroll 1
+    for (int k = 0; k < NV; k += 2) sts2(S.RA + lane * LDJ + k, 0.0, 0.0);
+  }
   // pass 1: every lane writes its column of every Cartesian block to At and accumulates g
+#pragma unroll 1
   for (int e = 0; e < WBC_NEE; ++e) {
     if (!cfg.task_ee[e]) continue;
     const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_EE0 + e] >> lane) & 1u);
@@ -676,15 +824,15 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
         a[3 + r] = sup ? cfg.ee_W[e][3 + r] * (ang[r] * w) : 0.0;
       }
     }
-    // calcTargetVelEE3 (Robot_Wrapper4.py:1052-1157) — uniform arithmetic
-    const double* xt = A.in.ee_target + ((size_t)b * WBC_NEE + e) * 3;
-    const double* xp = A.in.prev_ee_target + ((size_t)b * WBC_NEE + e) * 3;
+    // calcTargetVelEE3 (Robot_Wrapper4.py:1052-1157) — uniform arithmetic on the staged inputs
+    const double* xt = S.in + IN_EET + 3 * e;
+    const double* xp = S.in + IN_EEP + 3 * e;
     double vel[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) / dt + cfg.ee_gain[e][i] * ((xt[i] - pfe[i]) / dt);
-    if (A.in.ee_ref_rot && A.in.ee_prev_rot) {   // omega = vee(((R* - R*_prev)/dt) R*^T)  (:1125-1128, 1133)
-      const double* Rs = A.in.ee_ref_rot + ((size_t)b * WBC_NEE + e) * 9;
-      const double* Rp = A.in.ee_prev_rot + ((size_t)b * WBC_NEE + e) * 9;
+    if (A.in.ee_ref_rot) {   // omega = vee(((R* - R*_prev)/dt) R*^T)  (:1125-1128, 1133)
+      const double* Rs = S.in + IN_ERR + 9 * e;
+      const double* Rp = S.in + IN_EPR + 9 * e;
       double D[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) D[i] = (Rs[i] - Rp[i]) / dt;
@@ -709,24 +857,27 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
       a[r] = sup ? (cfg.trunk_W[r] * lin[r]) * cfg.trunk_w : 0.0;
       a[3 + r] = sup ? (cfg.trunk_W[3 + r] * ang[r]) * cfg.trunk_w : 0.0;
     }
-    const double* xt = A.in.trunk_target + (size_t)b * 3;
-    const double* xp = A.in.prev_trunk_target + (size_t)b * 3;
+    const double* xt = S.in + IN_TT;
+    const double* xp = S.in + IN_TP;
     double vel[6];
 #pragma unroll
     for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) / dt + cfg.trunk_gain[i] * ((xt[i] - ptr[i]) / dt);
     double fq[4], rq[4], Rs[9];
     R_to_quat(Rtr, fq);
-    const double* er = A.in.trunk_ref_euler + (size_t)b * 3;
+    const double* er = S.in + IN_TRE;
     {
-      double sa, ca, sb, cb, sc, cc;
-      sincos(er[0], &sa, &ca); sincos(er[1], &sb, &cb); sincos(er[2], &sc, &cc);
+      // sin/cos of the three reference angles and of their halves: one loop body, results parked in LDS
+#pragma unroll 1
+      for (int i = 0; i < 6; ++i) {
+        const SinCos t = sincos_cw(i < 3 ? er[i] : 0.5 * er[i - 3]);
+        if (lane == 0) { S.yv[2 * i] = t.s; S.yv[2 * i + 1] = t.c; }
+      }
+      WSYNC();
+      const double sa = S.yv[0], ca = S.yv[1], sb = S.yv[2], cb = S.yv[3], sc = S.yv[4], cc = S.yv[5];
       Rs[0] = cc * cb; Rs[1] = cc * sb * sa - sc * ca; Rs[2] = cc * sb * ca + sc * sa;
       Rs[3] = sc * cb; Rs[4] = sc * sb * sa + cc * ca; Rs[5] = sc * sb * ca - cc * sa;
       Rs[6] = -sb;     Rs[7] = cb * sa;                Rs[8] = cb * ca;
-      double s2, c2;
-      sincos(er[0] / 2, &s2, &c2); const double qx[4] = {s2, 0, 0, c2};
-      sincos(er[1] / 2, &s2, &c2); const double qy[4] = {0, s2, 0, c2};
-      sincos(er[2] / 2, &s2, &c2); const double qz[4] = {0, 0, s2, c2};
+      const double qx[4] = {S.yv[6], 0, 0, S.yv[7]}, qy[4] = {0, S.yv[8], 0, S.yv[9]}, qz[4] = {0, 0, S.yv[10], S.yv[11]};
       double tq[4];
       quat_mul(qy, qx, tq);
       quat_mul(qz, tq, rq);
@@ -734,7 +885,7 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     const double qe0 = fq[3] * rq[0] - fq[0] * rq[3] + fq[1] * rq[2] - fq[2] * rq[1];   // :974
     const double qe1 = fq[3] * rq[1] - fq[1] * rq[3] - fq[0] * rq[2] + fq[2] * rq[0];   // :975
     const double qe2 = fq[3] * rq[2] - fq[3] * rq[2] + fq[0] * rq[1] - fq[1] * rq[0];   // :976 (sic)
-    const double* Ro = A.in.trunk_prev_rot + (size_t)b * 9;
+    const double* Ro = S.in + IN_TPR;
     double D[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) D[i] = (Rs[i] - Ro[i]) / dt;
@@ -752,8 +903,8 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     row += 6;
   }
   if (cfg.task_com) {     // Robot_Wrapper2 comJacobian (:600-603), cartesianTargetCoM (:661-668)
-    const double* ct = A.in.com_target + (size_t)b * 3;
-    const double* cv = A.in.com_target_vel + (size_t)b * 3;
+    const double* ct = S.in + IN_CT;
+    const double* cv = S.in + IN_CV;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const double ar = cfg.com_W[r] * jc[r];
@@ -765,55 +916,39 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     row += 3;
   }
   WSYNC();
-  // pass 2: H[lane][i] += sum_r At[i][r] At[lane][r]
+  // pass 2: H[lane][i] = sum_r At[i][r] At[lane][r]
   if (A.jtj_mfma) {
     // dense contraction on the fp64 matrix cores (the operand comes straight from the At image in LDS)
     const int mc = A.mcart;
-    jtj_mfma(S, lane, mc, [&](int r, int c) -> double { return (r < mc && c < NV) ? At[c * mtp + r] : 0.0; }, h);
+    jtj_mfma(S, lane, mc, [&](int r, int c) -> double { return (r < mc && c < NV) ? At[c * mtp + r] : 0.0; });
   } else {
     // vector units, block by block over each block's DoF support (skips the structural zeros of the Jacobians)
     int r0 = 0;
+#pragma unroll 1
     for (int e = 0; e < WBC_NEE; ++e) {
       if (!cfg.task_ee[e]) continue;
-      double a[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) a[r] = At[li_clamp(lane) * mtp + r0 + r];
-      jtj_block<6>(At, mtp, r0, M.frame_support[WBC_FR_EE0 + e], a, h);
+      jtj_block<6>(S, At, mtp, r0, M.frame_support[WBC_FR_EE0 + e], lane);
       r0 += 6;
     }
-    if (cfg.task_trunk) {
-      double a[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) a[r] = At[li_clamp(lane) * mtp + r0 + r];
-      jtj_block<6>(At, mtp, r0, M.frame_support[WBC_FR_TRUNK], a, h);
-      r0 += 6;
-    }
-    if (cfg.task_com) {
-      double a[3];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) a[r] = At[li_clamp(lane) * mtp + r0 + r];
-      jtj_block<3>(At, mtp, r0, (1u << nv) - 1u, a, h);
-      r0 += 3;
-    }
+    if (cfg.task_trunk) { jtj_block<6>(S, At, mtp, r0, M.frame_support[WBC_FR_TRUNK], lane); r0 += 6; }
+    if (cfg.task_com) { jtj_block<3>(S, At, mtp, r0, (1u << nv) - 1u, lane); r0 += 3; }
   }
   // posture rows: qpJointA (Robot_Wrapper4.py:1199-1206), qpJointb (:1209-1268)
   double dpost = 0.0, upost = 0.0;
   if (cfg.task_joint) {
     dpost = (1.0 / nv) * cfg.joint_w;
-    if (cfg.task_joint == WBC_JOINT_PREV && lane < nv) upost = S.qv[lane < 6 ? lane : lane + 1];   // np.delete(q, 6)
+    if (cfg.task_joint == WBC_JOINT_PREV && lane < nv) upost = qv[lane < 6 ? lane : lane + 1];   // np.delete(q, 6)
     const double bj = (1.0 / nv) * upost * cfg.joint_w;
     if (lane < nv) g = fma(-dpost, bj, g);
     upost = bj;
   }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    if (i == lane) h[i] += (lane < nv) ? dpost * dpost : 1.0;   // padded DoF: H_dd = 1
-  }
+  if (lane < NV) S.RA[lane * LDJ + lane] += (lane < nv) ? dpost * dpost : 1.0;   // padded DoF: H_dd = 1
   if (lane >= nv) g = 0.0;
+  WSYNC();
 
   if (MODE == MODE_ASSEMBLE) {
     const int m = A.mrows;
-    if (out_A && lane < NV) {
+    if (A.qp.A && lane < NV) {
       double* o = A.qp.A + (size_t)b * m * NV;
       for (int r = 0; r < A.mcart; ++r) o[r * NV + lane] = At[lane * mtp + r];
       if (cfg.task_joint) for (int r = 0; r < NV; ++r) o[(A.mcart + r) * NV + lane] = (r == lane && lane < nv) ? dpost : 0.0;
@@ -825,15 +960,14 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     }
     if (A.qp.H && lane < NV) {
       double* o = A.qp.H + (size_t)b * NV * NV + (size_t)lane * NV;
-#pragma unroll
-      for (int k = 0; k < NV; ++k) o[k] = h[k];
+      for (int k = 0; k < NV; ++k) o[k] = S.RA[lane * LDJ + k];
     }
     if (A.qp.g && lane < NV) A.qp.g[(size_t)b * NV + lane] = g;
   }
   WSYNC();   // At is dead: Cm may be written
 
   // ---- P6: constraints in order CoM, Trunk, FR, FL, RR, RL, Grip: findConstraints (Robot_Wrapper4.py:764-836)
-  double* Cm = S.U + OFF_CM;
+  double* const Cm = S.RC;
   double clb = 0.0, cub = 0.0;
   int prow = 0;
   if (cfg.con_com) {   // CoMConstraint (Robot_Wrapper4.py:669-694); EE_frame_pos[1] = FL, [2] = RR
@@ -851,7 +985,7 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     double wxp[3];
     cross3(ang, ptr, wxp);
     const double rowv[4] = {sup ? lin[2] + wxp[2] : 0.0, sup ? ang[0] : 0.0, sup ? ang[1] : 0.0, sup ? ang[2] : 0.0};
-    const double* bc = A.in.trunk_box_center + (size_t)b * 4;
+    const double* bc = S.in + IN_BOX;
     // scipy as_euler('xyz') of the trunk rotation (:714-715)
     const double cur[4] = {ptr[2], atan2(Rtr[7], Rtr[8]), -asin(Rtr[6]), atan2(Rtr[3], Rtr[0])};
     const double var[4] = {bc[0] * cfg.trunk_box_z_frac, cfg.trunk_box_ang, cfg.trunk_box_ang, cfg.trunk_box_ang};
@@ -864,6 +998,7 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     }
     prow += 4;
   }
+#pragma unroll 1
   for (int e = 0; e < WBC_NEE; ++e) {   // EEConstraint (Robot_Wrapper4.py:757-761): WORLD rows 0..2, 0 <= . <= 0
     if (!cfg.con_ee[e]) continue;
     const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_EE0 + e] >> lane) & 1u);
@@ -879,7 +1014,7 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
   if (lane < nv) {
     if (!cfg.use_bounds) { lb = -1e30; ub = 1e30; }
     else {
-      const double qi = S.qv[cfg.damper_qidx[ll]], lo = cfg.damper_lo[ll], hi = cfg.damper_hi[ll], vm = cfg.damper_vmax[ll];
+      const double qi = qv[lc.dq_idx], lo = lc.d_lo, hi = lc.d_hi, vm = lc.d_vm;
       if (qi <= lo + cfg.damper_qi) {
         lb = -cfg.damper_coef * (qi - lo - cfg.damper_qs) / (cfg.damper_qi - cfg.damper_qs);
         if (lb > vm) lb = vm;
@@ -906,10 +1041,10 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     WSYNC();
     return;
   }
-
   STAMP(ts, T_ASM);
+
   // ---- P7/P8: the QP (QP_Wrapper.py:23-73). Padded DoF (lane >= nv) carry no constraint and stay 0.
-  const QpResult res = qp_core(S, h, g, lb, ub, clb, cub, nv, A.prows, lane, ts);
+  const QpResult res = qp_core(S, g, lb, ub, clb, cub, nv, A.prows, lane, ts);
   if (A.out.qdot && lane < NV) A.out.qdot[(size_t)b * NV + lane] = (lane < nv) ? res.x : 0.0;
   if (lane == 0) {
     if (A.out.status) A.out.status[b] = res.status;
@@ -921,11 +1056,8 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
     const double v = res.x * dt;
     if (lane < 32) S.xv[lane] = (lane < nv) ? v : 0.0;
     WSYNC();
-    double R0[9], p0[3];
-    quat_to_R(S.qv + 3, R0);
-    p0[0] = S.qv[0]; p0[1] = S.qv[1]; p0[2] = S.qv[2];
-    integrate_ff(S, lane, R0, p0, qn);
-    if (lane >= 6 && lane < nv) qn[M.col_q[ll]] = S.qv[M.col_q[ll]] + v;
+    integrate_ff(S, lane, qn);
+    if (lane >= 6 && lane < nv) qn[lc.col_q] = qv[lc.col_q] + v;
     if (lane >= nq && lane < NQ) qn[lane] = 0.0;
     WSYNC();
   }
@@ -940,28 +1072,48 @@ __device__ void process_instance(Smem& S, const KernelArgs& A, const int b, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// kernels: single-wave workgroups, persistent over the batch (exit: b >= B, reached by every wave)
+// kernels: single-wave workgroups, persistent over the batch (exit: b >= B, reached by every wave);
+// the next instance's inputs are fetched from HBM while the current one is being solved.
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A) {
   __shared__ Smem S;
-  for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
-    int lane = threadIdx.x;
-    asm volatile("" : "+v"(lane));   // keep lane-derived values out of LICM's reach (they would be spilled)
-    process_instance<MODE>(S, A, b, lane);
+  const int lane_true = threadIdx.x;
+  const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
+                    A.in.com_target || A.in.com_target_vel;
+  const bool has3 = A.in.ee_ref_rot != nullptr;
+  int b = blockIdx.x;
+  if (b >= A.B) return;
+  int mid = A.in.model_id ? A.in.model_id[b] : 0;
+  LaneConst lc = load_lane_const(A.models[mid], A.cfgs[mid], lane_true);
+  InRegs cur = load_inputs(A.in, b, lane_true, has2, has3);
+#pragma unroll 1
+  for (; b < A.B; b += gridDim.x) {
+    int lane = lane_true;
+    asm volatile("" : "+v"(lane));   // keep lane-derived masks out of LICM's reach (they would be spilled)
+    stage_inputs(S, cur, lane, has2, has3);
+    WSYNC();
+    const int bn = b + gridDim.x;
+    int mid_next = mid;
+    if (bn < A.B) {                  // prefetch: these loads complete while this instance is processed
+      cur = load_inputs(A.in, bn, lane, has2, has3);
+      if (A.in.model_id) mid_next = A.in.model_id[bn];
+    }
+    process_instance<MODE>(S, A, A.models[mid], A.cfgs[mid], lc, b, lane);
+    if (mid_next != mid) { mid = mid_next; lc = load_lane_const(A.models[mid], A.cfgs[mid], lane_true); }
+    WSYNC();
   }
 }
 
 // Stand-alone QP (QP_Wrapper.QP.solveQP): H, g (or A, b) and constraints straight from HBM.
 __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
   __shared__ Smem S;
+#pragma unroll 1
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     int lane = threadIdx.x, n = A.n, p = A.p, m = A.m;
     asm volatile("" : "+v"(lane), "+s"(n), "+s"(p), "+s"(m));   // no LICM of lane/n-derived masks
-    double h[NV];
+    const int li = li_clamp(lane);
     double g = 0.0;
-    unsigned long long nullptr_ts[T_N];
-    (void)nullptr_ts;
     if (m > 0) {
       // H = A'A, g = -A'b (QP_Wrapper.py:17-18)
       const double* Ab = A.A + (size_t)b * m * n;
@@ -972,43 +1124,63 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
           if (r >= m) return 0.0;
           if (c < n) return Ab[(size_t)r * n + c];
           return (c == NV) ? bb[r] : 0.0;
-        }, h);
-        g = (lane < n) ? -S.npv[li_clamp(lane)] : 0.0;
-        WSYNC();
+        });
+        g = (lane < n) ? -S.npv[li] : 0.0;
+        if (n < NV) {                                   // padded rows / columns of H are exactly zero off the diagonal
+          WSYNC();
+        }
       } else {
-        // vector path: lane k owns column k; row r of A is broadcast by uniform loads
-#pragma unroll
-        for (int i = 0; i < NV; ++i) h[i] = 0.0;
-        for (int r = 0; r < m; ++r) {
-          const double ak = (lane < n) ? Ab[(size_t)r * n + lane] : 0.0;
-          g = fma(-ak, bb[r], g);
-#pragma unroll
-          for (int i = 0; i < NV; ++i) h[i] = fma((i < n) ? Ab[(size_t)r * n + i] : 0.0, ak, h[i]);
+        // vector path: A is staged by DoF (At[dof][row]) in chunks of <= 48 rows; H accumulates in RA
+        double* const At = S.RB;
+        constexpr int CH = 48, MT = 50;
+        if (lane < NV) for (int k = 0; k < NV; k += 2) sts2(S.RA + lane * LDJ + k, 0.0, 0.0);
+#pragma unroll 1
+        for (int r0 = 0; r0 < m; r0 += CH) {
+          const int mc = (m - r0 < CH) ? m - r0 : CH;
+#pragma unroll 1
+          for (int r = 0; r < CH; ++r) {
+            const double a = (r < mc && lane < n) ? Ab[(size_t)(r0 + r) * n + lane] : 0.0;
+            if (lane < NV) At[lane * MT + r] = a;
+            if (r < mc) g = fma(-a, bb[r0 + r], g);
+          }
+          WSYNC();
+#pragma unroll 1
+          for (int i = 0; i < n; ++i) {
+            double s = S.RA[li * LDJ + i];
+#pragma unroll 2
+            for (int r = 0; r < CH; r += 2) {
+              const double2a x2 = lds2(At + i * MT + r); const double2a y2 = lds2(At + li * MT + r);
+              s = fma(x2.x, y2.x, fma(x2.y, y2.y, s));
+            }
+            if (lane < NV) S.RA[lane * LDJ + i] = s;
+          }
+          WSYNC();
         }
       }
-#pragma unroll
-      for (int i = 0; i < NV; ++i) if (i == lane && lane >= n) h[i] = 1.0;
-      if (A.H_out && lane < n) {
-        double* o = A.H_out + (size_t)b * n * n + (size_t)lane * n;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) if (k < n) o[k] = h[k];
-      }
+      if (lane >= n && lane < NV) S.RA[lane * LDJ + lane] = 1.0;   // padded DoF
+      WSYNC();
+      if (A.H_out && lane < n) { double* o = A.H_out + (size_t)b * n * n + (size_t)lane * n; for (int k = 0; k < n; ++k) o[k] = S.RA[lane * LDJ + k]; }
       if (A.g_out && lane < n) A.g_out[(size_t)b * n + lane] = g;
     } else {
       const double* Hb = A.H + (size_t)b * n * n;
-#pragma unroll
-      for (int k = 0; k < NV; ++k) h[k] = (lane < n && k < n) ? Hb[(size_t)lane * n + k] : ((k == lane) ? 1.0 : 0.0);
+#pragma unroll 1
+      for (int idx = lane; idx < NV * NV; idx += 64) {
+        const int r = idx / NV, c = idx - r * NV;
+        S.RA[r * LDJ + c] = (r < n && c < n) ? Hb[(size_t)r * n + c] : ((r == c) ? 1.0 : 0.0);
+      }
       g = (lane < n) ? A.g[(size_t)b * n + lane] : 0.0;
     }
-    double* Cm = S.U + OFF_CM;
+#pragma unroll 1
     for (int r = 0; r < p; ++r)
-      if (lane < NV) Cm[r * LDJ + lane] = (lane < n) ? A.C[((size_t)b * p + r) * n + lane] : 0.0;
+      if (lane < NV) S.RC[r * LDJ + lane] = (lane < n) ? A.C[((size_t)b * p + r) * n + lane] : 0.0;
     const double lb = (lane < n) ? (A.lb ? A.lb[(size_t)b * n + lane] : -1e30) : 0.0;
     const double ub = (lane < n) ? (A.ub ? A.ub[(size_t)b * n + lane] : 1e30) : 0.0;
     const double clb = (lane < p) ? A.Clb[(size_t)b * p + lane] : 0.0;
     const double cub = (lane < p) ? A.Cub[(size_t)b * p + lane] : 0.0;
     WSYNC();
-    const QpResult res = qp_core(S, h, g, lb, ub, clb, cub, n, p, lane, nullptr_ts);
+    unsigned long long ts[T_N];
+    (void)ts;
+    const QpResult res = qp_core(S, g, lb, ub, clb, cub, n, p, lane, ts);
     if (lane < n) A.x[(size_t)b * n + lane] = res.x;
     if (lane == 0) {
       if (A.status) A.status[b] = res.status;
@@ -1021,22 +1193,20 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
 // pin.integrate for a batch (Robot_Wrapper4.py:440-441): q_next = q (+) v * dt
 __global__ void __launch_bounds__(64) wbc_integrate_kernel(const IntegrateArgs A) {
   __shared__ Smem S;
+#pragma unroll 1
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     int lane = threadIdx.x;
     asm volatile("" : "+v"(lane));
     const DevModel& M = A.models[A.model_id ? A.model_id[b] : 0];
     const int nv = M.nv, nq = M.nq;
-    if (lane < 32) S.qv[lane] = (lane < nq) ? A.q[(size_t)b * NQ + lane] : 0.0;
+    if (lane < 32) S.in[IN_Q + lane] = (lane < nq) ? A.q[(size_t)b * NQ + lane] : 0.0;
     const double v = (lane < nv) ? A.v[(size_t)b * NV + lane] * A.dt : 0.0;
     if (lane < 32) S.xv[lane] = v;
     WSYNC();
-    double R0[9], p0[3];
-    quat_to_R(S.qv + 3, R0);
-    p0[0] = S.qv[0]; p0[1] = S.qv[1]; p0[2] = S.qv[2];
     double* qn = A.q_next + (size_t)b * NQ;
-    integrate_ff(S, lane, R0, p0, qn);
-    const int ll = lane & 31;
-    if (lane >= 6 && lane < nv) qn[M.col_q[ll]] = S.qv[M.col_q[ll]] + v;
+    integrate_ff(S, lane, qn);
+    const int cq = M.col_q[lane & 31];
+    if (lane >= 6 && lane < nv) qn[cq] = S.in[IN_Q + cq] + v;
     if (lane >= nq && lane < NQ) qn[lane] = 0.0;
     WSYNC();
   }

@@ -144,3 +144,155 @@ def solve(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, max_iter=None):
             T[:q - 1, :q - 1] = np.triu(Tt[:, :q - 1])
             q -= 1
             s_ip = (-1.0 if side else 1.0) * value(ip, x) - b_ip
+
+
+
+def solve_v2(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, max_iter=None):
+    """Kernel v2 algebra: the equalities are absorbed first by a Householder QR of J'N_e that updates only J
+    (x and the multipliers are not tracked meanwhile); x_eq = J1 y1 - J2 J2'g with R'y1 = b_e solved incrementally;
+    T = R^-1 is kept only for the inequality slots (its lower-right block, which is all r = T d1 and the drop ever read)."""
+    n = len(g)
+    p = 0 if C is None else C.shape[0]
+    ncon = n + p
+
+    def lo(c):
+        return (lb[c] if lb is not None else -1e30) if c < n else Clb[c - n]
+
+    def hi(c):
+        return (ub[c] if ub is not None else 1e30) if c < n else Cub[c - n]
+
+    def normal(c, side):
+        sgn = -1.0 if side else 1.0
+        if c < n:
+            e = np.zeros(n)
+            e[c] = sgn
+            return e
+        return sgn * C[c - n]
+
+    def value(c, x):
+        return x[c] if c < n else C[c - n] @ x
+
+    try:
+        L = np.linalg.cholesky(H)
+    except np.linalg.LinAlgError:
+        return np.zeros(n), 3, 0
+    J = np.linalg.inv(L).T.copy()
+    jf2 = (J * J).sum()
+    iters = 0
+    max_iter = max_iter or 10 * (n + p) + 20
+    # ---- equality block
+    q = 0
+    y1 = np.zeros(n)
+    active = np.zeros(ncon, bool)
+    for c in range(ncon):
+        if not (lo(c) == hi(c) and abs(lo(c)) < INF):
+            continue
+        iters += 1
+        npv = normal(c, 0)
+        b_e = lo(c)
+        d = J.T @ npv
+        zn = d[q:] @ d[q:]
+        dy = d[:q] @ y1[:q]
+        if not zn > 100.0 * n * EPS2 * jf2 * (npv @ npv):
+            if abs(dy - b_e) <= 1e-9 * max(1.0, abs(b_e)):
+                continue
+            return np.zeros(n), 2, iters
+        dq = d[q]
+        delta = -np.sqrt(zn) if dq >= 0 else np.sqrt(zn)
+        v = d[q:].copy()
+        v[0] -= delta
+        vv = 2.0 * (zn - delta * dq)
+        if vv > 0:
+            w = J[:, q:] @ v
+            J[:, q:] -= np.outer(w, (2.0 / vv) * v)
+        y1[q] = (b_e - dy) / delta
+        active[c] = True
+        q += 1
+    qe = q
+    dg = J.T @ g
+    yv = np.concatenate([y1[:qe], -dg[qe:]])
+    x = J @ yv
+    # ---- inequality phase: slots qe.. ; T holds only the (q-qe) x (q-qe) block
+    T = np.zeros((n, n))
+    u = np.zeros(n + 1)
+    act = []
+    while True:
+        worst, ip = 0.0, -1
+        for c in range(ncon):
+            if active[c] or (lo(c) == hi(c) and abs(lo(c)) < INF):
+                continue
+            vv_ = value(c, x)
+            if lo(c) > -INF:
+                s = vv_ - lo(c)
+                if s < -1e-9 * max(1.0, abs(lo(c))) and s < worst:
+                    worst, ip, side, b_ip = s, c, 0, lo(c)
+            if hi(c) < INF:
+                s = hi(c) - vv_
+                if s < -1e-9 * max(1.0, abs(hi(c))) and s < worst:
+                    worst, ip, side, b_ip = s, c, 1, -hi(c)
+        if ip < 0:
+            return x, 0, iters
+        s_ip = worst
+        npv = normal(ip, side)
+        np2 = npv @ npv
+        u_ip = 0.0
+        while True:
+            iters += 1
+            if iters > max_iter:
+                return x, 1, iters
+            d = J.T @ npv
+            zn = d[q:] @ d[q:]
+            z = J[:, q:] @ d[q:]
+            r = T[qe:q, qe:q] @ d[qe:q]                     # only the inequality slots
+            have_step = zn > 100.0 * n * EPS2 * jf2 * np2
+            t1, l = np.inf, -1
+            for k in range(q - qe):
+                if r[k] > 0 and u[k] / r[k] < t1:
+                    t1, l = u[k] / r[k], k
+            t2 = -s_ip / zn if have_step else np.inf
+            t = min(t1, t2)
+            if not np.isfinite(t):
+                return x, 2, iters
+            if have_step:
+                x = x + t * z
+            u[:q - qe] -= t * r
+            u_ip += t
+            if have_step and t == t2:
+                dq = d[q]
+                delta = -np.sqrt(zn) if dq >= 0 else np.sqrt(zn)
+                v = d[q:].copy()
+                v[0] -= delta
+                vv = 2.0 * (zn - delta * dq)
+                if vv > 0:
+                    w = z - delta * J[:, q]
+                    J[:, q:] -= np.outer(w, (2.0 / vv) * v)
+                T[qe:q, q] = -r / delta
+                T[q, q] = 1.0 / delta
+                u[q - qe] = u_ip
+                act.append(ip)
+                active[ip] = True
+                q += 1
+                break
+            # drop inequality slot l (absolute slot qe + l)
+            la = qe + l
+            trow = T[la, la:q].copy()
+            active[act[l]] = False
+            del act[l]
+            u[l:q - qe - 1] = u[l + 1:q - qe].copy()
+            Tt = np.delete(T[qe:q, qe:q], l, axis=0)
+            h = trow[0]
+            for k in range(la, q - 1):
+                a_, b_ = h, trow[k - la + 1]
+                rho = np.hypot(a_, b_)
+                c_, s_ = (b_ / rho, -a_ / rho) if rho > 0 else (1.0, 0.0)
+                h = rho
+                kk = k - qe
+                ck, ck1 = Tt[:, kk].copy(), Tt[:, kk + 1].copy()
+                Tt[:, kk], Tt[:, kk + 1] = c_ * ck + s_ * ck1, -s_ * ck + c_ * ck1
+                jk, jk1 = J[:, k].copy(), J[:, k + 1].copy()
+                J[:, k], J[:, k + 1] = c_ * jk + s_ * jk1, -s_ * jk + c_ * jk1
+            T[qe:, qe:] = 0
+            m_ = q - qe - 1
+            T[qe:qe + m_, qe:qe + m_] = np.triu(Tt[:, :m_])
+            q -= 1
+            s_ip = (-1.0 if side else 1.0) * value(ip, x) - b_ip

@@ -118,6 +118,7 @@ def test_robot_model_tick_matches_oracle(robot):
         assert A.shape == (32, 26) and Ct.shape == (26, 16)
         assert np.abs(A - a["A"][0]).max() < 1e-12 and np.abs(Ct.T - a["C"][0]).max() < 1e-12
         assert np.abs(Clb - a["Clb"][0]).max() < 1e-9 and np.abs(lb - a["lb"][0]).max() < 1e-12 and np.abs(ub - a["ub"][0]).max() < 1e-12
+        base_before = np.array(rm.current_joint_config[:3])
         FL, FR, RL, RR, grip = rm.runWBC(imu, target_cartesian_pos_EE=EE_target, target_cartesian_pos_trunk=trunk_target)
         assert rm.solver_status == 0
         assert np.abs(rm.q_vel - ref["qdot"][0]).max() < 1e-5
@@ -127,9 +128,14 @@ def test_robot_model_tick_matches_oracle(robot):
         # updateState(running=True): base xyz re-estimated from the stance feet (:414-415, :1297-1327), quaternion = IMU
         q = rm.current_joint_config
         assert np.abs(q[3:7] - imu).max() == 0 and np.abs(q[7:] - joints).max() < 1e-7
-        feet = np.array([rm.EE_frame_pos[i] for i in range(4)])
+        # trunkWorldPos restated with the oracle's FK at [old base xyz, IMU quaternion, new joints]: WPA - WRB @ BPA with
+        # BPA the mean WORLD-frame foot offset from the trunk (the reference rotates it once more; replicated literally)
+        q_first = np.concatenate([base_before, imu, joints])
+        o = oracle.fk([wx], q_first[None], want_com=False)["oMf"][0]
+        Rt, pt = o[capi.FR_TRUNK, :9].reshape(3, 3), o[capi.FR_TRUNK, 9:]
         tgt = np.array([np.asarray(EE_target[i]).reshape(3) for i in range(4)])
-        assert np.abs(feet.mean(0) - tgt.mean(0)).max() < 1e-9
+        want_base = tgt.mean(0) - Rt @ (o[:4, 9:].mean(0) - pt)
+        assert np.abs(q[:3] - want_base).max() < 1e-9
         assert np.abs(np.asarray(rm.prev_EE_pos[4]).reshape(3) - EE_target[4].reshape(3)).max() == 0
     # single-block accessors
     rm.endEffectorA2(4)
