@@ -234,12 +234,14 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
     if (lane < NV) { L[lane * LDJ + j] = lij; S.lv[lane] = lij; }
     if (lane == 0) S.dinv[j] = rinv;
     WSYNC();
-#pragma unroll 1
-    for (int k = (j + 1) & ~1; k < NV; k += 2) {
+    // trailing update of row `lane`: all 13 pairs issued back to back (masked below column j+1) so that the LDS
+    // round trip is paid once per column, not once per pair
+#pragma unroll
+    for (int k = 0; k < NV; k += 2) {
       const double2a l2 = lds2(S.lv + k);
       double2a h2 = lds2(L + li * LDJ + k);
-      if (k > j) h2.x = fma(-lij, l2.x, h2.x);
-      h2.y = fma(-lij, l2.y, h2.y);
+      h2.x = fma((k > j) ? -lij : 0.0, l2.x, h2.x);
+      h2.y = fma((k + 1 > j) ? -lij : 0.0, l2.y, h2.y);
       if (lane < NV) sts2(L + lane * LDJ + k, h2.x, h2.y);
     }
     WSYNC();
@@ -251,14 +253,15 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
   double sq = 0.0;
 #pragma unroll 1
   for (int i = 0; i < NV; ++i) {
-    double s = (i == lane) ? 1.0 : 0.0;
-#pragma unroll 1
-    for (int k = 0; k < i; k += 2) {
+    double s = (i == lane) ? 1.0 : 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; k += 2) {
       const double2a l2 = lds2(L + i * LDJ + k);
       const double2a y2 = lds2(J + li * LDJ + k);
-      s = fma(-l2.x, y2.x, s);
-      if (k + 1 < i) s = fma(-l2.y, y2.y, s);
+      s = fma((k < i) ? -l2.x : 0.0, (k < i) ? y2.x : 0.0, s);
+      s2 = fma((k + 1 < i) ? -l2.y : 0.0, (k + 1 < i) ? y2.y : 0.0, s2);
     }
+    s += s2;
     const double y = s * S.dinv[i];
     sq = fma(y, y, sq);
     if (lane < NV) J[lane * LDJ + i] = y;
@@ -297,11 +300,14 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
     ++iters;
     double d = 0.0;                       // d = J' n  (lane k: column k of J)
     if (is_row) {
-#pragma unroll 2
+      double d2 = 0.0;
+#pragma unroll
       for (int i = 0; i < NV; i += 2) {
         const double2a c2 = lds2(Cm + c * LDJ + i);
-        d = fma(J[i * LDJ + li], c2.x, fma(J[(i + 1) * LDJ + li], c2.y, d));
+        d = fma(J[i * LDJ + li], c2.x, d);
+        d2 = fma(J[(i + 1) * LDJ + li], c2.y, d2);
       }
+      d += d2;
     } else {
       d = J[c * LDJ + li];
     }
@@ -320,20 +326,20 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
     if (lane < 32) S.dv[lane] = v;
     WSYNC();
     if (vv > 0.0) {
+      // J2 <- J2 (I - beta v v'): row `lane` of J is read once, w = (row . v) beta, row -= w v'  (v is zero below q)
       const double beta = 2.0 / vv;
-      const int k0 = q & ~1;
-      double w = 0.0;                     // w = J2 v  (lane i: row i of J)
-#pragma unroll 1
-      for (int k = k0; k < NV; k += 2) {
+      double jr[NV], w = 0.0, w2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NV; k += 2) {
         const double2a j2 = lds2(J + li * LDJ + k); const double2a v2 = lds2(S.dv + k);
-        w = fma(j2.x, v2.x, fma(j2.y, v2.y, w));
+        jr[k] = j2.x; jr[k + 1] = j2.y;
+        w = fma(j2.x, v2.x, w); w2 = fma(j2.y, v2.y, w2);
       }
-      w *= beta;
-#pragma unroll 1
-      for (int k = k0; k < NV; k += 2) {
-        double2a j2 = lds2(J + li * LDJ + k); const double2a v2 = lds2(S.dv + k);
-        j2.x = fma(-w, v2.x, j2.x); j2.y = fma(-w, v2.y, j2.y);
-        if (lane < n) sts2(J + lane * LDJ + k, j2.x, j2.y);
+      w = (w + w2) * beta;
+#pragma unroll
+      for (int k = 0; k < NV; k += 2) {
+        const double2a v2 = lds2(S.dv + k);
+        if (lane < n) sts2(J + lane * LDJ + k, fma(-w, v2.x, jr[k]), fma(-w, v2.y, jr[k + 1]));
       }
     }
     const double yq = (b_e - dy) / delta;
@@ -346,20 +352,23 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
   // ---- x_eq = J1 y1 - J2 J2' g
   if (lane < 32) S.npv[lane] = (lane < n) ? g : 0.0;
   WSYNC();
-  double dg = 0.0;
-#pragma unroll 2
+  double dg = 0.0, dg2 = 0.0;
+#pragma unroll
   for (int i = 0; i < NV; i += 2) {
     const double2a g2 = lds2(S.npv + i);
-    dg = fma(J[i * LDJ + li], g2.x, fma(J[(i + 1) * LDJ + li], g2.y, dg));
+    dg = fma(J[i * LDJ + li], g2.x, dg);
+    dg2 = fma(J[(i + 1) * LDJ + li], g2.y, dg2);
   }
+  dg += dg2;
   if (lane < 32) S.dv[lane] = (lane < qe) ? y1 : ((lane < n) ? -dg : 0.0);
   WSYNC();
-  double x = 0.0;
-#pragma unroll 2
+  double x = 0.0, x2s = 0.0;
+#pragma unroll
   for (int k = 0; k < NV; k += 2) {
     const double2a j2 = lds2(J + li * LDJ + k); const double2a v2 = lds2(S.dv + k);
-    x = fma(j2.x, v2.x, fma(j2.y, v2.y, x));
+    x = fma(j2.x, v2.x, x); x2s = fma(j2.y, v2.y, x2s);
   }
+  x += x2s;
   if (lane >= n) x = 0.0;
   STAMP(ts, T_EQ);
 
@@ -375,12 +384,13 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
       if (ub < QP_INF) { const double s = ub - x; if (s < -1e-9 * fmax(1.0, fabs(ub)) && s < best) { best = s; code = lane | 256; } }
     }
     if (p > 0) {
-      double v = 0.0;
-#pragma unroll 2
+      double v = 0.0, vb = 0.0;
+#pragma unroll
       for (int k = 0; k < NV; k += 2) {
         const double2a c2 = lds2(Cm + (has_r ? lane : 0) * LDJ + k); const double2a x2 = lds2(S.xv + k);
-        v = fma(c2.x, x2.x, fma(c2.y, x2.y, v));
+        v = fma(c2.x, x2.x, v); vb = fma(c2.y, x2.y, vb);
       }
+      v += vb;
       if (has_r && !act_r && !eq_r) {
         if (clb > -QP_INF) { const double s = v - clb; if (s < -1e-9 * fmax(1.0, fabs(clb)) && s < best) { best = s; code = n + lane; } }
         if (cub < QP_INF) { const double s = cub - v; if (s < -1e-9 * fmax(1.0, fabs(cub)) && s < best) { best = s; code = (n + lane) | 256; } }
@@ -404,30 +414,37 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
       if (++iters > max_iter) { res.status = WBC_QP_MAX_ITER; goto done; }
       double d = 0.0;
       if (is_row) {
-#pragma unroll 2
+        double d2 = 0.0;
+#pragma unroll
         for (int i = 0; i < NV; i += 2) {
           const double2a c2 = lds2(Cm + rr * LDJ + i);
-          d = fma(J[i * LDJ + li], c2.x, fma(J[(i + 1) * LDJ + li], c2.y, d));
+          d = fma(J[i * LDJ + li], c2.x, d);
+          d2 = fma(J[(i + 1) * LDJ + li], c2.y, d2);
         }
-        d *= sgn;
+        d = (d + d2) * sgn;
       } else {
         d = sgn * J[ip * LDJ + li];
       }
       if (lane >= n) d = 0.0;
-      if (lane < 32) S.dv[lane] = d;
+      if (lane < 32) { S.dv[lane] = d; S.yv[lane] = (lane >= q) ? d : 0.0; }
       WSYNC();
       const double zn = wsum((lane >= q && lane < n) ? d * d : 0.0);
-      // z = J2 d2 (lane i: row i of J), r = T d1 over the inequality slots (lane i in [qe, q): row i of T)
-      double z = 0.0, r = 0.0;
-#pragma unroll 1
-      for (int k = q & ~1; k < NV; k += 2) {
-        const double2a j2 = lds2(J + li * LDJ + k); const double2a d2 = lds2(S.dv + k);
-        z = fma(j2.x, (k >= q) ? d2.x : 0.0, fma(j2.y, d2.y, z));
+      // z = J2 d2 (lane i: row i of J against d restricted to k >= q); r = T d1 (T is zero outside the block of the
+      // inequality slots, so the full row product is the product over [qe, q))
+      double z = 0.0, zb = 0.0, r = 0.0, rb = 0.0;
+#pragma unroll
+      for (int k = 0; k < NV; k += 2) {
+        const double2a j2 = lds2(J + li * LDJ + k); const double2a y2 = lds2(S.yv + k);
+        z = fma(j2.x, y2.x, z); zb = fma(j2.y, y2.y, zb);
       }
-#pragma unroll 1
-      for (int k = qe & ~1; k < q; k += 2) {
-        const double2a t2 = lds2(T + li * LDJ + k); const double2a d2 = lds2(S.dv + k);
-        r = fma(t2.x, (k >= qe) ? d2.x : 0.0, fma(t2.y, (k + 1 < q) ? d2.y : 0.0, r));
+      z += zb;
+      if (q > qe) {
+#pragma unroll
+        for (int k = 0; k < NV; k += 2) {
+          const double2a t2 = lds2(T + li * LDJ + k); const double2a d2 = lds2(S.dv + k);
+          r = fma(t2.x, d2.x, r); rb = fma(t2.y, d2.y, rb);
+        }
+        r += rb;
       }
       if (lane < qe || lane >= q) r = 0.0;
       if (lane >= n) z = 0.0;
@@ -450,13 +467,12 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
         const double vv = 2.0 * (zn - delta * dq);
         if (vv > 0.0) {
           const double w = (z - delta * J[li * LDJ + q]) * (2.0 / vv);
-#pragma unroll 1
-          for (int k = q & ~1; k < NV; k += 2) {
-            double2a j2 = lds2(J + li * LDJ + k); const double2a d2 = lds2(S.dv + k);
-            const double v0 = (k > q) ? d2.x : ((k == q) ? d2.x - delta : 0.0);
-            const double v1 = (k + 1 > q) ? d2.y : d2.y - delta;       // k + 1 >= q always holds here
-            j2.x = fma(-w, v0, j2.x); j2.y = fma(-w, v1, j2.y);
-            if (lane < n) sts2(J + lane * LDJ + k, j2.x, j2.y);
+#pragma unroll
+          for (int k = 0; k < NV; k += 2) {
+            const double2a j2 = lds2(J + li * LDJ + k); const double2a y2 = lds2(S.yv + k);   // yv = d for k >= q, else 0
+            const double v0 = (k == q) ? y2.x - delta : y2.x;
+            const double v1 = (k + 1 == q) ? y2.y - delta : y2.y;
+            if (lane < n) sts2(J + lane * LDJ + k, fma(-w, v0, j2.x), fma(-w, v1, j2.y));
           }
         }
         const double idel = 1.0 / delta;
@@ -1084,23 +1100,26 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A) {
   const bool has3 = A.in.ee_ref_rot != nullptr;
   int b = blockIdx.x;
   if (b >= A.B) return;
-  int mid = A.in.model_id ? A.in.model_id[b] : 0;
-  LaneConst lc = load_lane_const(A.models[mid], A.cfgs[mid], lane_true);
+  // the model index is wave-uniform: say so, or every M.* / cfg.* access becomes a vector load + full wait
+  int mid = A.in.model_id ? __builtin_amdgcn_readfirstlane(A.in.model_id[b]) : 0;
   InRegs cur = load_inputs(A.in, b, lane_true, has2, has3);
 #pragma unroll 1
   for (; b < A.B; b += gridDim.x) {
     int lane = lane_true;
-    asm volatile("" : "+v"(lane));   // keep lane-derived masks out of LICM's reach (they would be spilled)
+    asm volatile("" : "+v"(lane));   // keep lane-derived values out of LICM's reach: they would live (spilled) through the QP
     stage_inputs(S, cur, lane, has2, has3);
+    // per-lane model constants: an L1-resident 3 KB table, re-read every tick so that no register holds them during
+    // the QP; issued BEFORE the prefetch so that waiting for them does not wait for HBM
+    const LaneConst lc = load_lane_const(A.models[mid], A.cfgs[mid], lane);
     WSYNC();
     const int bn = b + gridDim.x;
     int mid_next = mid;
     if (bn < A.B) {                  // prefetch: these loads complete while this instance is processed
       cur = load_inputs(A.in, bn, lane, has2, has3);
-      if (A.in.model_id) mid_next = A.in.model_id[bn];
+      if (A.in.model_id) mid_next = __builtin_amdgcn_readfirstlane(A.in.model_id[bn]);
     }
     process_instance<MODE>(S, A, A.models[mid], A.cfgs[mid], lc, b, lane);
-    if (mid_next != mid) { mid = mid_next; lc = load_lane_const(A.models[mid], A.cfgs[mid], lane_true); }
+    mid = mid_next;
     WSYNC();
   }
 }
@@ -1197,7 +1216,7 @@ __global__ void __launch_bounds__(64) wbc_integrate_kernel(const IntegrateArgs A
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     int lane = threadIdx.x;
     asm volatile("" : "+v"(lane));
-    const DevModel& M = A.models[A.model_id ? A.model_id[b] : 0];
+    const DevModel& M = A.models[A.model_id ? __builtin_amdgcn_readfirstlane(A.model_id[b]) : 0];
     const int nv = M.nv, nq = M.nq;
     if (lane < 32) S.in[IN_Q + lane] = (lane < nq) ? A.q[(size_t)b * NQ + lane] : 0.0;
     const double v = (lane < nv) ? A.v[(size_t)b * NV + lane] * A.dt : 0.0;
