@@ -262,7 +262,8 @@ static int check_batch(WbcBatch* b, int B, const char* who, bool need_cfg, bool 
       if (!b->configured[i]) return fail(WBC_E_STATE, "%s: model %d has no configuration (wbc_batch_configure)", who, i);
   return WBC_OK;
 }
-static int grid_for(const WbcBatch* b, int B) { return B < b->grid ? B : b->grid; }
+static int grid_for(const WbcBatch* b, int B) { return B < b->grid ? B : b->grid; }   // persistent kernels (QP, integrate)
+static int grid_tick(const WbcBatch*, int B) { return B; }                           // tick kernels: one instance per workgroup
 
 static void stage_tick_in(Stager& st, WbcTickIn& in, int B, const WbcBatch* b) {
   const size_t n = (size_t)B;
@@ -297,6 +298,7 @@ static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
   a.models = b->d_models; a.cfgs = b->d_cfgs;
   a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma; a.dt = dt;
   a.prof = b->d_prof;
+  if (b->n_models > 0) { a.fk_nj = b->models[0]->blob.njoints; a.fk_nf = b->models[0]->blob.nframes; }
 }
 
 // ---------------------------------------------------------------------------------------------- entry points
@@ -322,7 +324,7 @@ extern "C" int wbc_fk_jacobians(WbcBatch* b, int B, const double* q, const int32
   st.out(&a.fk.oMi, (size_t)B * nj * 12); st.out(&a.fk.oMf, (size_t)B * nf * 12);
   st.out(&a.fk.J, (size_t)B * 6 * WBC_V_STRIDE); st.out(&a.fk.com, (size_t)B * 3); st.out(&a.fk.Jcom, (size_t)B * 3 * WBC_V_STRIDE);
   if ((rc = st.stage())) return rc;
-  if (int e = launch_tick(a, MODE_FK, grid_for(b, B), stream)) return fail(WBC_E_HIP, "fk kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (int e = launch_tick(a, MODE_FK, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "fk kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return st.finish();
 }
 
@@ -341,7 +343,7 @@ extern "C" int wbc_assemble(WbcBatch* b, int B, const WbcTickIn* in, double dt, 
   st.out(&a.qp.A, n * m * V); st.out(&a.qp.b, n * m); st.out(&a.qp.H, n * V * V); st.out(&a.qp.g, n * V);
   st.out(&a.qp.C, n * p * V); st.out(&a.qp.Clb, n * p); st.out(&a.qp.Cub, n * p); st.out(&a.qp.lb, n * V); st.out(&a.qp.ub, n * V);
   if ((rc = st.stage())) return rc;
-  if (int e = launch_tick(a, MODE_ASSEMBLE, grid_for(b, B), stream)) return fail(WBC_E_HIP, "assemble kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (int e = launch_tick(a, MODE_ASSEMBLE, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "assemble kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return st.finish();
 }
 
@@ -359,7 +361,7 @@ extern "C" int wbc_tick(WbcBatch* b, int B, const WbcTickIn* in, double dt, int 
   const size_t n = (size_t)B;
   st.out(&a.out.qdot, n * WBC_V_STRIDE); st.out(&a.out.status, n); st.out(&a.out.iters, n); st.out(&a.out.q_next, n * WBC_Q_STRIDE);
   if ((rc = st.stage())) return rc;
-  if (int e = launch_tick(a, MODE_TICK, grid_for(b, B), stream)) return fail(WBC_E_HIP, "tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (int e = launch_tick(a, MODE_TICK, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return st.finish();
 }
 

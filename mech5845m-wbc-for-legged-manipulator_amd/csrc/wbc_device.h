@@ -35,6 +35,7 @@ struct KernelArgs {
   const WbcConfig* cfgs;
   int32_t B, mrows, prows, mcart;   // mcart = Cartesian task rows (excludes the diagonal posture block)
   int32_t jtj_mfma, pad0;
+  int32_t fk_nj, fk_nf;             // oMi / oMf output strides (sizes of model 0)
   unsigned long long* prof;         // WBC_PROFILE builds: per-phase cycle sums [16] (else unused)
   double dt;
   WbcTickIn in;

@@ -33,16 +33,19 @@ constexpr int IN_ERR = 96, IN_EPR = 141;                                        
 constexpr int IN_SIZE = 192;
 
 struct __attribute__((aligned(16))) Smem {
-  double RA[NV * LDJ];                  // H -> L (Cholesky) -> T = R^-1 of the inequality slots; early: oMi, m*c
-  double RB[NV * LDJ];                  // J = L^-T Q ; during assembly (with RC): At, the task stack by DoF
+  double RA[NV * LDJ];                  // H -> Lt (Cholesky, Lt[j][i] = L[i][j]) -> B columns -> T = R^-1 (inequality slots)
+  double RApad[LDJ];                    // stays zero: the rotating substitution reads one row past Lt
+  double RB[NV * LDJ];                  // J0 = L^-T, then J = J0 Q ; during assembly (with RC): At, the task stack by DoF
   double RC[PMAX * LDJ];                // Cm: constraint rows (p x 26)
   double in[IN_SIZE];                   // this instance's inputs (q, targets, controller state)
   double pf[WBC_MAX_FRAMES * 3];        // frame origins
   double dv[32], xv[32], npv[32], lv[32], dinv[32], yv[32];
+  double cl[64];                        // Cholesky column broadcast; entries 26..63 stay zero
   double bt[48];                        // Cartesian task targets (b of qpb), uniform values
 };
 constexpr int OFF_OMI = 0;              // RA: oMi[24][12] (dead before H is accumulated)
 constexpr int OFF_MC = 24 * 12;         // RA: m*c per joint [32][4]
+constexpr int MAXE = NV;                // equalities the QR keeps in registers (at most n can be independent)
 
 #define WSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
@@ -53,7 +56,8 @@ constexpr int OFF_MC = 24 * 12;         // RA: m*c per joint [32][4]
 #else
 #define STAMP(ts, i) do { } while (0)
 #endif
-enum { T_START = 0, T_FK = 1, T_ASM = 2, T_CHOL = 3, T_INV = 4, T_EQ = 5, T_INEQ = 6, T_END = 7, T_N = 8 };
+enum { T_START = 0, T_FK = 1, T_ASM = 2, T_CHOL = 3, T_INV = 4, T_EQ = 5, T_INEQ = 6, T_END = 7, T_N = 8,
+       T_A1 = 8, T_A2 = 9, T_A3 = 10, T_NN = 11 };   // sub-stamps inside the task-stack phase (profile build)
 
 // ---------------------------------------------------------------------------------------------- lane helpers
 __device__ __forceinline__ double rfl(double v) {
@@ -94,6 +98,11 @@ __device__ __forceinline__ double wmin(double v) {
   v = fmin(v, dpp<DPP_MIRROR>(v));
   return fmin(rdl(v, 0), rdl(v, 16));
 }
+
+// Scheduling hint: issue the block's LDS reads back to back, then its VALU work. hipcc otherwise serialises
+// "ds_read; s_waitcnt; fma" with one or three loads in flight (profiles/r01: 51 % of wave time in s_waitcnt).
+#define LDS_THEN_VALU(nread, nvalu) do { __builtin_amdgcn_sched_group_barrier(0x100, nread, 0); \
+                                         __builtin_amdgcn_sched_group_barrier(0x002, nvalu, 0); } while (0)
 
 struct double2a { double x, y; } __attribute__((aligned(16)));
 __device__ __forceinline__ double2a lds2(const double* p) { return *reinterpret_cast<const double2a*>(p); }
@@ -214,162 +223,203 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
                                             const double clb, const double cub, const int n, const int p, const int lane,
                                             unsigned long long* ts) {
   const int li = li_clamp(lane);
-  double* const L = S.RA;
-  double* const J = S.RB;
-  double* const T = S.RA;
-  const double* const Cm = S.RC;
   QpResult res;
   res.status = WBC_QP_OPTIMAL;
   res.iters = 0;
   res.x = 0.0;
 
-  // ---- Cholesky H = L L' in place, right-looking; lane i owns row i, column j is broadcast through S.lv
+  // ---- row `lane` of H into registers (lanes >= 26 shadow row 25; they never write)
+  double h[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k += 2) { const double2a v = lds2(S.RA + li * LDJ + k); h[k] = v.x; h[k + 1] = v.y; }
+  WSYNC();
+
+  // ---- Cholesky H = L L', right-looking, ROTATING registers: at step j register r holds column j + r of the row,
+  // so the body is the same for every j (a real loop, ~100 instructions) and the row never leaves the VGPRs.
+  // Column j is broadcast through S.cl (zero above entry 25); L is stored transposed, Lt[j][i] = L[i][j].
+  double* const Lt = S.RA;
   double pmin = 1.0;
 #pragma unroll 1
   for (int j = 0; j < NV; ++j) {
-    const double pj = L[j * LDJ + j];
+    const double pj = rdl(h[0], j);
     pmin = fmin(pmin, pj);
     const double rinv = rsqrt(pj);
-    const double lij = L[li * LDJ + j] * rinv;
-    if (lane < NV) { L[lane * LDJ + j] = lij; S.lv[lane] = lij; }
+    const double l = h[0] * rinv;
+    if (lane < NV) { S.cl[lane] = l; Lt[j * LDJ + lane] = (lane >= j) ? l : 0.0; }
     if (lane == 0) S.dinv[j] = rinv;
     WSYNC();
-    // trailing update of row `lane`: all 13 pairs issued back to back (masked below column j+1) so that the LDS
-    // round trip is paid once per column, not once per pair
+    const double* cj = S.cl + j;
+    double cm[NV];
 #pragma unroll
-    for (int k = 0; k < NV; k += 2) {
-      const double2a l2 = lds2(S.lv + k);
-      double2a h2 = lds2(L + li * LDJ + k);
-      h2.x = fma((k > j) ? -lij : 0.0, l2.x, h2.x);
-      h2.y = fma((k + 1 > j) ? -lij : 0.0, l2.y, h2.y);
-      if (lane < NV) sts2(L + lane * LDJ + k, h2.x, h2.y);
-    }
+    for (int r = 1; r < NV; ++r) cm[r] = cj[r];
+#pragma unroll
+    for (int r = 1; r < NV; ++r) h[r - 1] = fma(-l, cm[r], h[r]);
+    LDS_THEN_VALU(25, 25);
+    h[NV - 1] = 0.0;
     WSYNC();
   }
   STAMP(ts, T_CHOL);
   if (!(pmin > 0.0)) { res.status = WBC_QP_NUMERICAL; return res; }
 
-  // ---- J = L^-T: lane c solves L y = e_c by forward substitution; y_i is stored as J[c][i]
-  double sq = 0.0;
-#pragma unroll 1
-  for (int i = 0; i < NV; ++i) {
-    double s = (i == lane) ? 1.0 : 0.0, s2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < NV; k += 2) {
-      const double2a l2 = lds2(L + i * LDJ + k);
-      const double2a y2 = lds2(J + li * LDJ + k);
-      s = fma((k < i) ? -l2.x : 0.0, (k < i) ? y2.x : 0.0, s);
-      s2 = fma((k + 1 < i) ? -l2.y : 0.0, (k + 1 < i) ? y2.y : 0.0, s2);
-    }
-    s += s2;
-    const double y = s * S.dinv[i];
-    sq = fma(y, y, sq);
-    if (lane < NV) J[lane * LDJ + i] = y;
-    WSYNC();
-  }
-  const double jf2 = wsum(lane < NV ? sq : 0.0);
-  // T = 0 (RA is free now)
-  for (int k = lane; k < NV * LDJ; k += 64) T[k] = 0.0;
-  STAMP(ts, T_INV);
-
   // ---- constraint bookkeeping
   const bool has_b = lane < n, has_r = lane < p;
   const bool eq_b = has_b && (lb == ub) && (fabs(lb) < QP_INF);
   const bool eq_r = has_r && (clb == cub) && (fabs(clb) < QP_INF);
-  unsigned long long eqm_b = __ballot(eq_b), eqm_r = __ballot(eq_r);
-  bool act_b = false, act_r = false;      // bound `lane` / row `lane` in the working set
+  const unsigned long long eqm_b = __ballot(eq_b), eqm_r = __ballot(eq_r);
+  const int nbe = __popcll(eqm_b), ne = nbe + __popcll(eqm_r);
+  if (ne > MAXE) { res.status = WBC_QP_NUMERICAL; return res; }   // more equalities than unknowns
+
+  // ---- forward substitutions L y = rhs, one right-hand side per lane, ROTATING registers (same trick):
+  //   lane c < 26        : e_c        -> y = column c of L^-1 = row c of J0 = L^-T
+  //   lane 26 + r, r < p : C_r'       -> y = L^-1 C_r'   (column of B = J0' N for constraint row r)
+  //   lane 26 + p        : g          -> y = L^-1 g
+  // The multipliers Lt[k][k + q] are wave-uniform LDS reads; entries past the diagonal block are zero, so finished
+  // outputs ride along the rotation unchanged.
+  if (lane < 32) S.npv[lane] = (lane < n) ? g : 0.0;
+  WSYNC();
+  double y[NV];
+  {
+    const int rl = lane - NV;                           // which right-hand side this lane carries
+    const double* src = (rl >= 0 && rl < p) ? (S.RC + rl * LDJ) : S.npv;
+    const bool from_lds = (rl >= 0 && rl <= p);
+    double sqn = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; k += 2) {
+      const double2a v = lds2(src + k);
+      y[k] = from_lds ? v.x : ((k == lane) ? 1.0 : 0.0);
+      y[k + 1] = from_lds ? v.y : ((k + 1 == lane) ? 1.0 : 0.0);
+      sqn = fma(v.x, v.x, fma(v.y, v.y, sqn));
+    }
+    if (rl >= 0 && rl < p) S.yv[rl & 31] = sqn;         // |C_r|^2 (p <= 24 < 32)
+  }
+  WSYNC();
+#pragma unroll 1
+  for (int k = 0; k < NV; ++k) {
+    const double* lk = Lt + k * LDJ + k;
+    double lm[NV];
+    const double dk = S.dinv[k];
+#pragma unroll
+    for (int q2 = 1; q2 < NV; ++q2) lm[q2] = lk[q2];
+    const double yk = y[0] * dk;
+#pragma unroll
+    for (int q2 = 1; q2 < NV; ++q2) y[q2 - 1] = fma(-lm[q2], yk, y[q2]);
+    LDS_THEN_VALU(26, 26);
+    y[NV - 1] = yk;
+  }
+  // lanes < 26: y = row `lane` of J0.  jf2 = |J0|_F^2
+  double sq = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) sq = fma(y[k], y[k], sq);
+  const double jf2 = wsum(lane < NV ? sq : 0.0);
+  const double cn2 = has_r ? S.yv[lane & 31] : 0.0;     // |C_r|^2 for row = lane
+  WSYNC();
+  // J0 rows -> RB (bound-type equality columns are read from it), B columns and L^-1 g -> RA rows 0..p
+  {
+    double* dst = (lane < NV) ? (S.RB + lane * LDJ) : ((lane - NV <= p) ? (S.RA + (lane - NV) * LDJ) : nullptr);
+    if (dst) {
+#pragma unroll
+      for (int k = 0; k < NV; k += 2) sts2(dst + k, y[k], y[k + 1]);
+    }
+  }
+  STAMP(ts, T_INV);
+  WSYNC();
+
+  // ---- gather row `lane` of B (one register per equality, processing order: bounds by index, then rows) and L^-1 g
+  double bq[MAXE], bg;
+  {
+    unsigned long long mb = eqm_b, mr = eqm_r;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      double v = 0.0;
+      if (e < ne) {                                      // uniform
+        const double* col;
+        double be, n2;
+        if (mb) { const int c = ctz64(mb); mb &= mb - 1; col = S.RB + c * LDJ; be = rdl(lb, c); n2 = 1.0; }
+        else { const int c = ctz64(mr); mr &= mr - 1; col = S.RA + c * LDJ; be = rdl(clb, c); n2 = rdl(cn2, c); }
+        v = col[li];
+        if (lane == 0) { S.dinv[e] = be; S.lv[e] = n2; }   // (dinv / lv are free after the substitution)
+      }
+      bq[e] = (lane < n) ? v : 0.0;
+    }
+    bg = (lane < n) ? S.RA[p * LDJ + li] : 0.0;
+  }
+  WSYNC();
+
+  bool act_b = eq_b, act_r = eq_r;        // bound `lane` / row `lane` in the working set (equalities stay in)
   double u = 0.0;                         // multiplier of working-set slot `lane` (inequality slots only)
   int a_code = 0;                         // slot `lane`: constraint id | side << 8
   int q = 0, iters = 0;
   const int max_iter = 10 * (n + p) + 20;
-  double cn2 = 0.0;                       // |C_r|^2 for row = lane
-  if (p > 0) {
-#pragma unroll 1
-    for (int k = 0; k < NV; k += 2) { const double2a c2 = lds2(Cm + (has_r ? lane : 0) * LDJ + k); cn2 = fma(c2.x, c2.x, fma(c2.y, c2.y, cn2)); }
-  }
-  WSYNC();
 
-  // ---- equality block: Householder QR of J'N_e (updates J only); y1 solves R'y1 = b_e incrementally
+  // ---- equality block: Householder QR of B = J0'N_e with ROTATING columns (bq[0] is always the current column);
+  // every reflector is applied at once to the remaining columns, to L^-1 g and to row `lane` of J0 (all in registers).
+  // y1 solves R'y1 = b_e incrementally. Nothing but the reflector vector goes through LDS.
   double y1 = 0.0;                        // lane k < q: y1_k
 #pragma unroll 1
-  while (eqm_b | eqm_r) {
-    int c, is_row;
-    double b_e, np2;
-    if (eqm_b) { c = ctz64(eqm_b); eqm_b &= eqm_b - 1; is_row = 0; b_e = rdl(lb, c); np2 = 1.0; }
-    else { c = ctz64(eqm_r); eqm_r &= eqm_r - 1; is_row = 1; b_e = rdl(clb, c); np2 = rdl(cn2, c); }
+  for (int e = 0; e < ne; ++e) {
     ++iters;
-    double d = 0.0;                       // d = J' n  (lane k: column k of J)
-    if (is_row) {
-      double d2 = 0.0;
-#pragma unroll
-      for (int i = 0; i < NV; i += 2) {
-        const double2a c2 = lds2(Cm + c * LDJ + i);
-        d = fma(J[i * LDJ + li], c2.x, d);
-        d2 = fma(J[(i + 1) * LDJ + li], c2.y, d2);
-      }
-      d += d2;
-    } else {
-      d = J[c * LDJ + li];
-    }
-    if (lane >= n) d = 0.0;
-    const double zn = wsum((lane >= q && lane < n) ? d * d : 0.0);
-    const double dy = wsum((lane < q) ? d * y1 : 0.0);
-    if (!(zn > 100.0 * n * EPS2 * jf2 * np2)) {          // dependent on the equalities already absorbed
-      if (fabs(dy - b_e) <= 1e-9 * fmax(1.0, fabs(b_e))) continue;
+    const double d = bq[0];
+    const double zn = wsum(lane >= q ? d * d : 0.0);
+    const double dy = wsum(lane < q ? d * y1 : 0.0);
+    const double b_e = S.dinv[e], np2 = S.lv[e];
+    double beta = 0.0, v = 0.0;
+    if (zn > 100.0 * n * EPS2 * jf2 * np2) {
+      const double dq = rdl(d, q);
+      const double sz = sqrt(zn);
+      const double delta = (dq >= 0.0) ? -sz : sz;
+      const double vv = 2.0 * (zn - delta * dq);
+      v = (lane == q) ? d - delta : ((lane > q) ? d : 0.0);     // Householder vector, zero below slot q
+      beta = (vv > 0.0) ? 2.0 / vv : 0.0;
+      const double yq = (b_e - dy) / delta;
+      if (lane == q) y1 = yq;
+      ++q;
+    } else if (!(fabs(dy - b_e) <= 1e-9 * fmax(1.0, fabs(b_e)))) {   // dependent and inconsistent
       res.status = WBC_QP_INFEASIBLE; res.iters = iters; return res;
     }
-    const double dq = rdl(d, q);
-    const double sz = sqrt(zn);
-    const double delta = (dq >= 0.0) ? -sz : sz;
-    const double vv = 2.0 * (zn - delta * dq);
-    const double v = (lane == q) ? d - delta : ((lane > q) ? d : 0.0);   // Householder vector, zero below slot q
     if (lane < 32) S.dv[lane] = v;
     WSYNC();
-    if (vv > 0.0) {
-      // J2 <- J2 (I - beta v v'): row `lane` of J is read once, w = (row . v) beta, row -= w v'  (v is zero below q)
-      const double beta = 2.0 / vv;
-      double jr[NV], w = 0.0, w2 = 0.0;
+    // remaining columns (rotated down by one) and L^-1 g
+    const int left = ne - 1 - e;          // columns still to come
 #pragma unroll
-      for (int k = 0; k < NV; k += 2) {
-        const double2a j2 = lds2(J + li * LDJ + k); const double2a v2 = lds2(S.dv + k);
-        jr[k] = j2.x; jr[k + 1] = j2.y;
-        w = fma(j2.x, v2.x, w); w2 = fma(j2.y, v2.y, w2);
-      }
+    for (int r = 1; r < MAXE; ++r) {
+      if (((r - 1) & 3) == 0 && r > left) break;      // uniform: whole groups of four past the last column are skipped
+      const double tau = wsum(v * bq[r]) * beta;
+      bq[r - 1] = fma(-tau, v, bq[r]);
+    }
+    bg = fma(-wsum(v * bg) * beta, v, bg);
+    // row `lane` of J0:  row <- row - (row . v) beta v'
+    if (beta != 0.0) {
+      double vk[NV], w = 0.0, w2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NV; k += 2) { const double2a v2 = lds2(S.dv + k); vk[k] = v2.x; vk[k + 1] = v2.y; }
+#pragma unroll
+      for (int k = 0; k < NV; k += 2) { w = fma(y[k], vk[k], w); w2 = fma(y[k + 1], vk[k + 1], w2); }
+      LDS_THEN_VALU(13, 26);
       w = (w + w2) * beta;
 #pragma unroll
-      for (int k = 0; k < NV; k += 2) {
-        const double2a v2 = lds2(S.dv + k);
-        if (lane < n) sts2(J + lane * LDJ + k, fma(-w, v2.x, jr[k]), fma(-w, v2.y, jr[k + 1]));
-      }
+      for (int k = 0; k < NV; ++k) y[k] = fma(-w, vk[k], y[k]);
     }
-    const double yq = (b_e - dy) / delta;
-    if (lane == q) y1 = yq;
-    if (is_row) { if (lane == c) act_r = true; } else { if (lane == c) act_b = true; }
-    ++q;
     WSYNC();
   }
   const int qe = q;
-  // ---- x_eq = J1 y1 - J2 J2' g
-  if (lane < 32) S.npv[lane] = (lane < n) ? g : 0.0;
-  WSYNC();
-  double dg = 0.0, dg2 = 0.0;
+  // ---- x_eq = J1 y1 - J2 (J2' g):  bg now holds J'g
+  if (lane < 32) S.dv[lane] = (lane < qe) ? y1 : ((lane < n) ? -bg : 0.0);
+  // J = J0 Q -> RB for the inequality phase; T = 0 in RA
+  if (lane < NV) {
 #pragma unroll
-  for (int i = 0; i < NV; i += 2) {
-    const double2a g2 = lds2(S.npv + i);
-    dg = fma(J[i * LDJ + li], g2.x, dg);
-    dg2 = fma(J[(i + 1) * LDJ + li], g2.y, dg2);
+    for (int k = 0; k < NV; k += 2) sts2(S.RB + lane * LDJ + k, y[k], y[k + 1]);
   }
-  dg += dg2;
-  if (lane < 32) S.dv[lane] = (lane < qe) ? y1 : ((lane < n) ? -dg : 0.0);
+  for (int k = lane; k < NV * LDJ; k += 64) S.RA[k] = 0.0;
   WSYNC();
   double x = 0.0, x2s = 0.0;
 #pragma unroll
-  for (int k = 0; k < NV; k += 2) {
-    const double2a j2 = lds2(J + li * LDJ + k); const double2a v2 = lds2(S.dv + k);
-    x = fma(j2.x, v2.x, x); x2s = fma(j2.y, v2.y, x2s);
-  }
+  for (int k = 0; k < NV; k += 2) { const double2a v2 = lds2(S.dv + k); x = fma(y[k], v2.x, x); x2s = fma(y[k + 1], v2.y, x2s); }
+  LDS_THEN_VALU(13, 26);
   x += x2s;
   if (lane >= n) x = 0.0;
+  double* const J = S.RB;
+  double* const T = S.RA;
+  const double* const Cm = S.RC;
   STAMP(ts, T_EQ);
 
   // ---- inequality phase
@@ -390,6 +440,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
         const double2a c2 = lds2(Cm + (has_r ? lane : 0) * LDJ + k); const double2a x2 = lds2(S.xv + k);
         v = fma(c2.x, x2.x, v); vb = fma(c2.y, x2.y, vb);
       }
+      LDS_THEN_VALU(26, 26);
       v += vb;
       if (has_r && !act_r && !eq_r) {
         if (clb > -QP_INF) { const double s = v - clb; if (s < -1e-9 * fmax(1.0, fabs(clb)) && s < best) { best = s; code = n + lane; } }
@@ -421,6 +472,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
           d = fma(J[i * LDJ + li], c2.x, d);
           d2 = fma(J[(i + 1) * LDJ + li], c2.y, d2);
         }
+        LDS_THEN_VALU(39, 26);
         d = (d + d2) * sgn;
       } else {
         d = sgn * J[ip * LDJ + li];
@@ -437,6 +489,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
         const double2a j2 = lds2(J + li * LDJ + k); const double2a y2 = lds2(S.yv + k);
         z = fma(j2.x, y2.x, z); zb = fma(j2.y, y2.y, zb);
       }
+      LDS_THEN_VALU(26, 26);
       z += zb;
       if (q > qe) {
 #pragma unroll
@@ -444,6 +497,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
           const double2a t2 = lds2(T + li * LDJ + k); const double2a d2 = lds2(S.dv + k);
           r = fma(t2.x, d2.x, r); rb = fma(t2.y, d2.y, rb);
         }
+        LDS_THEN_VALU(26, 26);
         r += rb;
       }
       if (lane < qe || lane >= q) r = 0.0;
@@ -569,13 +623,16 @@ __device__ __forceinline__ void jtj_block(Smem& S, const double* At, const int m
 #pragma unroll
   for (int r = 0; r < NR; ++r) a[r] = At[li * mtp + row0 + r];
 #pragma unroll 1
-  while (mask) {
-    const int i = __ffs((int)mask) - 1;
+  while (mask) {                         // two support columns per trip: two independent read-modify-write chains
+    const int i0 = __ffs((int)mask) - 1;
     mask &= mask - 1;
-    double s = S.RA[li * LDJ + i];
+    const bool two = mask != 0;
+    const int i1 = two ? __ffs((int)mask) - 1 : i0;
+    mask &= mask - 1;                    // (0 & anything stays 0)
+    double s0 = S.RA[li * LDJ + i0], s1 = S.RA[li * LDJ + i1];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) s = fma(At[i * mtp + row0 + r], a[r], s);
-    if (lane < NV) S.RA[lane * LDJ + i] = s;
+    for (int r = 0; r < NR; ++r) { s0 = fma(At[i0 * mtp + row0 + r], a[r], s0); s1 = fma(At[i1 * mtp + row0 + r], a[r], s1); }
+    if (lane < NV) { S.RA[lane * LDJ + i0] = s0; if (two) S.RA[lane * LDJ + i1] = s1; }
   }
 }
 
@@ -685,10 +742,11 @@ template <int MODE>
 __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
                                                  const LaneConst& lc, const int b, const int lane) {
   const int nv = M.nv, nq = M.nq, nj = M.njoints;
-  const double dt = A.dt;
+  const double dt = A.dt, inv_dt = 1.0 / A.dt;   // x * (1/dt) for x / dt: one rounding more than the reference's division
+  (void)dt;
   double* const oMi = S.RA + OFF_OMI;   // [joint][12]: R column-major (3 columns), then p
   const double* const qv = S.in + IN_Q;
-  unsigned long long ts[T_N];
+  unsigned long long ts[T_NN];
   (void)ts;
   STAMP(ts, T_START);
 
@@ -786,9 +844,10 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
   }
 
   if (MODE == MODE_FK) {
+    const int M0nj = A.fk_nj, M0nf = A.fk_nf;   // output strides = model 0's sizes
     // outputs of updateState: oMi / oMf (row-major R then p), data.J, com, Jcom
     if (A.fk.oMi && lane < nj) {
-      double* o = A.fk.oMi + ((size_t)b * A.models[0].njoints + lane) * 12;   // strides of model 0
+      double* o = A.fk.oMi + ((size_t)b * M0nj + lane) * 12;   // strides of model 0
       if (lane == 0) { for (int i = 0; i < 12; ++i) o[i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0; }
       else {
         const double* Pj = oMi + 12 * lane;
@@ -797,7 +856,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
       }
     }
     if (A.fk.oMf && lane < M.nframes) {
-      double* o = A.fk.oMf + ((size_t)b * A.models[0].nframes + lane) * 12;
+      double* o = A.fk.oMf + ((size_t)b * M0nf + lane) * 12;
       const double* Pj = oMi + lc.fj_off;
       for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o[3 * r + c] = Pj[3 * c + r];
       o[9] = S.pf[3 * lane]; o[10] = S.pf[3 * lane + 1]; o[11] = S.pf[3 * lane + 2];
@@ -845,13 +904,13 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     const double* xp = S.in + IN_EEP + 3 * e;
     double vel[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) / dt + cfg.ee_gain[e][i] * ((xt[i] - pfe[i]) / dt);
+    for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) * inv_dt + cfg.ee_gain[e][i] * ((xt[i] - pfe[i]) * inv_dt);
     if (A.in.ee_ref_rot) {   // omega = vee(((R* - R*_prev)/dt) R*^T)  (:1125-1128, 1133)
       const double* Rs = S.in + IN_ERR + 9 * e;
       const double* Rp = S.in + IN_EPR + 9 * e;
       double D[9];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) D[i] = (Rs[i] - Rp[i]) / dt;
+      for (int i = 0; i < 9; ++i) D[i] = (Rs[i] - Rp[i]) * inv_dt;
       vel[3] = D[6] * Rs[3] + D[7] * Rs[4] + D[8] * Rs[5];   // S[2][1]
       vel[4] = D[0] * Rs[6] + D[1] * Rs[7] + D[2] * Rs[8];   // S[0][2]
       vel[5] = D[3] * Rs[0] + D[4] * Rs[1] + D[5] * Rs[2];   // S[1][0]
@@ -877,7 +936,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     const double* xp = S.in + IN_TP;
     double vel[6];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) / dt + cfg.trunk_gain[i] * ((xt[i] - ptr[i]) / dt);
+    for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) * inv_dt + cfg.trunk_gain[i] * ((xt[i] - ptr[i]) * inv_dt);
     double fq[4], rq[4], Rs[9];
     R_to_quat(Rtr, fq);
     const double* er = S.in + IN_TRE;
@@ -904,7 +963,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     const double* Ro = S.in + IN_TPR;
     double D[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) D[i] = (Rs[i] - Ro[i]) / dt;
+    for (int i = 0; i < 9; ++i) D[i] = (Rs[i] - Ro[i]) * inv_dt;
     // skew = D Rs (R*, not R*^T: :984); omega = (S[2][1], S[0][2], S[1][0]) + K qe
     vel[3] = (D[6] * Rs[1] + D[7] * Rs[4] + D[8] * Rs[7]) + cfg.trunk_gain[3] * qe0;
     vel[4] = (D[0] * Rs[2] + D[1] * Rs[5] + D[2] * Rs[8]) + cfg.trunk_gain[4] * qe1;
@@ -932,6 +991,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     row += 3;
   }
   WSYNC();
+  STAMP(ts, T_A1);
   // pass 2: H[lane][i] = sum_r At[i][r] At[lane][r]
   if (A.jtj_mfma) {
     // dense contraction on the fp64 matrix cores (the operand comes straight from the At image in LDS)
@@ -981,6 +1041,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     if (A.qp.g && lane < NV) A.qp.g[(size_t)b * NV + lane] = g;
   }
   WSYNC();   // At is dead: Cm may be written
+  STAMP(ts, T_A2);
 
   // ---- P6: constraints in order CoM, Trunk, FR, FL, RR, RL, Grip: findConstraints (Robot_Wrapper4.py:764-836)
   double* const Cm = S.RC;
@@ -990,8 +1051,8 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       if (lane < NV) Cm[(prow + r) * LDJ + lane] = jc[r];
-      const double lo = ((S.pf[3 * 2 + r] - com[r]) / dt) * cfg.com_box_scale;
-      const double hi = ((S.pf[3 * 1 + r] - com[r]) / dt) * cfg.com_box_scale;
+      const double lo = ((S.pf[3 * 2 + r] - com[r]) * inv_dt) * cfg.com_box_scale;
+      const double hi = ((S.pf[3 * 1 + r] - com[r]) * inv_dt) * cfg.com_box_scale;
       if (lane == prow + r) { clb = lo; cub = hi; }
     }
     prow += 2;
@@ -1002,15 +1063,23 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     cross3(ang, ptr, wxp);
     const double rowv[4] = {sup ? lin[2] + wxp[2] : 0.0, sup ? ang[0] : 0.0, sup ? ang[1] : 0.0, sup ? ang[2] : 0.0};
     const double* bc = S.in + IN_BOX;
-    // scipy as_euler('xyz') of the trunk rotation (:714-715)
-    const double cur[4] = {ptr[2], atan2(Rtr[7], Rtr[8]), -asin(Rtr[6]), atan2(Rtr[3], Rtr[0])};
-    const double var[4] = {bc[0] * cfg.trunk_box_z_frac, cfg.trunk_box_ang, cfg.trunk_box_ang, cfg.trunk_box_ang};
+    // scipy as_euler('xyz') of the trunk rotation (:714-715): roll = atan2(R21, R22), pitch = -asin(R20) =
+    // atan2(-R20, |(R21, R22)|), yaw = atan2(R10, R00) — ONE atan2 evaluated on lanes 0..2, then broadcast
+    const double ay = (lane == 0) ? Rtr[7] : ((lane == 1) ? -Rtr[6] : Rtr[3]);
+    const double ax = (lane == 0) ? Rtr[8] : ((lane == 1) ? sqrt(fma(Rtr[7], Rtr[7], Rtr[8] * Rtr[8])) : Rtr[0]);
+    const double eul = atan2(ay, ax);
+    const double cur[4] = {ptr[2], rdl(eul, 0), rdl(eul, 1), rdl(eul, 2)};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (lane < NV) Cm[(prow + r) * LDJ + lane] = rowv[r];
-      const double lo = (((bc[r] - var[r]) - cur[r]) / dt) * cfg.trunk_box_scale;   // :735
-      const double hi = (((bc[r] + var[r]) - cur[r]) / dt) * cfg.trunk_box_scale;   // :736
-      if (lane == prow + r) { clb = lo; cub = hi; }
+    for (int r = 0; r < 4; ++r) if (lane < NV) Cm[(prow + r) * LDJ + lane] = rowv[r];
+    {   // the lane that owns row prow + r computes that row's bounds (:719-736)
+      const int r = lane - prow;
+      const double bcr = (r == 0) ? bc[0] : (r == 1) ? bc[1] : (r == 2) ? bc[2] : bc[3];
+      const double cr = (r == 0) ? cur[0] : (r == 1) ? cur[1] : (r == 2) ? cur[2] : cur[3];
+      const double vr = (r == 0) ? bc[0] * cfg.trunk_box_z_frac : cfg.trunk_box_ang;
+      if (r >= 0 && r < 4) {
+        clb = (((bcr - vr) - cr) * inv_dt) * cfg.trunk_box_scale;   // :735
+        cub = (((bcr + vr) - cr) * inv_dt) * cfg.trunk_box_scale;   // :736
+      }
     }
     prow += 4;
   }
@@ -1025,6 +1094,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     }
     prow += 3;
   }
+  STAMP(ts, T_A3);
   // ---- velDamperJointConstraints (Robot_Wrapper4.py:572-637), index map from cfg
   double lb = 0.0, ub = 0.0;
   if (lane < nv) {
@@ -1083,6 +1153,10 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     for (int i = 1; i < T_N; ++i) atomicAdd(A.prof + i, ts[i] - ts[i - 1]);
     atomicAdd(A.prof + 0, 1ull);
     atomicAdd(A.prof + 8, (unsigned long long)res.iters);
+    atomicAdd(A.prof + 9, ts[T_A1] - ts[T_FK]);     // task rows + targets
+    atomicAdd(A.prof + 10, ts[T_A2] - ts[T_A1]);    // J'J + posture
+    atomicAdd(A.prof + 11, ts[T_A3] - ts[T_A2]);    // constraint rows (incl. trunk Euler angles)
+    atomicAdd(A.prof + 12, ts[T_ASM] - ts[T_A3]);   // damper bounds
   }
 #endif
 }
@@ -1092,41 +1166,36 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
 // the next instance's inputs are fetched from HBM while the current one is being solved.
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A) {
+__global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, const DevModel* __restrict__ models,
+                                                         const WbcConfig* __restrict__ cfgs) {
+  // models / cfgs are separate __restrict__ const parameters so that the compiler may read them with scalar loads
+  // (as members of A it must assume the kernel's own stores clobber them: every access became a vector load + full wait).
+  // ONE instance per single-wave workgroup, no loop: inside a persistent loop the compiler hoists hundreds of
+  // "invariants" (polynomial coefficients, masks, addresses) out of the tick, spills them to scratch and reloads them
+  // one by one with full memory waits (profiles/r01_phase_cycles_v6: 60k cycles in one atan2). The hardware's
+  // workgroup dispatcher does the batch loop instead; other resident waves cover this wave's input latency.
   __shared__ Smem S;
-  const int lane_true = threadIdx.x;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  S.cl[lane] = 0.0;                            // zero padding the rotating loops rely on (never written above entry 25)
+  if (lane < LDJ) S.RApad[lane] = 0.0;
   const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
                     A.in.com_target || A.in.com_target_vel;
   const bool has3 = A.in.ee_ref_rot != nullptr;
-  int b = blockIdx.x;
-  if (b >= A.B) return;
-  // the model index is wave-uniform: say so, or every M.* / cfg.* access becomes a vector load + full wait
-  int mid = A.in.model_id ? __builtin_amdgcn_readfirstlane(A.in.model_id[b]) : 0;
-  InRegs cur = load_inputs(A.in, b, lane_true, has2, has3);
-#pragma unroll 1
-  for (; b < A.B; b += gridDim.x) {
-    int lane = lane_true;
-    asm volatile("" : "+v"(lane));   // keep lane-derived values out of LICM's reach: they would live (spilled) through the QP
-    stage_inputs(S, cur, lane, has2, has3);
-    // per-lane model constants: an L1-resident 3 KB table, re-read every tick so that no register holds them during
-    // the QP; issued BEFORE the prefetch so that waiting for them does not wait for HBM
-    const LaneConst lc = load_lane_const(A.models[mid], A.cfgs[mid], lane);
-    WSYNC();
-    const int bn = b + gridDim.x;
-    int mid_next = mid;
-    if (bn < A.B) {                  // prefetch: these loads complete while this instance is processed
-      cur = load_inputs(A.in, bn, lane, has2, has3);
-      if (A.in.model_id) mid_next = __builtin_amdgcn_readfirstlane(A.in.model_id[bn]);
-    }
-    process_instance<MODE>(S, A, A.models[mid], A.cfgs[mid], lc, b, lane);
-    mid = mid_next;
-    WSYNC();
-  }
+  // the model index is wave-uniform: say so, or every M.* / cfg.* access becomes a vector load
+  const int mid = A.in.model_id ? __builtin_amdgcn_readfirstlane(A.in.model_id[b]) : 0;
+  const InRegs cur = load_inputs(A.in, b, lane, has2, has3);
+  const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);   // L1/L2-resident 3 KB table
+  stage_inputs(S, cur, lane, has2, has3);
+  WSYNC();
+  process_instance<MODE>(S, A, models[mid], cfgs[mid], lc, b, lane);
 }
 
 // Stand-alone QP (QP_Wrapper.QP.solveQP): H, g (or A, b) and constraints straight from HBM.
 __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
   __shared__ Smem S;
+  S.cl[threadIdx.x] = 0.0;
+  if (threadIdx.x < LDJ) S.RApad[threadIdx.x] = 0.0;
 #pragma unroll 1
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     int lane = threadIdx.x, n = A.n, p = A.p, m = A.m;
@@ -1197,7 +1266,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
     const double clb = (lane < p) ? A.Clb[(size_t)b * p + lane] : 0.0;
     const double cub = (lane < p) ? A.Cub[(size_t)b * p + lane] : 0.0;
     WSYNC();
-    unsigned long long ts[T_N];
+    unsigned long long ts[T_NN];
     (void)ts;
     const QpResult res = qp_core(S, g, lb, ub, clb, cub, n, p, lane, ts);
     if (lane < n) A.x[(size_t)b * n + lane] = res.x;
@@ -1239,9 +1308,9 @@ static int check_launch(const char* what) {
 
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (mode == MODE_TICK) hipLaunchKernelGGL(wbc_tick_kernel<MODE_TICK>, dim3(grid), dim3(64), 0, s, a);
-  else if (mode == MODE_ASSEMBLE) hipLaunchKernelGGL(wbc_tick_kernel<MODE_ASSEMBLE>, dim3(grid), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL(wbc_tick_kernel<MODE_FK>, dim3(grid), dim3(64), 0, s, a);
+  if (mode == MODE_TICK) hipLaunchKernelGGL(wbc_tick_kernel<MODE_TICK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs);
+  else if (mode == MODE_ASSEMBLE) hipLaunchKernelGGL(wbc_tick_kernel<MODE_ASSEMBLE>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs);
+  else hipLaunchKernelGGL(wbc_tick_kernel<MODE_FK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs);
   return check_launch("tick");
 }
 int launch_qp(const QpArgs& a, int grid, void* stream) {

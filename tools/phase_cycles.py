@@ -32,4 +32,5 @@ out = {"ticks": c[0], "iters_mean": c[8] / n}
 for i in range(1, 8):
     out[names[i]] = c[i] / n
 out["total"] = sum(c[1:8]) / n
+out["task_sub"] = dict(rows_targets=c[9] / n, jtj_posture=c[10] / n, constraint_rows=c[11] / n, damper=c[12] / n)
 print(json.dumps(out))
