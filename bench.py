@@ -34,6 +34,23 @@ FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak
 ALGO_FLOP_PER_TICK = 5.5e4     # + ~1e4 per working-set change beyond the equalities
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the tick kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_summary_v8.txt: FETCH_SIZE and WRITE_SIZE in KiB, separate --pmc runs, tools/gpu_profile.sh).
+    8-byte-per-lane accesses: the gfx950 x2 FETCH_SIZE correction for 16-byte streams does not apply (uncalibrated width)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_v8.txt")
+    try:
+        vals = {}
+        for line in open(path):
+            if "tick_kernel<0>" in line:
+                for key in ("FETCH_SIZE", "WRITE_SIZE"):
+                    if " %s " % key in line:
+                        vals[key] = float(line.split("per_dispatch=")[1])
+        return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,11 +139,11 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "dt": DT, "parallelism": "shard%d (no collective)" % world,
                        "jtj": "mfma_f64" if args.jtj_mfma else "valu_f64"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "wbc_tick_kernel<0>", "kernel_ms": kernel_ms,
+                         "traffic": pmc_traffic_bytes(), "traffic_unit": "bytes/launch (PMC, batch 65536)", "kernel": "wbc_tick_kernel<0>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_tick": ALGO_BYTES_PER_TICK, "streamed_bytes_per_tick": ACTUAL_BYTES_PER_TICK,
                          "fp64_tflops": ALGO_FLOP_PER_TICK * B / (kernel_ms * 1e-3) / 1e12,
                          "fp64_frac": ALGO_FLOP_PER_TICK * B / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                         "note": "tiny-dense LDS-resident fp64 work: latency/occupancy bound, neither HBM nor MFMA is approachable (SURVEY.md §8d)"},
+                         "note": "tiny-dense LDS-resident fp64 work: VALU- and LDS-issue bound, neither HBM nor MFMA is approachable (SURVEY.md §8d); see profiles/"},
             "solver": {"optimal_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
                        "iters_p95": float(np.percentile(iters, 95)), "iters_max": int(iters.max())},
         }

@@ -219,14 +219,55 @@ __device__ __forceinline__ void integrate_ff(const Smem& S, const int lane, doub
 // ------------------------------------------------------------------------------------------------
 struct QpResult { double x; int status; int iters; };
 
-__device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const double lb, const double ub,
-                                            const double clb, const double cub, const int n, const int p, const int lane,
+__device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const double lb_in, const double ub_in,
+                                            const double clb_in, const double cub_in, const int n, const int p, const int lane,
                                             unsigned long long* ts) {
   const int li = li_clamp(lane);
   QpResult res;
   res.status = WBC_QP_OPTIMAL;
   res.iters = 0;
   res.x = 0.0;
+  double g = g_in, lb = lb_in, ub = ub_in, clb = clb_in, cub = cub_in;
+
+  // ---- presolve: variables with lb == ub are fixed (the locked gripper / finger DoF, Robot_Wrapper4.py:627-630).
+  // Their rows and columns leave H and C (H_kk = 1, g_k = -value reproduces x_k = value), the value's contribution
+  // moves into g and the row bounds. Same solution as carrying them as equality constraints, three fewer columns
+  // in the equality factorisation. Counted as working-set changes so that `iters` keeps its meaning.
+  const bool fixb = (lane < n) && (lb == ub) && (fabs(lb) < QP_INF);
+  const unsigned long long fixm = __ballot(fixb);
+  const int nfix = __popcll(fixm);
+  if (fixm) {
+    const double fv = fixb ? lb : 0.0;
+    if (__ballot(fv != 0.0)) {              // non-zero fixed values: shift g and the row bounds
+      if (lane < 32) S.yv[lane] = fv;
+      WSYNC();
+      double gs = 0.0, cs = 0.0;
+#pragma unroll
+      for (int k = 0; k < NV; k += 2) {
+        const double2a h2 = lds2(S.RA + li * LDJ + k); const double2a c2 = lds2(S.RC + ((lane < p) ? lane : 0) * LDJ + k);
+        const double2a f2 = lds2(S.yv + k);
+        gs = fma(h2.x, f2.x, fma(h2.y, f2.y, gs)); cs = fma(c2.x, f2.x, fma(c2.y, f2.y, cs));
+      }
+      g += gs;
+      if (lane < p) { clb -= cs; cub -= cs; }
+      WSYNC();
+    }
+    unsigned long long m = fixm;
+#pragma unroll 1
+    while (m) {
+      const int k = ctz64(m); m &= m - 1;
+      if (lane < NV) S.RA[lane * LDJ + k] = 0.0;
+      if (lane < p) S.RC[lane * LDJ + k] = 0.0;
+    }
+    if (fixb) {
+#pragma unroll
+      for (int k = 0; k < NV; k += 2) sts2(S.RA + lane * LDJ + k, 0.0, 0.0);
+      S.RA[lane * LDJ + lane] = 1.0;
+      g = -fv;
+      lb = -1e30; ub = 1e30;                // no longer a constraint
+    }
+    WSYNC();
+  }
 
   // ---- row `lane` of H into registers (lanes >= 26 shadow row 25; they never write)
   double h[NV];
@@ -348,19 +389,20 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
   bool act_b = eq_b, act_r = eq_r;        // bound `lane` / row `lane` in the working set (equalities stay in)
   double u = 0.0;                         // multiplier of working-set slot `lane` (inequality slots only)
   int a_code = 0;                         // slot `lane`: constraint id | side << 8
-  int q = 0, iters = 0;
+  int q = 0, iters = nfix;
   const int max_iter = 10 * (n + p) + 20;
 
   // ---- equality block: Householder QR of B = J0'N_e with ROTATING columns (bq[0] is always the current column);
   // every reflector is applied at once to the remaining columns, to L^-1 g and to row `lane` of J0 (all in registers).
   // y1 solves R'y1 = b_e incrementally. Nothing but the reflector vector goes through LDS.
   double y1 = 0.0;                        // lane k < q: y1_k
+  const bool any_be = __ballot((eq_b && lb != 0.0) || (eq_r && clb != 0.0)) != 0;
 #pragma unroll 1
   for (int e = 0; e < ne; ++e) {
     ++iters;
     const double d = bq[0];
     const double zn = wsum(lane >= q ? d * d : 0.0);
-    const double dy = wsum(lane < q ? d * y1 : 0.0);
+    const double dy = any_be ? wsum(lane < q ? d * y1 : 0.0) : 0.0;   // y1 stays 0 when every right-hand side is 0
     const double b_e = S.dinv[e], np2 = S.lv[e];
     double beta = 0.0, v = 0.0;
     if (zn > 100.0 * n * EPS2 * jf2 * np2) {
@@ -389,15 +431,25 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g, const doubl
     bg = fma(-wsum(v * bg) * beta, v, bg);
     // row `lane` of J0:  row <- row - (row . v) beta v'
     if (beta != 0.0) {
+      // (v is zero below the slot it was built for; q was already advanced, so entries k < q - 1 can be skipped
+      //  in groups of eight with one uniform branch per group)
       double vk[NV], w = 0.0, w2 = 0.0;
 #pragma unroll
       for (int k = 0; k < NV; k += 2) { const double2a v2 = lds2(S.dv + k); vk[k] = v2.x; vk[k + 1] = v2.y; }
+      LDS_THEN_VALU(13, 0);
 #pragma unroll
-      for (int k = 0; k < NV; k += 2) { w = fma(y[k], vk[k], w); w2 = fma(y[k + 1], vk[k + 1], w2); }
-      LDS_THEN_VALU(13, 26);
+      for (int k0 = 0; k0 < NV; k0 += 8) {
+        if (k0 + 8 < q) continue;
+#pragma unroll
+        for (int k = k0; k < k0 + 8 && k < NV; k += 2) { w = fma(y[k], vk[k], w); w2 = fma(y[k + 1], vk[k + 1], w2); }
+      }
       w = (w + w2) * beta;
 #pragma unroll
-      for (int k = 0; k < NV; ++k) y[k] = fma(-w, vk[k], y[k]);
+      for (int k0 = 0; k0 < NV; k0 += 8) {
+        if (k0 + 8 < q) continue;
+#pragma unroll
+        for (int k = k0; k < k0 + 8 && k < NV; ++k) y[k] = fma(-w, vk[k], y[k]);
+      }
     }
     WSYNC();
   }

@@ -70,14 +70,14 @@ def test_assemble_parity(wx200, cfg_name, with_rot):
     bt.close()
 
 
-def _random_qps(rng, B, n, p, n_eq):
+def _random_qps(rng, B, n, p, n_eq, fixed_value=0.0):
     A = rng.normal(size=(B, n + 6, n))
     H = np.einsum("bmi,bmj->bij", A, A) + 1e-3 * np.eye(n)
     g = rng.normal(size=(B, n)) * 4
     C = rng.normal(size=(B, p, n))
     lb, ub = -rng.uniform(0.02, 0.8, (B, n)), rng.uniform(0.02, 0.8, (B, n))
-    lb[:, -2:] = 0.0
-    ub[:, -2:] = 0.0
+    lb[:, -2:] = fixed_value          # fixed variables (lb == ub): the kernel presolves them out
+    ub[:, -2:] = fixed_value
     cl, cu = -rng.uniform(0.02, 0.8, (B, p)), rng.uniform(0.02, 0.8, (B, p))
     cl[:, :n_eq] = cu[:, :n_eq] = rng.normal(size=(B, n_eq)) * 0.1
     return H, g, C, lb, ub, cl, cu
@@ -99,6 +99,14 @@ def test_qp_parity_random(wx200, n, p, n_eq):
     ok = sr == 0
     assert ok.sum() > B // 2
     assert np.abs(x[ok] - xr[ok]).max() < 1e-9
+    assert np.abs(it[ok] - ir[ok]).max() == 0        # same working-set changes as the textbook method
+    # non-zero fixed values: their contribution moves into g and the row bounds
+    H, g, C, lb, ub, cl, cu = _random_qps(rng, 64, n, p, n_eq, fixed_value=0.07)
+    x, st, it = bt.qp_solve(H, g, C if p else None, lb, ub, cl if p else None, cu if p else None)
+    xr, sr, ir = oracle.qp_solve(H, g, C if p else None, lb, ub, cl if p else None, cu if p else None)
+    assert (st == sr).all()
+    ok = sr == 0
+    assert np.abs(x[ok] - xr[ok]).max() < 1e-9 and np.abs(x[ok][:, -2:] - 0.07).max() < 1e-12
     bt.close()
 
 
