@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances for the CPU baseline (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--jtj-mfma", type=int, default=0)
+    ap.add_argument("--posture", default="PREV", choices=["PREV", "HYBRID", "MANI"],
+                    help="posture mode of the tick (default PREV = the BASELINE workload; HYBRID is what sim3.py:145 sets)")
     args = ap.parse_args()
 
     import torch
@@ -83,7 +85,7 @@ def main():
 
     B, DT = args.batch, 0.002
     model = wbc_model.load_model("a1_wx200")
-    cfg = wbc_model.sim3_config(model)
+    cfg = wbc_model.sim3_config(model, Joint=args.posture)
     bt = WbcBatch(model, B, device_id=local)
     bt.configure(cfg)
     if args.jtj_mfma:
@@ -134,7 +136,7 @@ def main():
             "metric": "wbc_qp_solves_per_sec", "value": value, "unit": "ticks/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2] / SURVEY C3: A1+wx200 (nq 27, nv 26), sim3 switch set: Grip task + PREV posture, "
+            "config": {"workload": "BASELINE configs[2] / SURVEY C3: A1+wx200 (nq 27, nv 26), sim3 switch set: Grip task + " + args.posture + " posture, "
                                    "12 contact equalities + 4 trunk-box rows + 26 damper bounds (3 locked), m=32 p=16 n=26",
                        "batch_per_gpu": B, "global_batch": B * world, "dt": DT, "parallelism": "shard%d (no collective)" % world,
                        "jtj": "mfma_f64" if args.jtj_mfma else "valu_f64"},

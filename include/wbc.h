@@ -60,7 +60,10 @@ enum { WBC_MEM_HOST = 0, WBC_MEM_DEVICE = 1 };
 enum { WBC_QP_OPTIMAL = 0, WBC_QP_MAX_ITER = 1, WBC_QP_INFEASIBLE = 2, WBC_QP_NUMERICAL = 3 };
 
 /* posture-task mode = RobotModel.task_active_Joint (Robot_Wrapper4.py:1209-1268) */
-enum { WBC_JOINT_OFF = 0, WBC_JOINT_TIKHONOV = 1 /* True */, WBC_JOINT_PREV = 2 /* "PREV" */ };
+enum { WBC_JOINT_OFF = 0, WBC_JOINT_TIKHONOV = 1 /* True */, WBC_JOINT_PREV = 2 /* "PREV" */,
+       WBC_JOINT_MANI = 3 /* "MANI": manipulability gradient, :1220-1242 */,
+       WBC_JOINT_HYBRID = 4 /* "HYBRID": PREV for the quadruped + manipulability gradient for the arm, :1245-1260 */,
+       WBC_JOINT_CUSTOM = 5 /* u supplied per instance in WbcTickIn.posture_u */ };
 
 /* API return codes */
 enum { WBC_OK = 0, WBC_E_ARG = -1, WBC_E_HIP = -2, WBC_E_UNSUPPORTED = -3, WBC_E_STATE = -4 };
@@ -100,6 +103,11 @@ typedef struct WbcConfig {
   int32_t con_ee[WBC_NEE];     /* const_active_{FR,FL,RR,RL}_foot, const_active_GRIP              */
   int32_t use_bounds;          /* 1: velDamperJointConstraints box; 0: no box (equality-only QP)  */
   int32_t lock_from;           /* DoF >= lock_from get lb = ub = 0 (Robot_Wrapper4.py:627-630)    */
+  int32_t arm_base_id;         /* model.getJointId(G_base) (Robot_Wrapper4.py:37): HYBRID differentiates joints >= it */
+  int32_t posture_literal;     /* MANI/HYBRID: 1 = the reference's arithmetic to the letter (q is perturbed at
+                                  the velocity index, perturbations accumulate, and the perturbed configuration is what
+                                  findConstraints / velDamperJointConstraints / integrate then see); 0 = the intended
+                                  central difference (own q index, configuration restored)                           */
   int32_t damper_qidx[WBC_MAX_NV]; /* which q entry DoF i's damper looks at (quirk C.3)           */
   double damper_lo[WBC_MAX_NV], damper_hi[WBC_MAX_NV], damper_vmax[WBC_MAX_NV];
   double damper_coef, damper_qi, damper_qs;      /* 0.01, 0.026, 0.015 (Robot_Wrapper4.py:574-576) */
@@ -131,6 +139,10 @@ typedef struct WbcTickIn {
   const double* com_target;        /* [B][3]    Robot_Wrapper2 target_cartesian_pos_CoM (NULL if no CoM task) */
   const double* com_target_vel;    /* [B][3]    Robot_Wrapper2 target_cartesian_vel_CoM               */
   const int32_t* model_id;         /* [B] index into the batch's models; NULL => all model 0          */
+  const double* posture_u;         /* [B][26]   posture target u of qpJointb before the (1/nv) w scaling: required for
+                                                WBC_JOINT_CUSTOM; for MANI/HYBRID NULL => computed by the library (wbc_posture_target) */
+  const double* q_con;             /* [B][27]   configuration seen by findConstraints, velDamperJointConstraints and integrate when it
+                                                differs from q (the state qpJointb MANI/HYBRID leaves behind); NULL => q          */
 } WbcTickIn;
 
 #define WBC_Q_STRIDE 27   /* doubles per instance in q / q_next (nq of the largest model)           */
@@ -207,6 +219,13 @@ int wbc_qp_solve(WbcBatch* b, int B, int n, int p, const double* H, const double
 int wbc_qp_solve_ls(WbcBatch* b, int B, int m, int n, int p, const double* A, const double* bvec, const double* C,
                     const double* lb, const double* ub, const double* Clb, const double* Cub, int mem, int use_mfma,
                     double* x, int32_t* status, int32_t* iters, double* H_out, double* g_out, void* stream);
+
+/* replaces qpJointb's "MANI" / "HYBRID" branches (Robot_Wrapper4.py:1220-1260) under the configured task_joint,
+ * arm_base_id and posture_literal: u [B][26] = the posture target before scaling (PREV / zeros for the other modes),
+ * q_after [B][27] = the configuration the reference's state holds afterwards (optional). wbc_tick / wbc_assemble call
+ * this themselves when task_joint is MANI or HYBRID and WbcTickIn.posture_u is NULL. */
+int wbc_posture_target(WbcBatch* b, int B, const double* q, const int32_t* model_id, int mem, double* u, double* q_after,
+                       void* stream);
 
 /* the fused hot path = one runWBC tick up to and including the QP (+ optional integrate):
  * FK -> Jacobians -> task stack -> H, g, C, bounds -> QP -> qdot [-> q_next]. */

@@ -16,7 +16,9 @@ klampt are not used. Differences from the reference, all deliberate and document
   * ``dt`` is the fixed ``step_time`` (the reference busy-waits and measures wall-clock) unless
     ``pace_realtime = True`` is set on the object;
   * the per-tick debug prints of calcTargetVelEE3 (Robot_Wrapper4.py:1075-1085) are not emitted;
-  * posture modes "MANI"/"HYBRID" are not on the device path yet (SURVEY.md §8 f3): NotImplementedError;
+  * posture modes "MANI"/"HYBRID" run on the device to the letter of the reference, including the
+    perturbed configuration qpJointb leaves in current_joint_config / robot_data; ``posture_literal = False`` on the
+    object switches to the clean central difference;
   * ``solver_status`` / ``solver_iters`` expose what the reference throws away.
 """
 import time
@@ -166,6 +168,7 @@ class RobotModel:
         self.dt = 0.002
         self.pace_realtime = False
         self.damper_compat = True          # reproduce the reference's index quirk
+        self.posture_literal = True        # MANI/HYBRID to the letter, state leak included
 
         self.prev_trunk_ref = np.array([0, 0, 0])
         self.old_ref_trunk_rot_matrix = np.zeros((3, 3))
@@ -245,7 +248,8 @@ class RobotModel:
         j = self.task_active_Joint if joint == "same" else joint
         if j is False or j is None:
             j = True     # the device needs H > 0; callers that asked for no posture rows get them sliced off again
-        cfg = wbc_model.make_config(self._model, Joint=j, damper_compat=self.damper_compat, **t, **c)
+        cfg = wbc_model.make_config(self._model, Joint=j, damper_compat=self.damper_compat,
+                                    posture_literal=self.posture_literal, **t, **c)
         for i in range(5):
             W = _diag6(self.EE_weight[i], "EE_weight[%d]" % i)
             G = _diag6(self.EE_gains[i], "EE_gains[%d]" % i)
@@ -382,7 +386,7 @@ class RobotModel:
     def qpA(self):
         """reference :1271-1280: (6 n_tasks [+ nv]) x nv"""
         nv = self._model.nv
-        a = self._assemble(self._config(), want=("A",))["A"]
+        a = self._assemble(self._config(joint=True), want=("A",))["A"]   # qpJointA does not depend on the posture mode
         m_cart = a.shape[0] - capi.V_STRIDE          # the device always carries the (padded) posture block
         return a[:m_cart + (nv if self._has_posture() else 0), :nv]
 
@@ -392,6 +396,16 @@ class RobotModel:
         b = self._assemble(self._config(), target_cartesian_pos_EE, target_cartesian_pos_trunk, want=("b",))["b"]
         m_cart = b.shape[0] - capi.V_STRIDE
         b = b[:m_cart + nv] if self._has_posture() else b[:m_cart]
+        if self.task_active_Joint in ("MANI", "HYBRID") and self.posture_literal:
+            # qpJointb leaves the model at the last perturbed configuration (:1231-1236, :1252-1257; updateState aliases
+            # current_joint_config to the array being perturbed): everything called after qpb sees that state
+            q = np.zeros((1, capi.Q_STRIDE))
+            q[0, :self._model.nq] = self.current_joint_config
+            self._bt.configure(self._config())
+            _, q_after = self._bt.posture_target(q)
+            self.previous_joint_config = self.current_joint_config
+            self.current_joint_config = q_after[0, :self._model.nq].copy()
+            self._fk(self.current_joint_config)
         self._advance_reference_state(target_cartesian_pos_EE, target_cartesian_pos_trunk)
         return b.reshape(-1, 1)
 
@@ -400,12 +414,12 @@ class RobotModel:
 
     def findConstraints(self):
         """reference :764-836: returns (C.T, Clb, Cub) with C.T of shape (nv, p)"""
-        o = self._assemble(self._config(), want=("C", "Clb", "Cub"))
+        o = self._assemble(self._config(joint=True), want=("C", "Clb", "Cub"))   # independent of the posture mode
         return o["C"][:, :self._model.nv].T, o["Clb"], o["Cub"]
 
     def velDamperJointConstraints(self):
         """reference :572-637"""
-        o = self._assemble(self._config(), want=("lb", "ub"))
+        o = self._assemble(self._config(joint=True), want=("lb", "ub"))
         return o["lb"][:self._model.nv], o["ub"][:self._model.nv]
 
     def _one_task(self, **which):

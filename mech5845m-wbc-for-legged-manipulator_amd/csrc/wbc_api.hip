@@ -40,6 +40,7 @@ struct WbcBatch {
   int mrows, prows, mcart;
   int jtj_mfma;
   unsigned long long* d_prof;
+  double *d_pu, *d_pq;   // qpJointb MANI/HYBRID results: u [max_batch][26], q_after [max_batch][27] (lazy)
 };
 
 // ---------------------------------------------------------------------------------------------- model
@@ -154,6 +155,8 @@ extern "C" void wbc_batch_destroy(WbcBatch* b) {
   if (b->d_cfgs) (void)hipFree(b->d_cfgs);
   if (b->ws) (void)hipFree(b->ws);
   if (b->d_prof) (void)hipFree(b->d_prof);
+  if (b->d_pu) (void)hipFree(b->d_pu);
+  if (b->d_pq) (void)hipFree(b->d_pq);
   delete b;
 }
 
@@ -174,7 +177,9 @@ static int rows_con(const WbcConfig& c) {
 extern "C" int wbc_batch_configure(WbcBatch* b, int mi, const WbcConfig* cfg) {
   if (!b || !cfg || mi < 0 || mi >= b->n_models) return fail(WBC_E_ARG, "wbc_batch_configure: bad arguments");
   const int nv = b->models[mi]->blob.nv, nq = b->models[mi]->blob.nq;
-  if (cfg->task_joint < 0 || cfg->task_joint > WBC_JOINT_PREV) return fail(WBC_E_UNSUPPORTED, "posture mode %d not on the device path", cfg->task_joint);
+  if (cfg->task_joint < 0 || cfg->task_joint > WBC_JOINT_CUSTOM) return fail(WBC_E_ARG, "unknown posture mode %d", cfg->task_joint);
+  if (cfg->task_joint == WBC_JOINT_HYBRID && (cfg->arm_base_id < 1 || cfg->arm_base_id >= b->models[mi]->blob.njoints))
+    return fail(WBC_E_ARG, "HYBRID posture: arm_base_id %d is not a joint of the model", cfg->arm_base_id);
   if (!cfg->task_joint) return fail(WBC_E_UNSUPPORTED, "the posture task must be on: without it H = J'J is singular (Robot_Wrapper4.py:1199-1206)");
   for (int i = 0; i < nv; ++i)
     if (cfg->use_bounds && (cfg->damper_qidx[i] < 0 || cfg->damper_qidx[i] >= nq)) return fail(WBC_E_ARG, "damper_qidx[%d] = %d out of range", i, cfg->damper_qidx[i]);
@@ -275,6 +280,7 @@ static void stage_tick_in(Stager& st, WbcTickIn& in, int B, const WbcBatch* b) {
   st.in(&in.trunk_ref_euler, n * 3); st.in(&in.trunk_prev_rot, n * 9);
   st.in(&in.com_target, n * 3); st.in(&in.com_target_vel, n * 3);
   st.in(&in.model_id, n);
+  st.in(&in.posture_u, n * WBC_V_STRIDE); st.in(&in.q_con, n * WBC_Q_STRIDE);
   (void)b;
 }
 
@@ -290,6 +296,34 @@ static int validate_tick_in(const WbcBatch* b, const WbcTickIn* in, const char* 
   if (c.con_trunk && !in->trunk_box_center) return fail(WBC_E_ARG, "%s: the trunk constraint needs trunk_box_center", who);
   if (c.task_com && (!in->com_target || !in->com_target_vel)) return fail(WBC_E_ARG, "%s: the CoM task needs com_target and com_target_vel", who);
   if (b->n_models > 1 && !in->model_id) return fail(WBC_E_ARG, "%s: model_id is required with %d models", who, b->n_models);
+  for (int i = 0; i < b->n_models; ++i)
+    if (b->cfg_host[i].task_joint == WBC_JOINT_CUSTOM && !in->posture_u) return fail(WBC_E_ARG, "%s: posture mode CUSTOM needs posture_u", who);
+  return WBC_OK;
+}
+
+// qpJointb "MANI" / "HYBRID" (Robot_Wrapper4.py:1220-1260) ahead of the tick kernel: fills a.in.posture_u (and a.in.q_con
+// in literal mode) from the device-resident q unless the caller supplied them. Pointers in `a` are device pointers here.
+static int run_posture(WbcBatch* b, int B, const double* q, const int32_t* model_id, double* u, double* q_after, void* stream) {
+  PostureArgs pa;
+  memset(&pa, 0, sizeof pa);
+  pa.models = b->d_models; pa.cfgs = b->d_cfgs; pa.B = B; pa.q = q; pa.model_id = model_id; pa.u = u; pa.q_after = q_after;
+  if (int e = launch_posture(pa, B, stream)) return fail(WBC_E_HIP, "posture kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  return WBC_OK;
+}
+static int auto_posture(WbcBatch* b, KernelArgs& a, int B, void* stream) {
+  bool need = false, literal = false;
+  for (int i = 0; i < b->n_models; ++i) {
+    const int tj = b->cfg_host[i].task_joint;
+    if (tj == WBC_JOINT_MANI || tj == WBC_JOINT_HYBRID) { need = true; literal |= b->cfg_host[i].posture_literal != 0; }
+  }
+  if (!need || a.in.posture_u) return WBC_OK;
+  if (!b->d_pu) {
+    HIP_TRY(hipMalloc((void**)&b->d_pu, sizeof(double) * WBC_V_STRIDE * (size_t)b->max_batch));
+    HIP_TRY(hipMalloc((void**)&b->d_pq, sizeof(double) * WBC_Q_STRIDE * (size_t)b->max_batch));
+  }
+  if (int rc = run_posture(b, B, a.in.q, a.in.model_id, b->d_pu, b->d_pq, stream)) return rc;
+  a.in.posture_u = b->d_pu;
+  if (literal && !a.in.q_con) a.in.q_con = b->d_pq;
   return WBC_OK;
 }
 
@@ -343,6 +377,7 @@ extern "C" int wbc_assemble(WbcBatch* b, int B, const WbcTickIn* in, double dt, 
   st.out(&a.qp.A, n * m * V); st.out(&a.qp.b, n * m); st.out(&a.qp.H, n * V * V); st.out(&a.qp.g, n * V);
   st.out(&a.qp.C, n * p * V); st.out(&a.qp.Clb, n * p); st.out(&a.qp.Cub, n * p); st.out(&a.qp.lb, n * V); st.out(&a.qp.ub, n * V);
   if ((rc = st.stage())) return rc;
+  if ((rc = auto_posture(b, a, B, stream))) return rc;
   if (int e = launch_tick(a, MODE_ASSEMBLE, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "assemble kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return st.finish();
 }
@@ -361,7 +396,23 @@ extern "C" int wbc_tick(WbcBatch* b, int B, const WbcTickIn* in, double dt, int 
   const size_t n = (size_t)B;
   st.out(&a.out.qdot, n * WBC_V_STRIDE); st.out(&a.out.status, n); st.out(&a.out.iters, n); st.out(&a.out.q_next, n * WBC_Q_STRIDE);
   if ((rc = st.stage())) return rc;
+  if ((rc = auto_posture(b, a, B, stream))) return rc;
   if (int e = launch_tick(a, MODE_TICK, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  return st.finish();
+}
+
+extern "C" int wbc_posture_target(WbcBatch* b, int B, const double* q, const int32_t* model_id, int mem, double* u, double* q_after,
+                                  void* stream) {
+  int rc = check_batch(b, B, "wbc_posture_target", true);
+  if (rc) return rc;
+  if (!q || !u) return fail(WBC_E_ARG, "wbc_posture_target: q and u required");
+  if (b->n_models > 1 && !model_id) return fail(WBC_E_ARG, "wbc_posture_target: model_id is required with %d models", b->n_models);
+  HIP_TRY(hipSetDevice(b->device_id));
+  Stager st{b, mem, (hipStream_t)stream, {}};
+  st.in(&q, (size_t)B * WBC_Q_STRIDE); st.in(&model_id, (size_t)B);
+  st.out(&u, (size_t)B * WBC_V_STRIDE); st.out(&q_after, (size_t)B * WBC_Q_STRIDE);
+  if ((rc = st.stage())) return rc;
+  if ((rc = run_posture(b, B, q, model_id, u, q_after, stream))) return rc;
   return st.finish();
 }
 

@@ -61,10 +61,20 @@ struct IntegrateArgs {
   double* q_next;
 };
 
+struct PostureArgs {
+  const DevModel* models;
+  const WbcConfig* cfgs;
+  int32_t B, pad0;
+  const double* q;
+  const int32_t* model_id;
+  double *u, *q_after;
+};
+
 // launchers (wbc_kernels.hip); grid = min(B, waves) persistent single-wave workgroups
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream);
 int launch_qp(const QpArgs& a, int grid, void* stream);
 int launch_integrate(const IntegrateArgs& a, int grid, void* stream);
+int launch_posture(const PostureArgs& a, int grid, void* stream);
 int tick_lds_bytes();
 
 }  // namespace wbc

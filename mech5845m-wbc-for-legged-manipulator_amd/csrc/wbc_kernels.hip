@@ -751,11 +751,13 @@ __device__ __forceinline__ LaneConst load_lane_const(const DevModel& M, const Wb
 }
 
 // the per-instance inputs, one value per lane per group (coalesced loads), staged into S.in
-struct InRegs { double g1, g2, g3a, g3b; };
+struct InRegs { double g1, g2, g3a, g3b, pu, qc; };
 
 __device__ __forceinline__ InRegs load_inputs(const WbcTickIn& in, const int b, const int lane, const bool has2, const bool has3) {
   InRegs r;
-  r.g1 = r.g2 = r.g3a = r.g3b = 0.0;
+  r.g1 = r.g2 = r.g3a = r.g3b = r.pu = r.qc = 0.0;
+  if (in.posture_u && lane < NV) r.pu = in.posture_u[(size_t)b * NV + lane];
+  if (in.q_con && lane < NQ) r.qc = in.q_con[(size_t)b * NQ + lane];
   {
     const double* p = nullptr;
     if (lane < 27) p = in.q + (size_t)b * NQ + lane;
@@ -787,22 +789,11 @@ __device__ __forceinline__ void stage_inputs(Smem& S, const InRegs& r, const int
 }
 
 // ------------------------------------------------------------------------------------------------
-// One instance: FK -> Jacobians -> task stack -> H, g, C, bounds [-> QP -> qdot -> q_next]
-// (inputs already staged in S.in)
+// forward kinematics + Jacobian columns of one configuration (updateState's pinocchio calls, Robot_Wrapper4.py:400-405)
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
-                                                 const LaneConst& lc, const int b, const int lane) {
-  const int nv = M.nv, nq = M.nq, nj = M.njoints;
-  const double dt = A.dt, inv_dt = 1.0 / A.dt;   // x * (1/dt) for x / dt: one rounding more than the reference's division
-  (void)dt;
-  double* const oMi = S.RA + OFF_OMI;   // [joint][12]: R column-major (3 columns), then p
-  const double* const qv = S.in + IN_Q;
-  unsigned long long ts[T_NN];
-  (void)ts;
-  STAMP(ts, T_START);
-
-  // ---- P1: forward kinematics, pin.forwardKinematics (Robot_Wrapper4.py:400)
+// P1: pin.forwardKinematics. qv = the configuration (LDS), oMi = [joint][12] (R column-major, then p), lane j = joint j.
+__device__ __forceinline__ void fk_levels(double* const oMi, const double* const qv, const DevModel& M, const LaneConst& lc,
+                                          const int lane) {
   // root free-flyer: R from the quaternion exactly as Eigen's toRotationMatrix, p = xyz
   if (lane == 1) {
     double Rt[9];
@@ -813,40 +804,56 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
       for (int r = 0; r < 3; ++r) oMi[12 + 3 * c + r] = Rt[3 * r + c];
     oMi[12 + 9] = qv[0]; oMi[12 + 10] = qv[1]; oMi[12 + 11] = qv[2];
   }
-  {
-    const double th = lc.is_joint ? qv[lc.q_idx] : 0.0;
-    const SinCos sc = sincos_cw(lc.rev ? th : 0.0);
-    const double sn = sc.s, cs = sc.c;
-    const double pris = lc.pris ? th : 0.0;
-    WSYNC();
+  const double th = lc.is_joint ? qv[lc.q_idx] : 0.0;
+  const SinCos sc = sincos_cw(lc.rev ? th : 0.0);
+  const double sn = sc.s, cs = sc.c;
+  const double pris = lc.pris ? th : 0.0;
+  WSYNC();
 #pragma unroll 1
-    for (int lvl = 2; lvl <= M.maxdepth; ++lvl) {
-      if (lc.depth == lvl) {
-        const double* Pp = oMi + lc.par_off;
-        double Av[3], Bv[3], Cv[3], P[3];
+  for (int lvl = 2; lvl <= M.maxdepth; ++lvl) {
+    if (lc.depth == lvl) {
+      const double* Pp = oMi + lc.par_off;
+      double Av[3], Bv[3], Cv[3], P[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { Av[r] = Pp[lc.a0 + r]; Bv[r] = Pp[lc.a1 + r]; Cv[r] = Pp[lc.a2 + r]; P[r] = Pp[9 + r]; }
-        double* Po = oMi + 12 * lane;
+      for (int r = 0; r < 3; ++r) { Av[r] = Pp[lc.a0 + r]; Bv[r] = Pp[lc.a1 + r]; Cv[r] = Pp[lc.a2 + r]; P[r] = Pp[9 + r]; }
+      double* Po = oMi + 12 * lane;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          Po[lc.a0 + r] = Av[r];
-          Po[lc.a1 + r] = cs * Bv[r] + sn * Cv[r];
-          Po[lc.a2 + r] = cs * Cv[r] - sn * Bv[r];
-          Po[9 + r] = P[r] + Av[r] * (lc.t0 + pris) + Bv[r] * lc.t1 + Cv[r] * lc.t2;
-        }
+      for (int r = 0; r < 3; ++r) {
+        Po[lc.a0 + r] = Av[r];
+        Po[lc.a1 + r] = cs * Bv[r] + sn * Cv[r];
+        Po[lc.a2 + r] = cs * Cv[r] - sn * Bv[r];
+        Po[9 + r] = P[r] + Av[r] * (lc.t0 + pris) + Bv[r] * lc.t1 + Cv[r] * lc.t2;
       }
-      WSYNC();
     }
+    WSYNC();
   }
+}
+// P3: column `lane` of data.J (pin.computeJointJacobians, WORLD frame): lin = p_j x axis (revolute) or axis (prismatic)
+__device__ __forceinline__ void jac_column(const double* const oMi, const LaneConst& lc, const int lane, const int nv,
+                                           double* lin, double* ang) {
+  lin[0] = lin[1] = lin[2] = 0.0; ang[0] = ang[1] = ang[2] = 0.0;
+  if (lane < nv) {
+    const double* Pj = oMi + lc.cj_off;
+    const int la = lc.col_lin, aa = lc.col_ang;
+    const double pj[3] = {Pj[9], Pj[10], Pj[11]};
+    if (aa >= 0) { ang[0] = Pj[3 * aa]; ang[1] = Pj[3 * aa + 1]; ang[2] = Pj[3 * aa + 2]; cross3(pj, ang, lin); }
+    if (la >= 0) { lin[0] = Pj[3 * la]; lin[1] = Pj[3 * la + 1]; lin[2] = Pj[3 * la + 2]; }
+  }
+}
+struct FkOut { double lin[3], ang[3], com[3], jc[3], Rtr[9], ptr[3]; };
+// P1..P3 + frames + CoM. oMi and (oMi + OFF_MC) are scratch in LDS; frame origins go to S.pf.
+__device__ __forceinline__ void fk_pass(Smem& S, double* const oMi, const double* const qv, const DevModel& M,
+                                        const LaneConst& lc, const bool need_com, const int lane, FkOut& o) {
+  const int nv = M.nv, nj = M.njoints;
+  fk_levels(oMi, qv, M, lc, lane);
   // ---- P2: frame origins, pin.updateFramePlacements (Robot_Wrapper4.py:405); frames carry no rotation offset
   if (lane < M.nframes) {
     const double* Pj = oMi + lc.fj_off;
 #pragma unroll
     for (int r = 0; r < 3; ++r) S.pf[3 * lane + r] = Pj[9 + r] + Pj[r] * lc.f0 + Pj[3 + r] * lc.f1 + Pj[6 + r] * lc.f2;
   }
-  const bool need_com = cfg.task_com || cfg.con_com || (MODE == MODE_FK && (A.fk.com || A.fk.Jcom));
+  double* const mc = oMi + OFF_MC;
   if (need_com) {   // m_j * c_j (world) per joint, pin.jacobianCenterOfMass's subtree pass (Robot_Wrapper4.py:670)
-    double* mc = S.RA + OFF_MC;
     if (lane >= 1 && lane < nj) {
       const double* Pj = oMi + 12 * lane;
 #pragma unroll
@@ -855,18 +862,9 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     }
   }
   WSYNC();
-  // ---- P3: column k of data.J, pin.computeJointJacobians (Robot_Wrapper4.py:403), WORLD frame
-  double lin[3] = {0, 0, 0}, ang[3] = {0, 0, 0};
-  if (lane < nv) {
-    const double* Pj = oMi + lc.cj_off;
-    const int la = lc.col_lin, aa = lc.col_ang;
-    const double pj[3] = {Pj[9], Pj[10], Pj[11]};
-    if (aa >= 0) { ang[0] = Pj[3 * aa]; ang[1] = Pj[3 * aa + 1]; ang[2] = Pj[3 * aa + 2]; cross3(pj, ang, lin); }
-    if (la >= 0) { lin[0] = Pj[3 * la]; lin[1] = Pj[3 * la + 1]; lin[2] = Pj[3 * la + 2]; }
-  }
-  double com[3] = {0, 0, 0}, jc[3] = {0, 0, 0};   // whole-body CoM (uniform) and column k of Jcom
+  jac_column(oMi, lc, lane, nv, o.lin, o.ang);
+  o.com[0] = o.com[1] = o.com[2] = 0.0; o.jc[0] = o.jc[1] = o.jc[2] = 0.0;   // whole-body CoM (uniform), column of Jcom
   if (need_com) {
-    const double* mc = S.RA + OFF_MC;
     double ms = 0, s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll 1
     for (int j = 1; j < nj; ++j) {
@@ -874,26 +872,47 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
       s0 = fma(f, mc[4 * j], s0); s1 = fma(f, mc[4 * j + 1], s1); s2 = fma(f, mc[4 * j + 2], s2); ms = fma(f, mc[4 * j + 3], ms);
     }
     const double Mt = rdl(ms, 0);
-    com[0] = rdl(s0, 0) / Mt; com[1] = rdl(s1, 0) / Mt; com[2] = rdl(s2, 0) / Mt;
+    o.com[0] = rdl(s0, 0) / Mt; o.com[1] = rdl(s1, 0) / Mt; o.com[2] = rdl(s2, 0) / Mt;
     if (lane < nv && ms > 0.0) {
       const double cs_[3] = {s0 / ms, s1 / ms, s2 / ms};
       double wxc[3];
-      cross3(ang, cs_, wxc);
+      cross3(o.ang, cs_, wxc);
       const double f = ms / Mt;
 #pragma unroll
-      for (int r = 0; r < 3; ++r) jc[r] = f * (lin[r] + wxc[r]);
+      for (int r = 0; r < 3; ++r) o.jc[r] = f * (o.lin[r] + wxc[r]);
     }
   }
   // trunk frame (imu): rotation of its supporting joint, uniform read
-  double Rtr[9], ptr[3];
-  {
-    const double* Pj = oMi + 12 * M.frame_joint[WBC_FR_TRUNK];
+  const double* Pj = oMi + 12 * M.frame_joint[WBC_FR_TRUNK];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+  for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int r = 0; r < 3; ++r) Rtr[3 * r + c] = Pj[3 * c + r];
-    ptr[0] = S.pf[3 * WBC_FR_TRUNK]; ptr[1] = S.pf[3 * WBC_FR_TRUNK + 1]; ptr[2] = S.pf[3 * WBC_FR_TRUNK + 2];
-  }
+    for (int r = 0; r < 3; ++r) o.Rtr[3 * r + c] = Pj[3 * c + r];
+  o.ptr[0] = S.pf[3 * WBC_FR_TRUNK]; o.ptr[1] = S.pf[3 * WBC_FR_TRUNK + 1]; o.ptr[2] = S.pf[3 * WBC_FR_TRUNK + 2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// One instance: FK -> Jacobians -> task stack -> H, g, C, bounds [-> QP -> qdot -> q_next]
+// (inputs already staged in S.in)
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
+                                                 const LaneConst& lc, const InRegs& inr, const int b, const int lane) {
+  const int nv = M.nv, nq = M.nq, nj = M.njoints;
+  const double dt = A.dt, inv_dt = 1.0 / A.dt;   // x * (1/dt) for x / dt: one rounding more than the reference's division
+  (void)dt;
+  double* const oMi = S.RA + OFF_OMI;   // [joint][12]: R column-major (3 columns), then p
+  const double* const qv = S.in + IN_Q;
+  unsigned long long ts[T_NN];
+  (void)ts;
+  STAMP(ts, T_START);
+
+  // ---- P1..P3: forward kinematics, frames, Jacobian columns, CoM (updateState, Robot_Wrapper4.py:400-405, 670)
+  const bool need_com = cfg.task_com || cfg.con_com || (MODE == MODE_FK && (A.fk.com || A.fk.Jcom));
+  FkOut fo;
+  fk_pass(S, oMi, qv, M, lc, need_com, lane, fo);
+  double (&lin)[3] = fo.lin; double (&ang)[3] = fo.ang; double (&com)[3] = fo.com; double (&jc)[3] = fo.jc;
+  double (&Rtr)[9] = fo.Rtr; double (&ptr)[3] = fo.ptr;
 
   if (MODE == MODE_FK) {
     const int M0nj = A.fk_nj, M0nf = A.fk_nf;   // output strides = model 0's sizes
@@ -1066,6 +1085,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
   if (cfg.task_joint) {
     dpost = (1.0 / nv) * cfg.joint_w;
     if (cfg.task_joint == WBC_JOINT_PREV && lane < nv) upost = qv[lane < 6 ? lane : lane + 1];   // np.delete(q, 6)
+    if (cfg.task_joint >= WBC_JOINT_MANI && lane < nv) upost = inr.pu;   // MANI / HYBRID (:1220-1260): wbc_posture_kernel's u
     const double bj = (1.0 / nv) * upost * cfg.joint_w;
     if (lane < nv) g = fma(-dpost, bj, g);
     upost = bj;
@@ -1094,6 +1114,14 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
   }
   WSYNC();   // At is dead: Cm may be written
   STAMP(ts, T_A2);
+  if (A.in.q_con) {
+    // qpJointb MANI/HYBRID left robot_data and current_joint_config at a perturbed configuration:
+    // findConstraints, velDamperJointConstraints and integrate see THAT state. oMi scratch = RB (At is dead).
+    if (lane < NQ) S.in[IN_Q + lane] = inr.qc;
+    WSYNC();
+    fk_pass(S, S.RB, qv, M, lc, cfg.con_com != 0, lane, fo);
+    WSYNC();
+  }
 
   // ---- P6: constraints in order CoM, Trunk, FR, FL, RR, RL, Grip: findConstraints (Robot_Wrapper4.py:764-836)
   double* const Cm = S.RC;
@@ -1240,7 +1268,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
   const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);   // L1/L2-resident 3 KB table
   stage_inputs(S, cur, lane, has2, has3);
   WSYNC();
-  process_instance<MODE>(S, A, models[mid], cfgs[mid], lc, b, lane);
+  process_instance<MODE>(S, A, models[mid], cfgs[mid], lc, cur, b, lane);
 }
 
 // Stand-alone QP (QP_Wrapper.QP.solveQP): H, g (or A, b) and constraints straight from HBM.
@@ -1352,6 +1380,112 @@ __global__ void __launch_bounds__(64) wbc_integrate_kernel(const IntegrateArgs A
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// qpJointb "MANI" / "HYBRID" (Robot_Wrapper4.py:1220-1260): u_i = (f(q + d e) - f(q - d e)) / (2 d), f = sqrt(det(J J'))
+// of pin.getJointJacobian(joint_id, LOCAL_WORLD_ALIGNED); one instance per wave, the 2 x (6 or 26) perturbed
+// configurations are evaluated one after the other (each is a full FK: lane j = joint j, then lane k = column k).
+// literal (cfg.posture_literal): the reference's index arithmetic and accumulating perturbations.
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) PSmem {
+  double oMi[24 * 12];
+  double q[32];
+  double Jm[32 * 6];     // column k of the 6 x nv joint Jacobian at Jm[6 k ..]
+  double G[36];
+};
+// det of the symmetric positive semi-definite G = J J' by elimination without pivoting (numpy's det pivots; for an SPD
+// matrix both are backward stable and agree to rounding). G is wave-uniform in LDS.
+__device__ __forceinline__ double det6_spd(const double* G) {
+  double m[6][6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) m[a][b] = G[6 * a + b];
+  double det = 1.0;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double piv = m[c][c];
+    det *= piv;
+    const double ip = (piv > 0.0) ? 1.0 / piv : 0.0;
+#pragma unroll
+    for (int r = c + 1; r < 6; ++r) {
+      const double f = m[r][c] * ip;
+#pragma unroll
+      for (int k = c + 1; k < 6; ++k) m[r][k] = fma(-f, m[c][k], m[r][k]);
+    }
+  }
+  return det > 0.0 ? det : 0.0;
+}
+__device__ __forceinline__ double manipulability(PSmem& P, const DevModel& M, const LaneConst& lc, const int joint_id,
+                                                 const int lane) {
+  const int nv = M.nv;
+  fk_levels(P.oMi, P.q, M, lc, lane);
+  double lin[3], ang[3];
+  jac_column(P.oMi, lc, lane, nv, lin, ang);
+  const double* Pj = P.oMi + 12 * joint_id;
+  const double pj[3] = {Pj[9], Pj[10], Pj[11]};
+  const bool sup = (lane < nv) && ((lc.subtree >> joint_id) & 1u);   // column's joint is joint_id or one of its ancestors
+  double wxp[3];
+  cross3(ang, pj, wxp);
+  if (lane < 32) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { P.Jm[6 * lane + r] = sup ? lin[r] + wxp[r] : 0.0; P.Jm[6 * lane + 3 + r] = sup ? ang[r] : 0.0; }
+  }
+  WSYNC();
+  if (lane < 36) {
+    const int a = lane / 6, b = lane - 6 * a;
+    double s = 0.0;
+#pragma unroll 2
+    for (int k = 0; k < NV; ++k) s = fma(P.Jm[6 * k + a], P.Jm[6 * k + b], s);
+    P.G[lane] = s;
+  }
+  WSYNC();
+  const double f = sqrt(det6_spd(P.G));
+  WSYNC();
+  return f;
+}
+
+__global__ void __launch_bounds__(64) wbc_posture_kernel(const PostureArgs A, const DevModel* __restrict__ models,
+                                                         const WbcConfig* __restrict__ cfgs) {
+  __shared__ PSmem P;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int mid = A.model_id ? __builtin_amdgcn_readfirstlane(A.model_id[b]) : 0;
+  const DevModel& M = models[mid];
+  const WbcConfig& cfg = cfgs[mid];
+  const LaneConst lc = load_lane_const(M, cfg, lane);
+  const int nv = M.nv, nq = M.nq;
+  const double q0 = (lane < nq) ? A.q[(size_t)b * NQ + lane] : 0.0;
+  if (lane < 32) P.q[lane] = q0;
+  WSYNC();
+  const int mode = cfg.task_joint, literal = cfg.posture_literal;
+  const double dq = 0.0002;
+  double u = 0.0;
+  if ((mode == WBC_JOINT_PREV || mode == WBC_JOINT_HYBRID) && lane < nv) u = P.q[lane < 6 ? lane : lane + 1];   // np.delete(q, 6)
+  if (mode == WBC_JOINT_MANI || mode == WBC_JOINT_HYBRID) {
+#pragma unroll 1
+    for (int i = 0; i < nv; ++i) {
+      int joint_id;
+      if (mode == WBC_JOINT_MANI) joint_id = (i < 6) ? 1 : (literal ? i + 1 - 5 : i - 4);   // :1226-1229
+      else { joint_id = i - 6; if (joint_id < cfg.arm_base_id) continue; }                 // :1250-1251
+      if (joint_id >= M.njoints) continue;
+      const int qi = literal ? i : ((i < 6) ? i : i + 1);                                   // q[i]: the VELOCITY index (:1231, :1252)
+      const double keep = P.q[qi];
+      WSYNC();
+      if (lane == 0) P.q[qi] = keep + dq;
+      WSYNC();
+      const double f1 = manipulability(P, M, lc, joint_id, lane);
+      if (lane == 0) P.q[qi] = (keep + dq) - (dq * 2);
+      WSYNC();
+      const double f2 = manipulability(P, M, lc, joint_id, lane);
+      if (lane == i) u = 0.5 * (f1 - f2) / dq;
+      if (!literal) { if (lane == 0) P.q[qi] = keep; WSYNC(); }
+    }
+  }
+  WSYNC();
+  if (A.u && lane < NV) A.u[(size_t)b * NV + lane] = (lane < nv) ? u : 0.0;
+  if (A.q_after && lane < NQ) A.q_after[(size_t)b * NQ + lane] = (lane < nq) ? P.q[lane] : 0.0;
+}
+
 static int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   (void)what;
@@ -1372,6 +1506,10 @@ int launch_qp(const QpArgs& a, int grid, void* stream) {
 int launch_integrate(const IntegrateArgs& a, int grid, void* stream) {
   hipLaunchKernelGGL(wbc_integrate_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a);
   return check_launch("integrate");
+}
+int launch_posture(const PostureArgs& a, int grid, void* stream) {
+  hipLaunchKernelGGL(wbc_posture_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs);
+  return check_launch("posture");
 }
 int tick_lds_bytes() { return (int)sizeof(Smem); }
 

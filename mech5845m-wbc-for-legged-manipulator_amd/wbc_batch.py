@@ -215,6 +215,19 @@ class WbcBatch:
                                              _prep(Ho, f, keep), _prep(go, f, keep), _stream(mem)), self.lib)
         return (x, st, it, Ho, go) if want_Hg else (x, st, it)
 
+    def posture_target(self, q, model_id=None, want_q_after=True):
+        """qpJointb's "MANI" / "HYBRID" posture target u [B,26] under the configured mode (Robot_Wrapper4.py:1220-1260),
+        and the configuration the reference's state is left at, q_after [B,27]."""
+        keep = []
+        mem = _mem_of([q, model_id])
+        B = q.shape[0]
+        u = self._alloc(q, (B, NV))
+        qa = self._alloc(q, (B, NQS)) if want_q_after else None
+        f = np.float64
+        capi.check(self.lib.wbc_posture_target(self._h, B, _prep(q, f, keep), _prep(model_id, np.int32, keep), mem,
+                                                _prep(u, f, keep), _prep(qa, f, keep), _stream(mem)), self.lib)
+        return (u, qa) if want_q_after else u
+
     def integrate(self, q, v, dt, model_id=None):
         """pin.integrate(model, q, v * dt) for every instance."""
         keep = []

@@ -20,7 +20,7 @@ JT = dict(UNIVERSE=0, FF=1, RX=2, RY=3, RZ=4, PX=5, PY=6, PZ=7)
 FR_EE0, FR_TRUNK, FR_HIP0, FR_ARM_BASE, FR_NROLES = 0, 5, 6, 11, 12
 MEM_HOST, MEM_DEVICE = 0, 1
 QP_OPTIMAL, QP_MAX_ITER, QP_INFEASIBLE, QP_NUMERICAL = 0, 1, 2, 3
-JOINT_OFF, JOINT_TIKHONOV, JOINT_PREV = 0, 1, 2
+JOINT_OFF, JOINT_TIKHONOV, JOINT_PREV, JOINT_MANI, JOINT_HYBRID, JOINT_CUSTOM = 0, 1, 2, 3, 4, 5
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -45,6 +45,7 @@ class WbcConfig(C.Structure):
         ("task_ee", C.c_int32 * NEE), ("task_trunk", C.c_int32), ("task_com", C.c_int32), ("task_joint", C.c_int32),
         ("con_com", C.c_int32), ("con_trunk", C.c_int32), ("con_ee", C.c_int32 * NEE),
         ("use_bounds", C.c_int32), ("lock_from", C.c_int32),
+        ("arm_base_id", C.c_int32), ("posture_literal", C.c_int32),
         ("damper_qidx", C.c_int32 * MAX_NV),
         ("damper_lo", C.c_double * MAX_NV), ("damper_hi", C.c_double * MAX_NV), ("damper_vmax", C.c_double * MAX_NV),
         ("damper_coef", C.c_double), ("damper_qi", C.c_double), ("damper_qs", C.c_double),
@@ -60,7 +61,8 @@ class WbcConfig(C.Structure):
 class WbcTickIn(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "q", "ee_target", "prev_ee_target", "trunk_target", "prev_trunk_target", "trunk_box_center",
-        "ee_ref_rot", "ee_prev_rot", "trunk_ref_euler", "trunk_prev_rot", "com_target", "com_target_vel", "model_id")]
+        "ee_ref_rot", "ee_prev_rot", "trunk_ref_euler", "trunk_prev_rot", "com_target", "com_target_vel", "model_id",
+        "posture_u", "q_con")]
 
 
 class WbcQpData(C.Structure):
@@ -89,6 +91,7 @@ SIGNATURES = {
     "wbc_assemble": (_i, [_vp, _i, C.POINTER(WbcTickIn), _d, _i, C.POINTER(WbcQpData), _vp]),
     "wbc_qp_solve": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "wbc_qp_solve_ls": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "wbc_posture_target": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "wbc_tick": (_i, [_vp, _i, C.POINTER(WbcTickIn), _d, _i, C.POINTER(WbcTickOut), _vp]),
     "wbc_integrate": (_i, [_vp, _i, _vp, _vp, _vp, _d, _i, _vp, _vp]),
     "wbc_batch_set_option": (_i, [_vp, C.c_char_p, _i]),

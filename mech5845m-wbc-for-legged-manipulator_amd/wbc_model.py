@@ -132,12 +132,15 @@ def damper_tables(model, compat=True):
 
 def make_config(model, Trunk=False, FR=False, FL=False, RR=False, RL=False, Grip=False, Joint=False,
                 cCoM=False, cTrunk=False, cFR=False, cFL=False, cRR=False, cRL=False, cGrip=False,
-                task_com=False, mode="default", use_bounds=True, damper_compat=True):
+                task_com=False, mode="default", use_bounds=True, damper_compat=True, posture_literal=True):
     """WbcConfig for the given task / constraint switches.
 
     mode "default" = the weights of ``RobotModel.__init__`` (Robot_Wrapper4.py:72-125);
     mode "static_reach" = ``staticReachMode()`` (Robot_Wrapper4.py:1415-1464).
-    Joint: False / True (Tikhonov) / "PREV" as in ``setTasks`` (Robot_Wrapper4.py:176-183, 1209-1217).
+    Joint: False / True (Tikhonov) / "PREV" / "MANI" / "HYBRID" as in ``setTasks`` (Robot_Wrapper4.py:176-183,
+    1209-1260), or "CUSTOM" (u given per instance). posture_literal: MANI/HYBRID to the letter of the reference
+    (index quirks, accumulating perturbations, perturbed state leaking into the rest of the tick — SURVEY.md C.4)
+    or, if False, the intended central difference.
     """
     c = capi.WbcConfig()
     for i, on in enumerate((FR, FL, RR, RL, Grip)):
@@ -147,10 +150,18 @@ def make_config(model, Trunk=False, FR=False, FL=False, RR=False, RL=False, Grip
         c.task_joint = capi.JOINT_TIKHONOV
     elif Joint == "PREV":
         c.task_joint = capi.JOINT_PREV
+    elif Joint == "MANI":
+        c.task_joint = capi.JOINT_MANI
+    elif Joint == "HYBRID":
+        c.task_joint = capi.JOINT_HYBRID
+    elif Joint == "CUSTOM":
+        c.task_joint = capi.JOINT_CUSTOM
     elif Joint is False or Joint is None:
         c.task_joint = capi.JOINT_OFF
     else:
-        raise NotImplementedError("posture mode %r is not on the device path yet (SURVEY.md §8 f3)" % (Joint,))
+        raise ValueError("unknown posture mode %r" % (Joint,))
+    c.arm_base_id = model.joint_id(model.roles["G_base"])     # getJointId(G_base), Robot_Wrapper4.py:37
+    c.posture_literal = int(bool(posture_literal))
     c.con_com, c.con_trunk = int(bool(cCoM)), int(bool(cTrunk))
     for i, on in enumerate((cFR, cFL, cRR, cRL, cGrip)):
         c.con_ee[i] = int(bool(on))
@@ -180,11 +191,12 @@ def make_config(model, Trunk=False, FR=False, FL=False, RR=False, RL=False, Grip
     return c
 
 
-def sim3_config(model, damper_compat=True, Joint="PREV"):
+def sim3_config(model, damper_compat=True, Joint="PREV", posture_literal=True):
     """The switch set of the reference's sim3.py tick (sim3.py:145-148 + staticReachMode): tasks {Grip, Joint},
-    constraints {Trunk, FR, FL, RR, RL}; posture mode PREV on the device (HYBRID is SURVEY.md §8 f3)."""
+    constraints {Trunk, FR, FL, RR, RL}. sim3.py itself sets Joint="HYBRID"; "PREV" is the benchmark default
+    (BASELINE configs[2] / SURVEY.md §8d C3)."""
     return make_config(model, Grip=True, Joint=Joint, cTrunk=True, cFR=True, cFL=True, cRR=True, cRL=True,
-                       mode="static_reach", damper_compat=damper_compat)
+                       mode="static_reach", damper_compat=damper_compat, posture_literal=posture_literal)
 
 
 def equality_only_config(model):

@@ -154,6 +154,22 @@ def qp_solve(H, g, C_=None, lb=None, ub=None, Clb=None, Cub=None, nthreads=1):
     return x, st, it
 
 
+def posture_target(models, cfgs, q, model_id=None, nthreads=1):
+    """qpJointb MANI / HYBRID (Robot_Wrapper4.py:1220-1260) under cfgs[model].task_joint / posture_literal:
+    returns (u [B,26], q_after [B,27])."""
+    q = _f64(q).reshape(-1, NQS)
+    B = q.shape[0]
+    mid = None if model_id is None else np.ascontiguousarray(model_id, dtype=np.int32)
+    u, qa = np.zeros((B, NV)), np.zeros((B, NQS))
+    modes = {int(c.task_joint) for c in cfgs}
+    lits = {int(c.posture_literal) for c in cfgs}
+    assert len(modes) == 1 and len(lits) == 1, "oracle.posture_target: one mode per call"
+    arm = np.array([c.arm_base_id for c in cfgs], dtype=np.int32)
+    lib().orc_posture_batch(_models(models), C.c_int(B), _p(q), _p(mid), C.c_int(modes.pop()), _p(arm), C.c_int(lits.pop()),
+                            _p(u), _p(qa), C.c_int(nthreads))
+    return u, qa
+
+
 def integrate(models, q, v, dt, model_id=None):
     q = _f64(q).reshape(-1, NQS)
     v = _f64(v).reshape(-1, NV)

@@ -54,10 +54,14 @@ void orc_quat_to_R(const double* q /*xyzw*/, double* R) {
 }
 
 /* scipy Rotation.from_matrix(M).as_euler('xyz') for a proper rotation: extrinsic x-y-z,
- * M = Rz(c) Ry(b) Rx(a) -> (a, b, c).  Used at Robot_Wrapper4.py:714-715, 363-367, 382-383. */
+ * M = Rz(c) Ry(b) Rx(a) -> (a, b, c).  Used at Robot_Wrapper4.py:714-715, 363-367, 382-383.
+ * The pitch is written atan2(-M20, |(M21, M22)|) (= -asin(M20) on a proper rotation). On a matrix that is NOT
+ * orthonormal — only the "MANI" posture mode produces one, by perturbing the free-flyer quaternion —
+ * scipy first projects M to a rotation, by a method that changed between scipy releases (unit quaternion, later SVD)
+ * and that the reference does not pin: that corner is "parity unpinned"; oracle and device share this formula. */
 void orc_R_to_euler_xyz(const double* M, double* e) {
   e[0] = atan2(M[7], M[8]);
-  e[1] = -asin(M[6]);
+  e[1] = atan2(-M[6], sqrt(M[7] * M[7] + M[8] * M[8]));
   e[2] = atan2(M[3], M[0]);
 }
 /* scipy Rotation.from_euler('xyz', e).as_matrix() (Robot_Wrapper4.py:968-969, 1101-1102). */
@@ -334,10 +338,24 @@ static const double* opt_row(const double* base, int b, int k) { return base ? b
 /* One instance of the task stack and constraints. Outputs (any may be NULL):
  * A [m][NV], bv [m], C [p][NV], Clb/Cub [p], lb/ub [NV], H [NV][NV], g [NV].
  * Columns >= model nv are padded: A = 0, H_dd = 1, bounds 0. */
+void orc_posture_target(const WbcModelBlob* m, const double* q_in, int mode, int arm_base_id, int literal,
+                        double* u, double* q_after);
+/* q_con_used (27, optional): the configuration the constraints, bounds and the integration of this tick see. */
 void orc_assemble_one(const WbcModelBlob* m, const WbcConfig* c, const WbcTickIn* in, int b, double dt,
                       double* A, double* bv, double* C, double* Clb, double* Cub, double* lb, double* ub,
-                      double* H, double* g) {
+                      double* H, double* g, double* q_con_used) {
   const double* q = in->q + (size_t)b * NQS;
+  const double* qc = in->q_con ? in->q_con + (size_t)b * NQS : q;
+  double upost[NV], qleft[NQS];
+  memset(upost, 0, sizeof upost);
+  if (c->task_joint >= WBC_JOINT_MANI) {
+    if (in->posture_u) memcpy(upost, in->posture_u + (size_t)b * NV, sizeof upost);
+    else if (c->task_joint != WBC_JOINT_CUSTOM) {   /* qpJointb MANI / HYBRID (Robot_Wrapper4.py:1220-1260) */
+      orc_posture_target(m, q, c->task_joint, c->arm_base_id, c->posture_literal, upost, qleft);
+      if (c->posture_literal && !in->q_con) qc = qleft;   /* the perturbed state leaks into the rest of the tick (C.4) */
+    }
+  }
+  if (q_con_used) memcpy(q_con_used, qc, sizeof(double) * NQS);
   double oMi[WBC_MAX_JOINTS * 12], J[6 * NV], Jf[6 * NV];
   const int mrows = orc_task_rows(c), prows = orc_constraint_rows(c), nv = m->nv;
   double* At = (double*)calloc((size_t)(mrows ? mrows : 1) * NV, sizeof(double));
@@ -427,6 +445,7 @@ void orc_assemble_one(const WbcModelBlob* m, const WbcConfig* c, const WbcTickIn
       At[(row + k) * NV + k] = d;
       double u = 0.0;                                               /* True: Tikhonov :1212-1213 */
       if (c->task_joint == WBC_JOINT_PREV) u = (k < 6) ? q[k] : q[k + 1]; /* np.delete(q, 6) :1216-1217 */
+      if (c->task_joint >= WBC_JOINT_MANI) u = upost[k];                  /* :1220-1260 */
       bt[row + k] = (1.0 / nv) * u * c->joint_w;                    /* :1262-1266 */
     }
     row += NV;
@@ -452,6 +471,13 @@ void orc_assemble_one(const WbcModelBlob* m, const WbcConfig* c, const WbcTickIn
   free(At); free(bt);
 
   /* --- constraints in order CoM, Trunk, FR, FL, RR, RL, Grip: findConstraints (Robot_Wrapper4.py:764-836) */
+  if (qc != q) {   /* robot_data now belongs to the configuration qpJointb left behind */
+    q = qc;
+    orc_fk(m, q, oMi);
+    orc_joint_jacobians(m, oMi, J);
+    orc_frame_placement(m, oMi, WBC_FR_TRUNK, Mtrunk);
+    if (c->con_com) orc_com(m, oMi, J, com, Jcom);
+  }
   int prow = 0;
   double Cl[WBC_MAX_P * NV], cl[WBC_MAX_P], cu[WBC_MAX_P];
   memset(Cl, 0, sizeof Cl);
@@ -718,6 +744,77 @@ double orc_qp_objective(int n, const double* H, const double* g, const double* x
   return f;
 }
 
+
+/* ---------------------------------------------------------------- manipulability-gradient posture target
+ * qpJointb "MANI" (Robot_Wrapper4.py:1220-1242) and "HYBRID" (:1245-1260), restated LITERALLY:
+ *  - the nq-sized configuration is perturbed at index i = the VELOCITY index of the DoF (so i = 3..6 touch the
+ *    quaternion, and joint DoF i perturbs the angle of the joint before it);
+ *  - the manipulability is sqrt(det(J J')) of pin.getJointJacobian(joint_id, LOCAL_WORLD_ALIGNED) with
+ *    joint_id = 1 (i < 6) / i - 4 in MANI and joint_id = i - 6 in HYBRID (evaluated only when joint_id >= arm_base_id);
+ *  - the perturbations accumulate: after each DoF q[i] is left at q[i] - deltaq;
+ *  - updateState aliases current_joint_config to the perturbed array, so the configuration the rest of the tick sees
+ *    (findConstraints, velDamperJointConstraints, integrate) is q_after.
+ * mode 3 = MANI, 4 = HYBRID; literal = 0 gives the intended central difference (own q index, no accumulation, q restored).
+ * u (nv) = the posture target before the (1/nv) w scaling; q_after (27) = configuration left behind. */
+static double det6(double M[6][6]) { /* LU with partial pivoting, as numpy.linalg.det (LAPACK getrf) */
+  double det = 1.0;
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 6; ++r) if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+    if (M[piv][c] == 0.0) return 0.0;
+    if (piv != c) { for (int k = 0; k < 6; ++k) { double t = M[c][k]; M[c][k] = M[piv][k]; M[piv][k] = t; } det = -det; }
+    det *= M[c][c];
+    for (int r = c + 1; r < 6; ++r) {
+      const double f = M[r][c] / M[c][c];
+      for (int k = c + 1; k < 6; ++k) M[r][k] -= f * M[c][k];
+    }
+  }
+  return det;
+}
+static double manipulability(const WbcModelBlob* m, const double* q, int joint_id) {
+  double oMi[WBC_MAX_JOINTS * 12], J[6 * NV], Jj[6 * NV], G[6][6];
+  orc_fk(m, q, oMi);
+  orc_joint_jacobians(m, oMi, J);
+  orc_frame_jacobian(m, oMi, J, -1, joint_id, 2, Jj);
+  for (int a = 0; a < 6; ++a)
+    for (int b = 0; b < 6; ++b) { double s = 0; for (int k = 0; k < m->nv; ++k) s += Jj[a * NV + k] * Jj[b * NV + k]; G[a][b] = s; }
+  return sqrt(det6(G));
+}
+void orc_posture_target(const WbcModelBlob* m, const double* q_in, int mode, int arm_base_id, int literal,
+                        double* u, double* q_after) {
+  const double dq = 0.0002;
+  double q[NQS];
+  memcpy(q, q_in, sizeof q);
+  const int nv = m->nv;
+  for (int k = 0; k < nv; ++k) u[k] = (mode == 4) ? ((k < 6) ? q_in[k] : q_in[k + 1]) : 0.0;   /* HYBRID starts from "PREV" */
+  for (int i = 0; i < nv; ++i) {
+    int joint_id;
+    if (mode == 3) joint_id = (i < 6) ? 1 : i + 1 - 5;
+    else { joint_id = i - 6; if (joint_id < arm_base_id) continue; }
+    const int qi = literal ? i : ((i < 6) ? i : i + 1);
+    if (!literal && mode == 3 && i >= 6) joint_id = i - 4;
+    q[qi] += dq;
+    const double f1 = manipulability(m, q, joint_id);
+    q[qi] -= 2 * dq;
+    const double f2 = manipulability(m, q, joint_id);
+    u[i] = 0.5 * (f1 - f2) / dq;
+    if (!literal) q[qi] = q_in[qi];
+  }
+  if (q_after) memcpy(q_after, q, sizeof q);
+}
+void orc_posture_batch(const WbcModelBlob* const* models, int B, const double* q, const int32_t* model_id, int mode,
+                       const int32_t* arm_base_id, int literal, double* u, double* q_after, int nthreads) {
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (int b = 0; b < B; ++b) {
+    const int mi = model_id ? model_id[b] : 0;
+    double ub[NV], qa[NQS];
+    memset(ub, 0, sizeof ub);
+    orc_posture_target(models[mi], q + (size_t)b * NQS, mode, arm_base_id[mi], literal, ub, qa);
+    memcpy(u + (size_t)b * NV, ub, sizeof ub);
+    if (q_after) memcpy(q_after + (size_t)b * NQS, qa, sizeof qa);
+  }
+}
+
 /* ---------------------------------------------------------------- batched drivers (OpenMP) */
 
 static const WbcModelBlob* pick(const WbcModelBlob* const* models, const WbcTickIn* in, int b) {
@@ -735,7 +832,8 @@ void orc_tick_batch(const WbcModelBlob* const* models, const WbcConfig* cfgs, in
     const int p = orc_constraint_rows(c);
     double C[WBC_MAX_P * NV], Clb[WBC_MAX_P], Cub[WBC_MAX_P], lb[NV], ub[NV], H[NV * NV], g[NV], x[NV];
     int it = 0;
-    orc_assemble_one(m, c, in, b, dt, 0, 0, C, Clb, Cub, lb, ub, H, g);
+    double qcon[NQS];
+    orc_assemble_one(m, c, in, b, dt, 0, 0, C, Clb, Cub, lb, ub, H, g, qcon);
     const int st = orc_qp_solve(NV, p, H, g, C, lb, ub, Clb, Cub, x, &it);
     if (out->qdot) memcpy(out->qdot + (size_t)b * NV, x, sizeof x);
     if (out->status) out->status[b] = st;
@@ -744,7 +842,7 @@ void orc_tick_batch(const WbcModelBlob* const* models, const WbcConfig* cfgs, in
       double v[NV], qn[NQS];
       for (int k = 0; k < NV; ++k) v[k] = x[k] * dt;
       memset(qn, 0, sizeof qn);
-      orc_integrate(m, in->q + (size_t)b * NQS, v, qn);
+      orc_integrate(m, qcon, v, qn);   /* jointVelocitiestoConfig integrates current_joint_config (:441) */
       memcpy(out->q_next + (size_t)b * NQS, qn, sizeof qn);
     }
   }
@@ -761,7 +859,7 @@ void orc_assemble_batch(const WbcModelBlob* const* models, const WbcConfig* cfgs
                      o->C ? o->C + (size_t)b * p * NV : 0, o->Clb ? o->Clb + (size_t)b * p : 0,
                      o->Cub ? o->Cub + (size_t)b * p : 0, o->lb ? o->lb + (size_t)b * NV : 0,
                      o->ub ? o->ub + (size_t)b * NV : 0, o->H ? o->H + (size_t)b * NV * NV : 0,
-                     o->g ? o->g + (size_t)b * NV : 0);
+                     o->g ? o->g + (size_t)b * NV : 0, 0);
   }
 }
 

@@ -36,6 +36,14 @@ def config(name, model):
         return wbc_model.make_config(model, Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint="PREV",
                                      task_com=True, cCoM=True, cTrunk=True, cFR=True, cFL=True, cRR=True, cRL=True,
                                      mode="static_reach")
+    if name in ("c3_hybrid", "c3_hybrid_clean", "c3_mani"):   # sim3.py:145 sets Joint="HYBRID"; literal = to the letter (C.4)
+        return wbc_model.sim3_config(model, Joint="MANI" if name == "c3_mani" else "HYBRID",
+                                     posture_literal=not name.endswith("clean"))
+    if name == "hybrid_grip_com":  # HYBRID + constraints that DO depend on the arm: the leaked perturbed state shows in C
+        return wbc_model.make_config(model, Grip=True, Joint="HYBRID", cCoM=True, cTrunk=True, cFR=True, cFL=True, cRR=True,
+                                     cRL=True, cGrip=True, mode="static_reach")
+    if name == "c3_custom":
+        return wbc_model.sim3_config(model, Joint="CUSTOM")
     raise KeyError(name)
 
 

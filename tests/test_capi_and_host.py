@@ -92,8 +92,11 @@ def test_configs_follow_the_reference_presets():
     assert d.joint_w == 0.05 and d.ee_gain[4][0] == 0.5 and d.task_joint == capi.JOINT_TIKHONOV
     px = wbc_model.load_model("a1_px100_pin_ver")
     assert wbc_model.sim3_config(px).lock_from == 22
-    with pytest.raises(NotImplementedError):
-        wbc_model.make_config(m, Grip=True, Joint="HYBRID")
+    h = wbc_model.make_config(m, Grip=True, Joint="HYBRID")   # sim3.py:145's own posture mode
+    assert h.task_joint == capi.JOINT_HYBRID and h.arm_base_id == 14 and h.posture_literal == 1   # getJointId("waist"), :37
+    assert wbc_model.make_config(m, Joint="MANI", posture_literal=False).posture_literal == 0
+    with pytest.raises(ValueError):
+        wbc_model.make_config(m, Grip=True, Joint="SOMETHING")
     qidx, lo, hi, vm, _ = wbc_model.damper_tables(m, compat=True)
     assert list(qidx[:8]) == list(range(8)) and vm[6] == 5.0 and lo[6] == m.q_lo[7]     # quirk C.3
     qidx, lo, hi, vm, _ = wbc_model.damper_tables(m, compat=False)

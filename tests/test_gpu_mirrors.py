@@ -145,6 +145,50 @@ def test_robot_model_tick_matches_oracle(robot):
     assert np.abs(C - oracle.frame_jacobian(wx, rm.current_joint_config, frame=1, rf=0)[:3]).max() < 1e-12 and not l.any() and not u.any()
     C, l, u = rm.CoMConstraint()
     assert np.abs(C - oracle.fk([wx], rm.current_joint_config[None])["Jcom"][0, :2]).max() < 1e-12
-    with pytest.raises(NotImplementedError):
-        rm.setTasks(Grip=True, Joint="HYBRID")
-        rm.qpA()
+
+
+def test_robot_model_hybrid_posture_like_sim3(robot):
+    """sim3.py:145 runs the controller with Joint="HYBRID": the posture target and the perturbed state qpJointb leaves
+    behind come from the device; the oracle replays the same tick literally."""
+    rm = robot
+    rm.setTasks(Grip=True, Joint="HYBRID")
+    rm.setConstraints(Trunk=True, FR=True, FL=True, RR=True, RL=True)
+    rm.staticReachMode()
+    imu = np.array([0.0, 0.0, 0.0, 1.0])
+    rm.initialiseWBC(imu)
+    wx = rm._model
+    EE_target = [rm.prev_EE_pos[i].reshape(3, 1).copy() for i in range(5)]
+    trunk_target = rm.robot_data.oMf[rm.trunk_frame_index].translation.reshape(3, 1).copy()
+    for tick in range(2):
+        EE_target[4] = EE_target[4] + np.array([[0.0004], [0.0], [0.0003]])
+        cfg = rm._config()
+        assert cfg.task_joint == capi.JOINT_HYBRID and cfg.posture_literal == 1
+        d = rm._tick_inputs(EE_target, trunk_target)
+        ref = oracle.tick([wx], [cfg], d, rm.step_time, 1)
+        legs_grip = rm.runWBC(imu, target_cartesian_pos_EE=EE_target, target_cartesian_pos_trunk=trunk_target)
+        assert rm.solver_status == 0 and ref["status"][0] == 0
+        assert np.abs(rm.q_vel - ref["qdot"][0]).max() < 1e-5
+        assert np.abs(np.concatenate(legs_grip) - ref["q_next"][0, 7:]).max() < 1e-7
+        # the leak: the commanded arm joints carry the -2e-4 rad left by the finite differences, every tick
+        plain = oracle.integrate([wx], d["q"], ref["qdot"], rm.step_time)[0, 7:]
+        assert np.allclose((np.concatenate(legs_grip) - plain)[13:19], -0.0002, rtol=0, atol=1e-7)
+    # the accessor sequence of runWBC (:1348-1361): qpb perturbs the state, findConstraints / dampers then read it
+    EE_target[4] = EE_target[4] + np.array([[0.0004], [0.0], [0.0003]])
+    cfg = rm._config()
+    d = rm._tick_inputs(EE_target, trunk_target)
+    a = oracle.assemble([wx], [cfg], d, rm.step_time, 1)
+    q_before = rm.current_joint_config.copy()
+    A = rm.qpA()
+    b = rm.qpb(EE_target, trunk_target)
+    Ct, Clb, Cub = rm.findConstraints()
+    lb, ub = rm.velDamperJointConstraints()
+    assert np.abs(A - a["A"][0]).max() < 1e-12 and np.abs(b.ravel() - a["b"][0]).max() < 1e-9
+    assert np.allclose((rm.current_joint_config - q_before)[20:26], -0.0002, rtol=0, atol=1e-12)
+    assert (rm.current_joint_config[:20] == q_before[:20]).all()
+    assert np.abs(Ct.T - a["C"][0]).max() < 1e-12 and np.abs(Clb - a["Clb"][0]).max() < 1e-9
+    assert np.abs(lb - a["lb"][0]).max() < 1e-12 and np.abs(ub - a["ub"][0]).max() < 1e-12
+    rm.posture_literal = False
+    q_before = rm.current_joint_config.copy()
+    rm.qpb(EE_target, trunk_target)
+    assert (rm.current_joint_config == q_before).all()
+    rm.posture_literal = True

@@ -152,6 +152,83 @@ def test_tick_parity(wx200, cfg_name, B, with_rot):
     bt.close()
 
 
+@pytest.mark.parametrize("mode,literal", [("HYBRID", True), ("HYBRID", False), ("MANI", True), ("MANI", False)])
+def test_posture_target_parity(wx200, px100, mode, literal):
+    """qpJointb MANI / HYBRID (Robot_Wrapper4.py:1220-1260): u and the configuration left behind, both morphologies."""
+    import wbc_workload
+    B = 256
+    models = [wx200, px100]
+    cfgs = [wbc_model.sim3_config(m, Joint=mode, posture_literal=literal) for m in models]
+    rng = np.random.default_rng(17)
+    mid = (np.arange(B) % 2).astype(np.int32)
+    qs = [wbc_workload.sample_q(m, B, rng) for m in models]
+    q = np.where(mid[:, None] == 0, qs[0], qs[1])
+    ur, qar = oracle.posture_target(models, cfgs, q, mid, nthreads=8)
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    u, qa = bt.posture_target(q, mid)
+    # f = sqrt(det(J J')) is O(1..10) and is differenced over 2e-4: rounding in f (1e-16 relative) shows as ~1e-11 in u
+    assert np.abs(u - ur).max() < 1e-9
+    assert (qa == qar).all()                      # same IEEE operations on q: bit-equal
+    assert np.abs(ur).max() > 1e-3
+    if literal:
+        assert np.abs(qa - q).max() == pytest.approx(2e-4, rel=1e-6)
+    else:
+        assert (qa == q).all()
+    bt.close()
+
+
+@pytest.mark.parametrize("cfg_name,B", [("c3_hybrid", 1024), ("c3_hybrid_clean", 512), ("c3_mani", 512), ("hybrid_grip_com", 512)])
+def test_tick_parity_posture_modes(wx200, cfg_name, B):
+    """A whole tick under sim3.py's own posture mode ("HYBRID", sim3.py:145) and "MANI": wbc_tick runs the posture
+    kernel itself, and in literal mode the rest of the tick sees the perturbed configuration."""
+    cfg = common.config(cfg_name, wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=23)
+    ref = oracle.tick([wx200], [cfg], d, DT, B, nthreads=8)
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    got = bt.tick(d, DT, want_q_next=True)
+    assert (got["status"] == ref["status"]).all()
+    ok = ref["status"] == 0
+    assert ok.mean() > 0.9
+    err = np.abs(got["qdot"] - ref["qdot"])[ok].max()
+    print("%s: qdot max-abs err %.3e" % (cfg_name, err))
+    assert err < QDOT_TOL
+    assert np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    a, ar = bt.assemble(d, DT), oracle.assemble([wx200], [cfg], d, DT, B)
+    for k in ("A", "b", "H", "g", "C", "Clb", "Cub", "lb", "ub"):
+        assert relerr(a[k], ar[k]) < 1e-9, (k, relerr(a[k], ar[k]))
+    if cfg.posture_literal:
+        # the leak is visible: integrating from q instead of the perturbed state would be off by the 2e-4 perturbation
+        plain = bt.integrate(d["q"], got["qdot"], DT)
+        assert np.abs(plain - got["q_next"])[ok].max() > 1e-4
+    bt.close()
+
+
+def test_tick_custom_posture_and_q_con(wx200):
+    """WBC_JOINT_CUSTOM: u supplied per instance; q_con: a second configuration for constraints / bounds / integrate."""
+    B = 256
+    cfg = common.config("c3_custom", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=29)
+    rng = np.random.default_rng(4)
+    d["posture_u"] = rng.normal(size=(B, 26))
+    d["q_con"] = d["q"].copy()
+    d["q_con"][:, 7:] += rng.normal(0, 1e-3, (B, 20))
+    ref = oracle.tick([wx200], [cfg], d, DT, B, nthreads=8)
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    got = bt.tick(d, DT, want_q_next=True)
+    assert (got["status"] == ref["status"]).all()
+    ok = ref["status"] == 0
+    assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+    assert np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    del d["posture_u"]
+    with pytest.raises(capi.WbcError):
+        bt.tick(d, DT)
+    bt.close()
+
+
 def test_tick_mixed_morphology(wx200, px100):
     """BASELINE config 5: wx200 (nv 26) and px100 (nv 25, padded DoF) interleaved lane by lane."""
     B = 1024

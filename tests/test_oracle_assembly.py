@@ -170,3 +170,65 @@ def test_oracle_reproduces_golden_fixtures(name):
         a = oracle.assemble(models, cfgs, d, DT, B)
         for k in ("H", "g", "C", "lb", "ub"):
             assert np.abs(a[k] - z["asm_" + k]).max() < 1e-12 * max(1, np.abs(z["asm_" + k]).max())
+
+
+@pytest.mark.parametrize("mode", ["MANI", "HYBRID"])
+def test_posture_target_restated_in_numpy(wx, mode):
+    """qpJointb "MANI" (Robot_Wrapper4.py:1220-1242) and "HYBRID" (:1245-1260) replayed line by line in Python on top of
+    the oracle's getJointJacobian, numpy's det included — the C restatement must give the same u and leave the same q."""
+    import wbc_workload
+    rng = np.random.default_rng(8)
+    cfg = wbc_model.sim3_config(wx, Joint=mode)
+    nv, arm_base_id = wx.nv, wx.joint_id("waist")
+    assert cfg.arm_base_id == arm_base_id == 14
+    for q0 in wbc_workload.sample_q(wx, 3, rng):
+        def f(qq, joint_id):
+            J = oracle.frame_jacobian(wx, qq, joint=joint_id, rf=2)[:, :nv]
+            return np.sqrt(np.linalg.det(J @ J.T))
+        q = q0.copy()
+        deltaq = 0.0002
+        if mode == "MANI":
+            u = []
+            for i in range(nv):
+                joint_id = 1 if i < 6 else i + 1 - 5
+                q[i] = q[i] + deltaq
+                f1 = f(q, joint_id)
+                q[i] = q[i] - (deltaq * 2)
+                f2 = f(q, joint_id)
+                u.append(0.5 * (f1 - f2) / deltaq)
+            u = np.array(u)
+        else:
+            u = np.delete(q0, 6)
+            for i in range(len(u)):
+                joint_id = i - 6
+                if joint_id >= arm_base_id:
+                    q[i] = q[i] + deltaq
+                    f1 = f(q, joint_id)
+                    q[i] = q[i] - (deltaq * 2)
+                    f2 = f(q, joint_id)
+                    u[i] = 0.5 * (f1 - f2) / deltaq
+        uo, qa = oracle.posture_target([wx], [cfg], q0[None])
+        assert np.abs(uo[0] - u).max() < 1e-9
+        assert (qa[0] == q).all()
+        # the posture rows of b carry (1/nv) u w, and the rest of the tick runs at the perturbed q (SURVEY.md C.4)
+        d = common.tick_inputs(wx, cfg, 1, seed=3)
+        d["q"] = q0[None].copy()
+        a = oracle.assemble([wx], [cfg], d, DT, 1)
+        assert np.abs(a["b"][0, 6:] - (1.0 / nv) * u * cfg.joint_w).max() < 1e-12
+        cfg_prev = wbc_model.sim3_config(wx, Joint="PREV")
+        d2 = dict(d)
+        d2["q"] = q[None].copy()
+        a2 = oracle.assemble([wx], [cfg_prev], d2, DT, 1)
+        for k in ("C", "Clb", "Cub", "lb", "ub"):
+            assert (a[k] == a2[k]).all(), k
+
+
+def test_hybrid_posture_is_prev_plus_zero_gradient(wx):
+    """What HYBRID evaluates to with the reference's indices: DoF 20..25 differentiate joints 14..19 with respect to
+    the angle of the joint AFTER them, on which a joint's own Jacobian cannot depend -> exactly 0; the rest is PREV."""
+    import wbc_workload
+    q = wbc_workload.sample_q(wx, 16, np.random.default_rng(1))
+    u, qa = oracle.posture_target([wx], [wbc_model.sim3_config(wx, Joint="HYBRID")], q)
+    assert (u[:, :20] == np.delete(q, 6, axis=1)[:, :20]).all()
+    assert np.abs(u[:, 20:]).max() < 1e-9
+    assert np.allclose((qa - q)[:, 20:26], -0.0002, rtol=1e-9, atol=0) and (qa[:, :20] == q[:, :20]).all()
