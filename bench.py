@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances for the CPU baseline (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--jtj-mfma", type=int, default=0)
+    ap.add_argument("--rollout-ticks", type=int, default=10, help="closed-loop ticks of the extra wbc_rollout measurement (0 = skip)")
     ap.add_argument("--posture", default="PREV", choices=["PREV", "HYBRID", "MANI"],
                     help="posture mode of the tick (default PREV = the BASELINE workload; HYBRID is what sim3.py:145 sets)")
     args = ap.parse_args()
@@ -124,6 +125,21 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # closed loop: K chained ticks on the device = tick + updateState/trunkWorldPos + reference-state advance
+    closed = None
+    if args.rollout_ticks > 0:
+        step_t = torch.zeros((B, 5, 3), dtype=torch.float64, device=dev)
+        step_t[:, 4, 0] = 1e-4
+        bt.rollout(dev_in, DT, 2, ee_target_step=step_t, want_trace=False)
+        barrier()
+        t1 = time.perf_counter()
+        ro = bt.rollout(dev_in, DT, args.rollout_ticks, ee_target_step=step_t, want_trace=False)
+        barrier()
+        t_roll = time.perf_counter() - t1
+        closed = {"value": float(B) * args.rollout_ticks / t_roll, "unit": "closed-loop ticks/s per GPU", "ticks": args.rollout_ticks,
+                  "ms_per_tick": 1e3 * t_roll / args.rollout_ticks, "optimal_frac": float((ro["status"] == 0).double().mean().item()),
+                  "what": "wbc_rollout: wbc_tick + wbc_update_state (FK + trunkWorldPos) + prev-target state advance, targets moving 0.1 mm/tick"}
+
     status = dev_out["status"].cpu().numpy()
     iters = dev_out["iters"].cpu().numpy()
     qdot = dev_out["qdot"].cpu().numpy()
@@ -149,6 +165,8 @@ def main():
             "solver": {"optimal_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
                        "iters_p95": float(np.percentile(iters, 95)), "iters_max": int(iters.max())},
         }
+        if closed is not None:
+            line["closed_loop"] = closed
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle   # checker / yardstick only

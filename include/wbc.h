@@ -235,6 +235,35 @@ int wbc_tick(WbcBatch* b, int B, const WbcTickIn* in, double dt, int mem, const 
 int wbc_integrate(WbcBatch* b, int B, const double* q, const double* v, const int32_t* model_id, double dt, int mem,
                   double* q_next, void* stream);
 
+/* replaces the tail of runWBC, updateState(joint_config, base_config, running=True) (Robot_Wrapper4.py:1397-1399, 387-428)
+ * with the foot-anchored base estimator trunkWorldPos (:1297-1327):
+ *   q_new = [base xyz re-estimated from the stance-foot targets, imu quaternion, joints of q_next].
+ * q_cur: current_joint_config (its base xyz is read); q_next: wbc_tick's q_next; imu [B][4] (x, y, z, w) = base_config,
+ * NULL => the quaternion of q_next; foot_targets [B][5][3] = the tick's ee_target (FR, FL, RR, RL are read).
+ * q_new may alias q_cur. */
+int wbc_update_state(WbcBatch* b, int B, const double* q_cur, const double* q_next, const double* imu,
+                     const double* foot_targets, const int32_t* model_id, int mem, double* q_new, void* stream);
+
+/* K closed-loop ticks without leaving the device: per tick wbc_tick -> wbc_update_state -> the
+ * reference-state side effects of qpb() (prev_EE_pos / prev_EE_CoM_rot, calcTargetVelEE3 :1151-1152; prev_trunk_ref /
+ * old_ref_trunk_rot_matrix, calcTargetVelTrunk2 :995-996) -> the targets advance by a per-tick step (one linear segment
+ * of sim3.py's milestone trajectory, sim3.py:207-228). `in0` is the state and the targets of the first tick (never
+ * written); all outputs optional. */
+typedef struct WbcRollout {
+  int32_t ticks;                    /* K >= 1                                                              */
+  int32_t pad_;
+  const double* ee_target_step;     /* [B][5][3] added to ee_target after every tick; NULL => constant     */
+  const double* trunk_target_step;  /* [B][3]; NULL => constant                                            */
+  const double* imu;                /* [B][4] base quaternion fed back every tick; NULL => the integrated one */
+  double* q_final;                  /* [B][27] current_joint_config after K ticks                          */
+  double* qdot_last;                /* [B][26] xOpt of the last tick                                       */
+  double* ee_target_final;          /* [B][5][3] targets the NEXT tick would get                           */
+  double* grip_trace;               /* [K][B][3] gripper_bar position reached after every tick (sim3.py:340-348's log) */
+  int32_t* status_max;              /* [B] worst WBC_QP_* status over the K ticks                          */
+  int32_t* iters_sum;               /* [B] working-set changes over the K ticks                            */
+} WbcRollout;
+int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRollout* r, int mem, void* stream);
+
 /* knobs: 0 = default. "jtj_mfma": use v_mfma_f64_16x16x4_f64 for the J'J contraction in wbc_tick/wbc_assemble. */
 int wbc_batch_set_option(WbcBatch* b, const char* name, int value);
 

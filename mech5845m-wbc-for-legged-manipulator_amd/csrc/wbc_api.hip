@@ -41,6 +41,7 @@ struct WbcBatch {
   int jtj_mfma;
   unsigned long long* d_prof;
   double *d_pu, *d_pq;   // qpJointb MANI/HYBRID results: u [max_batch][26], q_after [max_batch][27] (lazy)
+  void* d_roll;          // wbc_rollout's mutable controller state for max_batch instances (lazy)
 };
 
 // ---------------------------------------------------------------------------------------------- model
@@ -157,6 +158,7 @@ extern "C" void wbc_batch_destroy(WbcBatch* b) {
   if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->d_pu) (void)hipFree(b->d_pu);
   if (b->d_pq) (void)hipFree(b->d_pq);
+  if (b->d_roll) (void)hipFree(b->d_roll);
   delete b;
 }
 
@@ -413,6 +415,99 @@ extern "C" int wbc_posture_target(WbcBatch* b, int B, const double* q, const int
   st.out(&u, (size_t)B * WBC_V_STRIDE); st.out(&q_after, (size_t)B * WBC_Q_STRIDE);
   if ((rc = st.stage())) return rc;
   if ((rc = run_posture(b, B, q, model_id, u, q_after, stream))) return rc;
+  return st.finish();
+}
+
+extern "C" int wbc_update_state(WbcBatch* b, int B, const double* q_cur, const double* q_next, const double* imu,
+                                const double* foot_targets, const int32_t* model_id, int mem, double* q_new, void* stream) {
+  int rc = check_batch(b, B, "wbc_update_state", true);
+  if (rc) return rc;
+  if (!q_cur || !q_next || !foot_targets || !q_new) return fail(WBC_E_ARG, "wbc_update_state: q_cur, q_next, foot_targets and q_new are required");
+  if (b->n_models > 1 && !model_id) return fail(WBC_E_ARG, "wbc_update_state: model_id is required with %d models", b->n_models);
+  HIP_TRY(hipSetDevice(b->device_id));
+  UpdateArgs a;
+  memset(&a, 0, sizeof a);
+  a.models = b->d_models; a.cfgs = b->d_cfgs; a.B = B;
+  a.q_cur = q_cur; a.q_next = q_next; a.imu = imu; a.foot_targets = foot_targets; a.model_id = model_id; a.q_new = q_new;
+  Stager st{b, mem, (hipStream_t)stream, {}};
+  const size_t n = (size_t)B;
+  const bool alias = (const double*)q_new == q_cur;
+  st.in(&a.q_cur, n * WBC_Q_STRIDE); st.in(&a.q_next, n * WBC_Q_STRIDE); st.in(&a.imu, n * 4); st.in(&a.foot_targets, n * 15);
+  st.in(&a.model_id, n);
+  st.out(&a.q_new, n * WBC_Q_STRIDE);
+  if ((rc = st.stage())) return rc;
+  (void)alias;
+  if (int e = launch_update(a, B, stream)) return fail(WBC_E_HIP, "update kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  return st.finish();
+}
+
+// K closed-loop ticks: the mutable controller state lives in the handle's rollout workspace; in0 is only read.
+extern "C" int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRollout* r, int mem, void* stream) {
+  int rc = check_batch(b, B, "wbc_rollout", true);
+  if (rc) return rc;
+  if (!r || r->ticks < 1 || !(dt > 0)) return fail(WBC_E_ARG, "wbc_rollout: ticks >= 1 and dt > 0 required");
+  if ((rc = validate_tick_in(b, in0, "wbc_rollout"))) return rc;
+  if (!in0->ee_target || !in0->prev_ee_target) return fail(WBC_E_ARG, "wbc_rollout: ee_target / prev_ee_target are required (the base estimator reads the foot targets)");
+  HIP_TRY(hipSetDevice(b->device_id));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)B, NB = (size_t)b->max_batch;
+  // workspace layout (doubles per instance), then two int32 per instance
+  enum { O_Q = 0, O_QN = 27, O_QD = 54, O_EET = 80, O_EEP = 95, O_TT = 110, O_TP = 113, O_EPR = 116, O_TPR = 161, O_END = 170 };
+  if (!b->d_roll) HIP_TRY(hipMalloc(&b->d_roll, NB * (O_END * sizeof(double) + 2 * sizeof(int32_t))));
+  double* W = (double*)b->d_roll;
+  auto blk = [&](int off) { return W + NB * (size_t)off; };
+  int32_t* w_status = (int32_t*)(W + NB * O_END);
+  int32_t* w_iters = w_status + NB;
+
+  KernelArgs a;
+  fill_args(a, b, B, dt);
+  a.in = *in0;
+  WbcRollout ro = *r;
+  Stager st{b, mem, s, {}};
+  stage_tick_in(st, a.in, B, b);
+  st.in(&ro.ee_target_step, n * 15); st.in(&ro.trunk_target_step, n * 3); st.in(&ro.imu, n * 4);
+  st.out(&ro.q_final, n * WBC_Q_STRIDE); st.out(&ro.qdot_last, n * WBC_V_STRIDE); st.out(&ro.ee_target_final, n * 15);
+  st.out(&ro.grip_trace, (size_t)r->ticks * n * 3); st.out(&ro.status_max, n); st.out(&ro.iters_sum, n);
+  if ((rc = st.stage())) return rc;
+  // seed the mutable state from in0
+  auto seed = [&](int off, const double* src, size_t k) -> int {
+    if (src) HIP_TRY(hipMemcpyAsync(blk(off), src, n * k * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return WBC_OK;
+  };
+  if ((rc = seed(O_Q, a.in.q, 27)) || (rc = seed(O_EET, a.in.ee_target, 15)) || (rc = seed(O_EEP, a.in.prev_ee_target, 15)) ||
+      (rc = seed(O_TT, a.in.trunk_target, 3)) || (rc = seed(O_TP, a.in.prev_trunk_target, 3)) ||
+      (rc = seed(O_EPR, a.in.ee_prev_rot, 45)) || (rc = seed(O_TPR, a.in.trunk_prev_rot, 9))) return rc;
+  if (ro.status_max) HIP_TRY(hipMemsetAsync(ro.status_max, 0, n * sizeof(int32_t), s));
+  if (ro.iters_sum) HIP_TRY(hipMemsetAsync(ro.iters_sum, 0, n * sizeof(int32_t), s));
+  const WbcTickIn first = a.in;
+  a.in.q = blk(O_Q); a.in.ee_target = blk(O_EET); a.in.prev_ee_target = blk(O_EEP);
+  if (first.trunk_target) a.in.trunk_target = blk(O_TT);
+  if (first.prev_trunk_target) a.in.prev_trunk_target = blk(O_TP);
+  if (first.ee_prev_rot) a.in.ee_prev_rot = blk(O_EPR);
+  if (first.trunk_prev_rot) a.in.trunk_prev_rot = blk(O_TPR);
+  a.out.qdot = blk(O_QD); a.out.q_next = blk(O_QN); a.out.status = w_status; a.out.iters = w_iters;
+
+  UpdateArgs u;
+  memset(&u, 0, sizeof u);
+  u.models = b->d_models; u.cfgs = b->d_cfgs; u.B = B;
+  u.q_cur = blk(O_Q); u.q_next = blk(O_QN); u.imu = ro.imu; u.foot_targets = blk(O_EET); u.model_id = a.in.model_id; u.q_new = blk(O_Q);
+  u.ee_target = blk(O_EET); u.prev_ee_target = blk(O_EEP);
+  u.trunk_target = first.trunk_target ? blk(O_TT) : nullptr; u.prev_trunk_target = first.prev_trunk_target ? blk(O_TP) : nullptr;
+  u.ee_prev_rot = first.ee_prev_rot ? blk(O_EPR) : nullptr; u.trunk_prev_rot = first.trunk_prev_rot ? blk(O_TPR) : nullptr;
+  u.ee_ref_rot = first.ee_ref_rot; u.trunk_ref_euler = first.trunk_ref_euler;
+  u.ee_step = ro.ee_target_step; u.trunk_step = ro.trunk_target_step;
+  u.status = w_status; u.iters = w_iters; u.status_max = ro.status_max; u.iters_sum = ro.iters_sum;
+  const WbcTickIn loop_in = a.in;
+  for (int k = 0; k < r->ticks; ++k) {
+    a.in = loop_in;                       // auto_posture fills posture_u / q_con afresh every tick
+    if ((rc = auto_posture(b, a, B, stream))) return rc;
+    if (int e = launch_tick(a, MODE_TICK, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    u.grip_trace = ro.grip_trace ? ro.grip_trace + (size_t)k * n * 3 : nullptr;
+    if (int e = launch_update(u, B, stream)) return fail(WBC_E_HIP, "update kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  }
+  if (ro.q_final) HIP_TRY(hipMemcpyAsync(ro.q_final, blk(O_Q), n * 27 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (ro.qdot_last) HIP_TRY(hipMemcpyAsync(ro.qdot_last, blk(O_QD), n * 26 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (ro.ee_target_final) HIP_TRY(hipMemcpyAsync(ro.ee_target_final, blk(O_EET), n * 15 * sizeof(double), hipMemcpyDeviceToDevice, s));
   return st.finish();
 }
 

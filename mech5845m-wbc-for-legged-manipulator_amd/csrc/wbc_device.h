@@ -70,11 +70,28 @@ struct PostureArgs {
   double *u, *q_after;
 };
 
+// updateState(running=True) + trunkWorldPos, and (rollout only; every pointer below `q_new` may be null) the reference-state
+// side effects of qpb() and the target advance
+struct UpdateArgs {
+  const DevModel* models;
+  const WbcConfig* cfgs;
+  int32_t B, pad0;
+  const double *q_cur, *q_next, *imu, *foot_targets;
+  const int32_t* model_id;
+  double* q_new;
+  double *ee_target, *prev_ee_target, *trunk_target, *prev_trunk_target, *ee_prev_rot, *trunk_prev_rot;
+  const double *ee_ref_rot, *trunk_ref_euler, *ee_step, *trunk_step;
+  double* grip_trace;                  // [B][3] of this tick
+  const int32_t *status, *iters;       // this tick's
+  int32_t *status_max, *iters_sum;
+};
+
 // launchers (wbc_kernels.hip); grid = min(B, waves) persistent single-wave workgroups
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream);
 int launch_qp(const QpArgs& a, int grid, void* stream);
 int launch_integrate(const IntegrateArgs& a, int grid, void* stream);
 int launch_posture(const PostureArgs& a, int grid, void* stream);
+int launch_update(const UpdateArgs& a, int grid, void* stream);
 int tick_lds_bytes();
 
 }  // namespace wbc

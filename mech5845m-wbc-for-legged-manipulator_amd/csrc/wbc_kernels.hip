@@ -1486,6 +1486,93 @@ __global__ void __launch_bounds__(64) wbc_posture_kernel(const PostureArgs A, co
   if (A.q_after && lane < NQ) A.q_after[(size_t)b * NQ + lane] = (lane < nq) ? P.q[lane] : 0.0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The tail of runWBC: updateState(joint_config, base_config, running=True) (Robot_Wrapper4.py:1397-1399, 387-428) with
+// trunkWorldPos (:1297-1327). One instance per wave. In a rollout the same wave then applies the side effects qpb() has on
+// the controller's reference state (:1151-1152, :995-996) and moves the targets one step along their segment.
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) USmem {
+  double oMi[24 * 12];
+  double q[32];
+  double pf[WBC_MAX_FRAMES * 3];
+  double ft[16];
+};
+__global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, const DevModel* __restrict__ models,
+                                                        const WbcConfig* __restrict__ cfgs) {
+  __shared__ USmem U;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int mid = A.model_id ? __builtin_amdgcn_readfirstlane(A.model_id[b]) : 0;
+  const DevModel& M = models[mid];
+  const WbcConfig& cfg = cfgs[mid];
+  const LaneConst lc = load_lane_const(M, cfg, lane);
+  const int nq = M.nq;
+  // config = [current base xyz, base_config (IMU quaternion), new joint angles]  (:388-389)
+  double c = 0.0;
+  if (lane < 3) c = A.q_cur[(size_t)b * NQ + lane];
+  else if (lane < 7) c = A.imu ? A.imu[(size_t)b * 4 + (lane - 3)] : A.q_next[(size_t)b * NQ + lane];
+  else if (lane < nq) c = A.q_next[(size_t)b * NQ + lane];
+  if (lane < 32) U.q[lane] = c;
+  if (lane < 12) U.ft[lane] = A.foot_targets[(size_t)b * 15 + lane];
+  WSYNC();
+  fk_levels(U.oMi, U.q, M, lc, lane);
+  if (lane < M.nframes) {
+    const double* Pj = U.oMi + lc.fj_off;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) U.pf[3 * lane + r] = Pj[9 + r] + Pj[r] * lc.f0 + Pj[3 + r] * lc.f1 + Pj[6 + r] * lc.f2;
+  }
+  WSYNC();
+  // trunkWorldPos: trunk_pos = WPA - WRB . BPA  (:1321-1325), evaluated uniformly
+  const double* Pt = U.oMi + 12 * M.frame_joint[WBC_FR_TRUNK];   // R column-major
+  double WPA[3], BPA[3], base[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double t = U.pf[3 * WBC_FR_TRUNK + i];
+    WPA[i] = (U.ft[i] + U.ft[3 + i] + U.ft[6 + i] + U.ft[9 + i]) / 4;
+    BPA[i] = ((U.pf[i] - t) + (U.pf[3 + i] - t) + (U.pf[6 + i] - t) + (U.pf[9 + i] - t)) / 4;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) base[r] = WPA[r] - (Pt[r] * BPA[0] + Pt[3 + r] * BPA[1] + Pt[6 + r] * BPA[2]);
+  if (lane < NQ) A.q_new[(size_t)b * NQ + lane] = (lane == 0) ? base[0] : (lane == 1) ? base[1] : (lane == 2) ? base[2] : c;
+  if (A.grip_trace && lane < 3) {
+    // gripper_bar after the base correction: the whole tree translates rigidly with the base
+    const double d = (lane == 0) ? base[0] - U.q[0] : (lane == 1) ? base[1] - U.q[1] : base[2] - U.q[2];
+    A.grip_trace[(size_t)b * 3 + lane] = U.pf[3 * (WBC_FR_EE0 + 4) + lane] + d;
+  }
+  if (A.status_max && lane == 0) { const int s = A.status[b]; if (s > A.status_max[b]) A.status_max[b] = s; }
+  if (A.iters_sum && lane == 0) A.iters_sum[b] += A.iters[b];
+  // ---- side effects of qpb() on the reference state, then the targets move on
+  if (A.ee_target && lane < 15) {
+    const int e = lane / 3;
+    const size_t i = (size_t)b * 15 + lane;
+    const double t = A.ee_target[i];
+    if (cfg.task_ee[e] && A.prev_ee_target) A.prev_ee_target[i] = t;                 // prev_EE_pos[i] = target (:1151)
+    if (A.ee_step) A.ee_target[i] = t + A.ee_step[i];
+  }
+  if (A.ee_prev_rot && A.ee_ref_rot && lane < 45) {
+    const int e = lane / 9;
+    if (cfg.task_ee[e]) A.ee_prev_rot[(size_t)b * 45 + lane] = A.ee_ref_rot[(size_t)b * 45 + lane];   // prev_EE_CoM_rot[i] = R* (:1152)
+  }
+  if (A.trunk_target && lane < 3) {
+    const size_t i = (size_t)b * 3 + lane;
+    const double t = A.trunk_target[i];
+    if (cfg.task_trunk && A.prev_trunk_target) A.prev_trunk_target[i] = t;           // prev_trunk_ref = target (:995)
+    if (A.trunk_step) A.trunk_target[i] = t + A.trunk_step[i];
+  }
+  if (cfg.task_trunk && A.trunk_prev_rot && A.trunk_ref_euler) {                      // old_ref_trunk_rot_matrix = R* (:996)
+    const double* er = A.trunk_ref_euler + (size_t)b * 3;
+    const SinCos a = sincos_cw(er[0]), bb = sincos_cw(er[1]), cc = sincos_cw(er[2]);
+    double Rs[9];
+    Rs[0] = cc.c * bb.c; Rs[1] = cc.c * bb.s * a.s - cc.s * a.c; Rs[2] = cc.c * bb.s * a.c + cc.s * a.s;
+    Rs[3] = cc.s * bb.c; Rs[4] = cc.s * bb.s * a.s + cc.c * a.c; Rs[5] = cc.s * bb.s * a.c - cc.c * a.s;
+    Rs[6] = -bb.s;       Rs[7] = bb.c * a.s;                     Rs[8] = bb.c * a.c;
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) A.trunk_prev_rot[(size_t)b * 9 + i] = Rs[i];
+    }
+  }
+}
+
 static int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   (void)what;
@@ -1510,6 +1597,10 @@ int launch_integrate(const IntegrateArgs& a, int grid, void* stream) {
 int launch_posture(const PostureArgs& a, int grid, void* stream) {
   hipLaunchKernelGGL(wbc_posture_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs);
   return check_launch("posture");
+}
+int launch_update(const UpdateArgs& a, int grid, void* stream) {
+  hipLaunchKernelGGL(wbc_update_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs);
+  return check_launch("update");
 }
 int tick_lds_bytes() { return (int)sizeof(Smem); }
 

@@ -228,6 +228,43 @@ class WbcBatch:
                                                 _prep(u, f, keep), _prep(qa, f, keep), _stream(mem)), self.lib)
         return (u, qa) if want_q_after else u
 
+    def update_state(self, q_cur, q_next, foot_targets, imu=None, model_id=None):
+        """The tail of runWBC (Robot_Wrapper4.py:1397-1399): updateState(joint_config, base_config, running=True) with the
+        foot-anchored base estimator trunkWorldPos (:1297-1327). Returns the new current_joint_config [B,27]."""
+        keep = []
+        mem = _mem_of([q_cur, q_next, foot_targets, imu, model_id])
+        B = q_cur.shape[0]
+        qn = self._alloc(q_cur, (B, NQS))
+        f = np.float64
+        capi.check(self.lib.wbc_update_state(self._h, B, _prep(q_cur, f, keep), _prep(q_next, f, keep), _prep(imu, f, keep),
+                                              _prep(foot_targets, f, keep), _prep(model_id, np.int32, keep), mem,
+                                              _prep(qn, f, keep), _stream(mem)), self.lib)
+        return qn
+
+    def rollout(self, inputs, dt, ticks, ee_target_step=None, trunk_target_step=None, imu=None, want_trace=True):
+        """K closed-loop ticks on the device: tick -> update_state -> reference-state side effects ->
+        targets advance by their step. Returns dict(q, qdot, ee_target, status, iters[, grip_trace [K,B,3]])."""
+        keep = []
+        extra = [ee_target_step, trunk_target_step, imu]
+        mem = _mem_of(list(inputs.values()) + extra)
+        q = inputs["q"]
+        B = q.shape[0]
+        out = dict(q=self._alloc(q, (B, NQS)), qdot=self._alloc(q, (B, NV)), ee_target=self._alloc(q, (B, 5, 3)),
+                   status=self._alloc(q, (B,), np.int32), iters=self._alloc(q, (B,), np.int32))
+        if want_trace:
+            out["grip_trace"] = self._alloc(q, (int(ticks), B, 3))
+        r = capi.WbcRollout()
+        r.ticks = int(ticks)
+        f = np.float64
+        r.ee_target_step, r.trunk_target_step, r.imu = _prep(ee_target_step, f, keep), _prep(trunk_target_step, f, keep), _prep(imu, f, keep)
+        r.q_final, r.qdot_last, r.ee_target_final = _prep(out["q"], f, keep), _prep(out["qdot"], f, keep), _prep(out["ee_target"], f, keep)
+        r.status_max, r.iters_sum = _prep(out["status"], np.int32, keep), _prep(out["iters"], np.int32, keep)
+        if want_trace:
+            r.grip_trace = _prep(out["grip_trace"], f, keep)
+        tin = self._tick_in(inputs, keep)
+        capi.check(self.lib.wbc_rollout(self._h, B, C.byref(tin), float(dt), C.byref(r), mem, _stream(mem)), self.lib)
+        return out
+
     def integrate(self, q, v, dt, model_id=None):
         """pin.integrate(model, q, v * dt) for every instance."""
         keep = []

@@ -73,6 +73,12 @@ class WbcTickOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("qdot", "status", "iters", "q_next")]
 
 
+class WbcRollout(C.Structure):
+    _fields_ = [("ticks", C.c_int32), ("pad_", C.c_int32)] + [(n, C.c_void_p) for n in (
+        "ee_target_step", "trunk_target_step", "imu", "q_final", "qdot_last", "ee_target_final", "grip_trace",
+        "status_max", "iters_sum")]
+
+
 class WbcFkOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("oMi", "oMf", "J", "com", "Jcom")]
 
@@ -93,6 +99,8 @@ SIGNATURES = {
     "wbc_qp_solve_ls": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wbc_posture_target": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "wbc_tick": (_i, [_vp, _i, C.POINTER(WbcTickIn), _d, _i, C.POINTER(WbcTickOut), _vp]),
+    "wbc_update_state": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "wbc_rollout": (_i, [_vp, _i, C.POINTER(WbcTickIn), _d, C.POINTER(WbcRollout), _i, _vp]),
     "wbc_integrate": (_i, [_vp, _i, _vp, _vp, _vp, _d, _i, _vp, _vp]),
     "wbc_batch_set_option": (_i, [_vp, C.c_char_p, _i]),
     "wbc_batch_synchronize": (_i, [_vp, _vp]),

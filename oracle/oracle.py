@@ -170,6 +170,53 @@ def posture_target(models, cfgs, q, model_id=None, nthreads=1):
     return u, qa
 
 
+def update_state(models, q_cur, q_next, foot_targets, imu=None, model_id=None):
+    """The tail of runWBC (Robot_Wrapper4.py:1397-1399): updateState(running=True) incl. trunkWorldPos -> q_new [B,27]."""
+    q_cur, q_next = _f64(q_cur).reshape(-1, NQS), _f64(q_next).reshape(-1, NQS)
+    B = q_cur.shape[0]
+    ft = _f64(foot_targets).reshape(B, 15)
+    im = None if imu is None else _f64(imu).reshape(B, 4)
+    mid = None if model_id is None else np.ascontiguousarray(model_id, dtype=np.int32)
+    out = np.zeros((B, NQS))
+    lib().orc_update_state_batch(_models(models), C.c_int(B), _p(q_cur), _p(q_next), _p(im), _p(ft), _p(mid), _p(out))
+    return out
+
+
+def rollout(models, cfgs, tick_in_kw, dt, B, ticks, ee_target_step=None, trunk_target_step=None, imu=None, nthreads=1):
+    """K closed-loop ticks on the CPU: tick -> update_state -> the reference-state side effects of qpb()
+    (calcTargetVelEE3 :1151-1152, calcTargetVelTrunk2 :995-996) -> targets advance by their per-tick step.
+    Returns dict(q, qdot, status (max over ticks), iters (sum), ee_target, prev_ee_target, grip_trace [K,B,3])."""
+    d = {k: np.array(v, copy=True) for k, v in tick_in_kw.items()}
+    mid = d.get("model_id")
+    status = np.zeros(B, dtype=np.int32)
+    iters = np.zeros(B, dtype=np.int32)
+    trace = np.zeros((ticks, B, 3))
+    out = None
+    for k in range(ticks):
+        out = tick(models, cfgs, d, dt, B, nthreads=nthreads, want_q_next=True)
+        status = np.maximum(status, out["status"])
+        iters += out["iters"]
+        d["q"] = update_state(models, d["q"], out["q_next"], d["ee_target"], imu, mid)
+        trace[k] = fk(models, d["q"], mid, want_com=False)["oMf"][:, capi.FR_EE0 + 4, 9:]
+        for i, c in enumerate(cfgs):
+            sel = slice(None) if mid is None else (mid == i)
+            for e in range(capi.NEE):
+                if c.task_ee[e]:
+                    d["prev_ee_target"][sel, e] = d["ee_target"][sel, e]
+                    if d.get("ee_ref_rot") is not None:
+                        d["ee_prev_rot"][sel, e] = d["ee_ref_rot"][sel, e]
+            if c.task_trunk:
+                d["prev_trunk_target"][sel] = d["trunk_target"][sel]
+                from scipy.spatial.transform import Rotation as R
+                d["trunk_prev_rot"][sel] = R.from_euler("xyz", d["trunk_ref_euler"][sel]).as_matrix().reshape(-1, 9)
+        if ee_target_step is not None:
+            d["ee_target"] = d["ee_target"] + np.asarray(ee_target_step).reshape(d["ee_target"].shape)
+        if trunk_target_step is not None and d.get("trunk_target") is not None:
+            d["trunk_target"] = d["trunk_target"] + np.asarray(trunk_target_step).reshape(d["trunk_target"].shape)
+    return dict(q=d["q"], qdot=out["qdot"], status=status, iters=iters, ee_target=d["ee_target"],
+                prev_ee_target=d["prev_ee_target"], grip_trace=trace)
+
+
 def integrate(models, q, v, dt, model_id=None):
     q = _f64(q).reshape(-1, NQS)
     v = _f64(v).reshape(-1, NV)

@@ -815,6 +815,45 @@ void orc_posture_batch(const WbcModelBlob* const* models, int B, const double* q
   }
 }
 
+
+/* ---------------------------------------------------------------- closing the loop: the tail of runWBC
+ * updateState(joint_config, base_config, running=True) (Robot_Wrapper4.py:1397-1399, 387-428): the new configuration is
+ * [current base xyz, base quaternion handed in (IMU), joints of q_next]; FK; then trunkWorldPos (:1297-1327) re-estimates
+ * the base position from the four stance-foot TARGETS: trunk_pos = WPA - WRB . BPA with WPA the mean foot target and BPA
+ * the mean world-frame offset foot - trunk (rotated by WRB once more, as the reference does). The second FK of
+ * updateState only refreshes robot_data; the next tick's FK does that here.
+ * foot_targets = ee_target of the tick ([5][3], first four used: FR, FL, RR, RL). imu may be NULL (q_next's quaternion). */
+void orc_update_state(const WbcModelBlob* m, const double* q_cur, const double* q_next, const double* imu,
+                      const double* foot_targets, double* q_new) {
+  double cfg[NQS], oMi[WBC_MAX_JOINTS * 12], Mt[12], Mf[12];
+  memset(cfg, 0, sizeof cfg);
+  for (int i = 0; i < 3; ++i) cfg[i] = q_cur[i];
+  for (int i = 0; i < 4; ++i) cfg[3 + i] = imu ? imu[i] : q_next[3 + i];
+  for (int i = 7; i < m->nq; ++i) cfg[i] = q_next[i];
+  orc_fk(m, cfg, oMi);
+  orc_frame_placement(m, oMi, WBC_FR_TRUNK, Mt);
+  double bpa[4][3];
+  for (int e = 0; e < 4; ++e) {
+    orc_frame_placement(m, oMi, WBC_FR_EE0 + e, Mf);
+    for (int i = 0; i < 3; ++i) bpa[e][i] = Mf[9 + i] - Mt[9 + i];
+  }
+  double WPA[3], BPA[3];
+  for (int i = 0; i < 3; ++i) {
+    WPA[i] = (foot_targets[0 + i] + foot_targets[3 + i] + foot_targets[6 + i] + foot_targets[9 + i]) / 4;   /* :1321 */
+    BPA[i] = (bpa[0][i] + bpa[1][i] + bpa[2][i] + bpa[3][i]) / 4;                                              /* :1323 */
+  }
+  double rb[3];
+  m3_vec(Mt, BPA, rb);
+  memcpy(q_new, cfg, sizeof cfg);
+  for (int i = 0; i < 3; ++i) q_new[i] = WPA[i] - rb[i];                                                       /* :1325 */
+}
+void orc_update_state_batch(const WbcModelBlob* const* models, int B, const double* q_cur, const double* q_next,
+                            const double* imu, const double* foot_targets, const int32_t* model_id, double* q_new) {
+  for (int b = 0; b < B; ++b)
+    orc_update_state(models[model_id ? model_id[b] : 0], q_cur + (size_t)b * NQS, q_next + (size_t)b * NQS,
+                     imu ? imu + (size_t)b * 4 : 0, foot_targets + (size_t)b * 15, q_new + (size_t)b * NQS);
+}
+
 /* ---------------------------------------------------------------- batched drivers (OpenMP) */
 
 static const WbcModelBlob* pick(const WbcModelBlob* const* models, const WbcTickIn* in, int b) {

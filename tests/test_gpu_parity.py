@@ -267,6 +267,83 @@ def test_integrate_parity(wx200):
     bt.close()
 
 
+def test_update_state_parity(wx200, px100):
+    """The tail of runWBC: updateState(running=True) + trunkWorldPos (Robot_Wrapper4.py:387-428, 1297-1327)."""
+    import wbc_workload
+    rng = np.random.default_rng(13)
+    B = 512
+    models = [wx200, px100]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    qa = [wbc_workload.sample_q(m, B, rng) for m in models]
+    qb = [wbc_workload.sample_q(m, B, rng) for m in models]
+    q_cur = np.where(mid[:, None] == 0, qa[0], qa[1])
+    q_next = np.where(mid[:, None] == 0, qb[0], qb[1])
+    imu = rng.normal(size=(B, 4))
+    imu /= np.linalg.norm(imu, axis=1, keepdims=True)
+    targets = rng.normal(size=(B, 5, 3))
+    bt = WbcBatch(models, B)
+    for i, m in enumerate(models):
+        bt.configure(common.config("c3", m), i)
+    for im in (imu, None):
+        ref = oracle.update_state(models, q_cur, q_next, targets, im, mid)
+        got = bt.update_state(q_cur, q_next, targets, im, mid)
+        assert np.abs(got - ref).max() < 1e-13
+        assert (got[:, 3:] == ref[:, 3:]).all()
+    bt.close()
+
+
+@pytest.mark.parametrize("cfg_name,K,with_imu", [("c3", 12, True), ("c3", 5, False), ("c3_hybrid", 6, True), ("everything", 6, True)])
+def test_rollout_parity(wx200, cfg_name, K, with_imu):
+    """K closed-loop ticks on the device against the oracle's tick / update_state / state-advance loop:
+    state, targets, worst status, iteration total and the gripper trace."""
+    B = 192
+    cfg = common.config(cfg_name, wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=37, with_rot=(cfg_name == "everything"))
+    rng = np.random.default_rng(2)
+    step = np.zeros((B, 5, 3))
+    step[:, 4] = rng.normal(0, 1e-4, (B, 3))
+    tstep = rng.normal(0, 5e-5, (B, 3))
+    imu = d["q"][:, 3:7].copy() if with_imu else None
+    ref = oracle.rollout([wx200], [cfg], d, DT, B, K, ee_target_step=step, trunk_target_step=tstep, imu=imu, nthreads=8)
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    before = {k: v.copy() for k, v in d.items()}
+    got = bt.rollout(d, DT, K, ee_target_step=step, trunk_target_step=tstep, imu=imu)
+    assert all((d[k] == before[k]).all() for k in d)            # in0 is only read
+    ok = ref["status"] == 0
+    assert ok.mean() > 0.8
+    assert (got["status"] == ref["status"]).all()
+    # one tick agrees to ~1e-6 in qdot (cond(H) ~ 3e9); K ticks of dt = 2 ms integrate that into ~1e-8 of state
+    assert np.abs(got["q"] - ref["q"])[ok].max() < 1e-6
+    assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < 10 * QDOT_TOL
+    assert np.abs(got["ee_target"] - ref["ee_target"]).max() < 1e-15
+    assert np.abs(got["grip_trace"] - ref["grip_trace"])[:, ok].max() < 1e-6
+    assert (got["iters"][ok] - ref["iters"][ok]).__abs__().max() <= 2 * K
+    if imu is not None:
+        assert (got["q"][:, 3:7] == imu).all()
+    bt.close()
+
+
+def test_rollout_equals_tick_plus_update_state(wx200):
+    """wbc_rollout is nothing but the entry points chained: replay it through wbc_tick / wbc_update_state from the host."""
+    B, K = 64, 4
+    cfg = common.config("c3", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=39)
+    step = np.zeros((B, 5, 3))
+    step[:, 4] = [1e-4, -5e-5, 2e-5]
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    got = bt.rollout(d, DT, K, ee_target_step=step)
+    s = {k: v.copy() for k, v in d.items()}
+    for _ in range(K):
+        o = bt.tick(s, DT, want_q_next=True)
+        s["q"] = bt.update_state(s["q"], o["q_next"], s["ee_target"])
+        s["prev_ee_target"][:, 4] = s["ee_target"][:, 4]
+        s["ee_target"] = s["ee_target"] + step
+    assert (got["q"] == s["q"]).all() and (got["qdot"] == o["qdot"]).all() and (got["ee_target"] == s["ee_target"]).all()
+    bt.close()
+
+
 def test_full_size_properties(wx200):
     """BASELINE's full single-GPU size (B = 65536, config 3): size-independent certificates on every instance
     (contact rows satisfied, bounds and box rows respected) + oracle parity on a random subsample."""
