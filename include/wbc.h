@@ -272,8 +272,8 @@ int wbc_batch_synchronize(WbcBatch* b, void* stream);
 
 /* diagnostics: per-phase shader-cycle sums of wbc_tick since the last call, filled only by the -DWBC_PROFILE build of
  * the library (zeros otherwise): [0] ticks, [1] FK+Jacobians, [2] task stack, [3] Cholesky, [4] L^-1 and x0,
- * [5] equality phase, [6] inequality phase, [7] output/integrate, [8] working-set changes. */
-int wbc_debug_cycles(WbcBatch* b, uint64_t* out16);
+ * [5] equality phase, [6] inequality phase, [7] output/integrate, [8] working-set changes, [9..12] task-stack sub-phases, [13..19] contact-presolve sub-phases (24 values). */
+int wbc_debug_cycles(WbcBatch* b, uint64_t* out24);
 
 const char* wbc_last_error(void);
 const char* wbc_version(void);

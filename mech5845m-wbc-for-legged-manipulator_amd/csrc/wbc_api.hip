@@ -35,10 +35,12 @@ struct WbcBatch {
   bool configured[WBC_MAX_MODELS];
   DevModel* d_models;
   WbcConfig* d_cfgs;
+  DevPlan* d_plans;
   void* ws;
   size_t ws_bytes;
   int mrows, prows, mcart;
   int jtj_mfma;
+  int presolve;
   unsigned long long* d_prof;
   double *d_pu, *d_pq;   // qpJointb MANI/HYBRID results: u [max_batch][26], q_after [max_batch][27] (lazy)
   void* d_roll;          // wbc_rollout's mutable controller state for max_batch instances (lazy)
@@ -129,7 +131,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   WbcBatch* b = new (std::nothrow) WbcBatch;
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
-  b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch;
+  b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
@@ -143,6 +145,8 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   if (n_models > 0) {   // n_models == 0: a QP-only handle (wbc_qp_solve / wbc_qp_solve_ls)
     HIP_TRY(hipMalloc((void**)&b->d_models, sizeof(DevModel) * n_models));
     HIP_TRY(hipMalloc((void**)&b->d_cfgs, sizeof(WbcConfig) * n_models));
+    HIP_TRY(hipMalloc((void**)&b->d_plans, sizeof(DevPlan) * n_models));
+    HIP_TRY(hipMemset(b->d_plans, 0, sizeof(DevPlan) * n_models));
     HIP_TRY(hipMemcpy(b->d_models, dm.data(), sizeof(DevModel) * n_models, hipMemcpyHostToDevice));
   }
   *out = b;
@@ -154,6 +158,7 @@ extern "C" void wbc_batch_destroy(WbcBatch* b) {
   (void)hipSetDevice(b->device_id);
   if (b->d_models) (void)hipFree(b->d_models);
   if (b->d_cfgs) (void)hipFree(b->d_cfgs);
+  if (b->d_plans) (void)hipFree(b->d_plans);
   if (b->ws) (void)hipFree(b->ws);
   if (b->d_prof) (void)hipFree(b->d_prof);
   if (b->d_pu) (void)hipFree(b->d_pu);
@@ -174,6 +179,35 @@ static int rows_con(const WbcConfig& c) {
   int p = (c.con_com ? 2 : 0) + (c.con_trunk ? 4 : 0);
   for (int i = 0; i < WBC_NEE; ++i) p += c.con_ee[i] ? 3 : 0;
   return p;
+}
+
+// Which stance feet's contact equalities the tick kernel eliminates structurally (contact_presolve in wbc_kernels.hip).
+// Enabled only when (1) every contact foot's rows are supported by the 6 base DoF + 3 own leg DoF, the leg sets disjoint,
+// (2) NO active task touches an eliminated leg DoF (then H_ll = d^2 I, H_lf = 0 and the reduction costs no accuracy),
+// (3) the reduced problem fits qp_core<16>.
+static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan* P) {
+  memset(P, 0, sizeof *P);
+  for (int i = 0; i < 32; ++i) { P->pos[i] = -1; P->lidx[i] = -1; }
+  uint32_t legmask = 0;
+  int prow = (c.con_com ? 2 : 0) + (c.con_trunk ? 4 : 0), nelim = 0, l = 0;
+  for (int e = 0; e < 4; ++e) {
+    if (!c.con_ee[e]) continue;
+    const uint32_t sup = M.frame_support[WBC_FR_EE0 + e], legs = sup & ~0x3Fu;
+    if ((sup & 0x3Fu) != 0x3Fu || __builtin_popcount(legs) != 3 || (legs & legmask)) return;
+    legmask |= legs;
+    P->elimrows |= 7u << prow;
+    P->rowstart[nelim++] = prow;
+    for (int d = 0; d < M.nv; ++d) if ((legs >> d) & 1u) { P->lidx[d] = l; P->legd[l++] = d; }
+    prow += 3;
+  }
+  if (!nelim || !c.task_joint || c.task_com) return;
+  for (int e = 0; e < WBC_NEE; ++e) if (c.task_ee[e] && (M.frame_support[WBC_FR_EE0 + e] & legmask)) return;
+  if (c.task_trunk && (M.frame_support[WBC_FR_TRUNK] & legmask)) return;
+  const int n_red = M.nv - 3 * nelim, p_keep = prows - 3 * nelim;
+  if (n_red > WBC_PLAN_NR || n_red < 6 || p_keep + (c.use_bounds ? 3 * nelim : 0) > WBC_MAX_P) return;
+  int cnt = 0;
+  for (int d = 0; d < M.nv; ++d) if (!((legmask >> d) & 1u)) { P->pos[d] = cnt; P->Fd[cnt++] = d; }
+  P->nelim = nelim; P->n_red = n_red; P->p_keep = p_keep; P->enabled = 1;
 }
 
 extern "C" int wbc_batch_configure(WbcBatch* b, int mi, const WbcConfig* cfg) {
@@ -199,6 +233,9 @@ extern "C" int wbc_batch_configure(WbcBatch* b, int mi, const WbcConfig* cfg) {
   b->configured[mi] = true;
   b->mrows = m; b->prows = p; b->mcart = mcart;
   HIP_TRY(hipMemcpy(b->d_cfgs + mi, cfg, sizeof *cfg, hipMemcpyHostToDevice));
+  DevPlan plan;
+  build_plan(b->models[mi]->dev, *cfg, p, &plan);
+  HIP_TRY(hipMemcpy(b->d_plans + mi, &plan, sizeof plan, hipMemcpyHostToDevice));
   return WBC_OK;
 }
 
@@ -208,6 +245,7 @@ extern "C" int wbc_constraint_rows(const WbcBatch* b) { return b ? b->prows : WB
 extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!b || !name) return fail(WBC_E_ARG, "wbc_batch_set_option: null");
   if (!strcmp(name, "jtj_mfma")) { b->jtj_mfma = value; return WBC_OK; }
+  if (!strcmp(name, "presolve")) { b->presolve = value; return WBC_OK; }
   if (!strcmp(name, "grid")) { if (value < 1) return fail(WBC_E_ARG, "grid must be >= 1"); b->grid = value; return WBC_OK; }
   return fail(WBC_E_ARG, "unknown option %s", name);
 }
@@ -331,8 +369,8 @@ static int auto_posture(WbcBatch* b, KernelArgs& a, int B, void* stream) {
 
 static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
   memset(&a, 0, sizeof a);
-  a.models = b->d_models; a.cfgs = b->d_cfgs;
-  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma; a.dt = dt;
+  a.models = b->d_models; a.cfgs = b->d_cfgs; a.plans = b->d_plans;
+  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma; a.presolve = b->presolve; a.dt = dt;
   a.prof = b->d_prof;
   if (b->n_models > 0) { a.fk_nj = b->models[0]->blob.njoints; a.fk_nf = b->models[0]->blob.nframes; }
 }
@@ -571,16 +609,16 @@ extern "C" int wbc_integrate(WbcBatch* b, int B, const double* q, const double* 
   return st.finish();
 }
 
-extern "C" int wbc_debug_cycles(WbcBatch* b, uint64_t* out16) {
-  if (!b || !out16) return fail(WBC_E_ARG, "wbc_debug_cycles: null argument");
+extern "C" int wbc_debug_cycles(WbcBatch* b, uint64_t* out24) {
+  if (!b || !out24) return fail(WBC_E_ARG, "wbc_debug_cycles: null argument");
   HIP_TRY(hipSetDevice(b->device_id));
   if (!b->d_prof) {   // first call arms the counters (they stay zero in non-profile builds)
-    HIP_TRY(hipMalloc((void**)&b->d_prof, 16 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(b->d_prof, 0, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&b->d_prof, 24 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(b->d_prof, 0, 24 * sizeof(unsigned long long)));
   }
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out16, b->d_prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemset(b->d_prof, 0, 16 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemcpy(out24, b->d_prof, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(b->d_prof, 0, 24 * sizeof(unsigned long long)));
   return WBC_OK;
 }
 

@@ -28,13 +28,28 @@ struct DevModel {
   double total_mass;
 };
 
+// Structural presolve plan of one (model, configuration): which stance feet's contact equalities are eliminated and
+// the index maps of the reduced problem (built by wbc_batch_configure, read with scalar loads by the tick kernel).
+#define WBC_PLAN_NR 16
+struct DevPlan {
+  int32_t enabled, nelim, n_red, p_keep;
+  uint32_t elimrows;                 // bit i: constraint row i belongs to an eliminated foot
+  int32_t pad_[3];
+  int32_t rowstart[4];               // first constraint row of eliminated foot f
+  int32_t legd[12];                  // DoF index of eliminated leg DoF l (feet in constraint order, DoF ascending)
+  int32_t Fd[WBC_PLAN_NR];           // DoF index of reduced variable k (0 beyond n_red)
+  int32_t pos[32];                   // DoF d -> reduced position (-1: eliminated / absent)
+  int32_t lidx[32];                  // DoF d -> l (-1: not an eliminated leg DoF)
+};
+
 enum Mode : int { MODE_TICK = 0, MODE_ASSEMBLE = 1, MODE_FK = 2 };
 
 struct KernelArgs {
   const DevModel* models;
   const WbcConfig* cfgs;
+  const DevPlan* plans;
   int32_t B, mrows, prows, mcart;   // mcart = Cartesian task rows (excludes the diagonal posture block)
-  int32_t jtj_mfma, pad0;
+  int32_t jtj_mfma, presolve;  // presolve: structural elimination of the contact equalities (default on)
   int32_t fk_nj, fk_nf;             // oMi / oMf output strides (sizes of model 0)
   unsigned long long* prof;         // WBC_PROFILE builds: per-phase cycle sums [16] (else unused)
   double dt;

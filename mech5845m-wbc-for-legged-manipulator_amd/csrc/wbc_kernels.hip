@@ -57,7 +57,7 @@ constexpr int MAXE = NV;                // equalities the QR keeps in registers 
 #define STAMP(ts, i) do { } while (0)
 #endif
 enum { T_START = 0, T_FK = 1, T_ASM = 2, T_CHOL = 3, T_INV = 4, T_EQ = 5, T_INEQ = 6, T_END = 7, T_N = 8,
-       T_A1 = 8, T_A2 = 9, T_A3 = 10, T_NN = 11 };   // sub-stamps inside the task-stack phase (profile build)
+       T_A1 = 8, T_A2 = 9, T_A3 = 10, T_PRE = 11, T_P1 = 12, T_P2 = 13, T_P3 = 14, T_NN = 15 };   // sub-stamps inside the task-stack phase (profile build)
 
 // ---------------------------------------------------------------------------------------------- lane helpers
 __device__ __forceinline__ double rfl(double v) {
@@ -219,10 +219,11 @@ __device__ __forceinline__ void integrate_ff(const Smem& S, const int lane, doub
 // ------------------------------------------------------------------------------------------------
 struct QpResult { double x; int status; int iters; };
 
+template <int NM>   // NM = compiled problem-size cap (even, n <= NM <= NM): register-array sizes and loop trip counts
 __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const double lb_in, const double ub_in,
                                             const double clb_in, const double cub_in, const int n, const int p, const int lane,
                                             unsigned long long* ts) {
-  const int li = li_clamp(lane);
+  const int li = lane < NM ? lane : NM - 1;
   QpResult res;
   res.status = WBC_QP_OPTIMAL;
   res.iters = 0;
@@ -243,7 +244,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
       WSYNC();
       double gs = 0.0, cs = 0.0;
 #pragma unroll
-      for (int k = 0; k < NV; k += 2) {
+      for (int k = 0; k < NM; k += 2) {
         const double2a h2 = lds2(S.RA + li * LDJ + k); const double2a c2 = lds2(S.RC + ((lane < p) ? lane : 0) * LDJ + k);
         const double2a f2 = lds2(S.yv + k);
         gs = fma(h2.x, f2.x, fma(h2.y, f2.y, gs)); cs = fma(c2.x, f2.x, fma(c2.y, f2.y, cs));
@@ -256,12 +257,12 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
 #pragma unroll 1
     while (m) {
       const int k = ctz64(m); m &= m - 1;
-      if (lane < NV) S.RA[lane * LDJ + k] = 0.0;
+      if (lane < NM) S.RA[lane * LDJ + k] = 0.0;
       if (lane < p) S.RC[lane * LDJ + k] = 0.0;
     }
     if (fixb) {
 #pragma unroll
-      for (int k = 0; k < NV; k += 2) sts2(S.RA + lane * LDJ + k, 0.0, 0.0);
+      for (int k = 0; k < NM; k += 2) sts2(S.RA + lane * LDJ + k, 0.0, 0.0);
       S.RA[lane * LDJ + lane] = 1.0;
       g = -fv;
       lb = -1e30; ub = 1e30;                // no longer a constraint
@@ -270,9 +271,9 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
   }
 
   // ---- row `lane` of H into registers (lanes >= 26 shadow row 25; they never write)
-  double h[NV];
+  double h[NM];
 #pragma unroll
-  for (int k = 0; k < NV; k += 2) { const double2a v = lds2(S.RA + li * LDJ + k); h[k] = v.x; h[k + 1] = v.y; }
+  for (int k = 0; k < NM; k += 2) { const double2a v = lds2(S.RA + li * LDJ + k); h[k] = v.x; h[k + 1] = v.y; }
   WSYNC();
 
   // ---- Cholesky H = L L', right-looking, ROTATING registers: at step j register r holds column j + r of the row,
@@ -281,22 +282,22 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
   double* const Lt = S.RA;
   double pmin = 1.0;
 #pragma unroll 1
-  for (int j = 0; j < NV; ++j) {
+  for (int j = 0; j < NM; ++j) {
     const double pj = rdl(h[0], j);
     pmin = fmin(pmin, pj);
     const double rinv = rsqrt(pj);
     const double l = h[0] * rinv;
-    if (lane < NV) { S.cl[lane] = l; Lt[j * LDJ + lane] = (lane >= j) ? l : 0.0; }
+    if (lane < NM) { S.cl[lane] = l; Lt[j * LDJ + lane] = (lane >= j) ? l : 0.0; }
     if (lane == 0) S.dinv[j] = rinv;
     WSYNC();
     const double* cj = S.cl + j;
-    double cm[NV];
+    double cm[NM];
 #pragma unroll
-    for (int r = 1; r < NV; ++r) cm[r] = cj[r];
+    for (int r = 1; r < NM; ++r) cm[r] = cj[r];
 #pragma unroll
-    for (int r = 1; r < NV; ++r) h[r - 1] = fma(-l, cm[r], h[r]);
-    LDS_THEN_VALU(25, 25);
-    h[NV - 1] = 0.0;
+    for (int r = 1; r < NM; ++r) h[r - 1] = fma(-l, cm[r], h[r]);
+    LDS_THEN_VALU(NM - 1, NM - 1);
+    h[NM - 1] = 0.0;
     WSYNC();
   }
   STAMP(ts, T_CHOL);
@@ -308,7 +309,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
   const bool eq_r = has_r && (clb == cub) && (fabs(clb) < QP_INF);
   const unsigned long long eqm_b = __ballot(eq_b), eqm_r = __ballot(eq_r);
   const int nbe = __popcll(eqm_b), ne = nbe + __popcll(eqm_r);
-  if (ne > MAXE) { res.status = WBC_QP_NUMERICAL; return res; }   // more equalities than unknowns
+  if (ne > NM) { res.status = WBC_QP_NUMERICAL; return res; }   // more equalities than unknowns
 
   // ---- forward substitutions L y = rhs, one right-hand side per lane, ROTATING registers (same trick):
   //   lane c < 26        : e_c        -> y = column c of L^-1 = row c of J0 = L^-T
@@ -318,14 +319,14 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
   // outputs ride along the rotation unchanged.
   if (lane < 32) S.npv[lane] = (lane < n) ? g : 0.0;
   WSYNC();
-  double y[NV];
+  double y[NM];
   {
-    const int rl = lane - NV;                           // which right-hand side this lane carries
+    const int rl = lane - NM;                           // which right-hand side this lane carries
     const double* src = (rl >= 0 && rl < p) ? (S.RC + rl * LDJ) : S.npv;
     const bool from_lds = (rl >= 0 && rl <= p);
     double sqn = 0.0;
 #pragma unroll
-    for (int k = 0; k < NV; k += 2) {
+    for (int k = 0; k < NM; k += 2) {
       const double2a v = lds2(src + k);
       y[k] = from_lds ? v.x : ((k == lane) ? 1.0 : 0.0);
       y[k + 1] = from_lds ? v.y : ((k + 1 == lane) ? 1.0 : 0.0);
@@ -335,42 +336,42 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
   }
   WSYNC();
 #pragma unroll 1
-  for (int k = 0; k < NV; ++k) {
+  for (int k = 0; k < NM; ++k) {
     const double* lk = Lt + k * LDJ + k;
-    double lm[NV];
+    double lm[NM];
     const double dk = S.dinv[k];
 #pragma unroll
-    for (int q2 = 1; q2 < NV; ++q2) lm[q2] = lk[q2];
+    for (int q2 = 1; q2 < NM; ++q2) lm[q2] = lk[q2];
     const double yk = y[0] * dk;
 #pragma unroll
-    for (int q2 = 1; q2 < NV; ++q2) y[q2 - 1] = fma(-lm[q2], yk, y[q2]);
-    LDS_THEN_VALU(26, 26);
-    y[NV - 1] = yk;
+    for (int q2 = 1; q2 < NM; ++q2) y[q2 - 1] = fma(-lm[q2], yk, y[q2]);
+    LDS_THEN_VALU(NM, NM);
+    y[NM - 1] = yk;
   }
   // lanes < 26: y = row `lane` of J0.  jf2 = |J0|_F^2
   double sq = 0.0;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) sq = fma(y[k], y[k], sq);
-  const double jf2 = wsum(lane < NV ? sq : 0.0);
+  for (int k = 0; k < NM; ++k) sq = fma(y[k], y[k], sq);
+  const double jf2 = wsum(lane < NM ? sq : 0.0);
   const double cn2 = has_r ? S.yv[lane & 31] : 0.0;     // |C_r|^2 for row = lane
   WSYNC();
   // J0 rows -> RB (bound-type equality columns are read from it), B columns and L^-1 g -> RA rows 0..p
   {
-    double* dst = (lane < NV) ? (S.RB + lane * LDJ) : ((lane - NV <= p) ? (S.RA + (lane - NV) * LDJ) : nullptr);
+    double* dst = (lane < NM) ? (S.RB + lane * LDJ) : ((lane - NM <= p) ? (S.RA + (lane - NM) * LDJ) : nullptr);
     if (dst) {
 #pragma unroll
-      for (int k = 0; k < NV; k += 2) sts2(dst + k, y[k], y[k + 1]);
+      for (int k = 0; k < NM; k += 2) sts2(dst + k, y[k], y[k + 1]);
     }
   }
   STAMP(ts, T_INV);
   WSYNC();
 
   // ---- gather row `lane` of B (one register per equality, processing order: bounds by index, then rows) and L^-1 g
-  double bq[MAXE], bg;
+  double bq[NM], bg;
   {
     unsigned long long mb = eqm_b, mr = eqm_r;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
+    for (int e = 0; e < NM; ++e) {
       double v = 0.0;
       if (e < ne) {                                      // uniform
         const double* col;
@@ -423,7 +424,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
     // remaining columns (rotated down by one) and L^-1 g
     const int left = ne - 1 - e;          // columns still to come
 #pragma unroll
-    for (int r = 1; r < MAXE; ++r) {
+    for (int r = 1; r < NM; ++r) {
       if (((r - 1) & 3) == 0 && r > left) break;      // uniform: whole groups of four past the last column are skipped
       const double tau = wsum(v * bq[r]) * beta;
       bq[r - 1] = fma(-tau, v, bq[r]);
@@ -433,22 +434,22 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
     if (beta != 0.0) {
       // (v is zero below the slot it was built for; q was already advanced, so entries k < q - 1 can be skipped
       //  in groups of eight with one uniform branch per group)
-      double vk[NV], w = 0.0, w2 = 0.0;
+      double vk[NM], w = 0.0, w2 = 0.0;
 #pragma unroll
-      for (int k = 0; k < NV; k += 2) { const double2a v2 = lds2(S.dv + k); vk[k] = v2.x; vk[k + 1] = v2.y; }
-      LDS_THEN_VALU(13, 0);
+      for (int k = 0; k < NM; k += 2) { const double2a v2 = lds2(S.dv + k); vk[k] = v2.x; vk[k + 1] = v2.y; }
+      LDS_THEN_VALU(NM / 2, 0);
 #pragma unroll
-      for (int k0 = 0; k0 < NV; k0 += 8) {
+      for (int k0 = 0; k0 < NM; k0 += 8) {
         if (k0 + 8 < q) continue;
 #pragma unroll
-        for (int k = k0; k < k0 + 8 && k < NV; k += 2) { w = fma(y[k], vk[k], w); w2 = fma(y[k + 1], vk[k + 1], w2); }
+        for (int k = k0; k < k0 + 8 && k < NM; k += 2) { w = fma(y[k], vk[k], w); w2 = fma(y[k + 1], vk[k + 1], w2); }
       }
       w = (w + w2) * beta;
 #pragma unroll
-      for (int k0 = 0; k0 < NV; k0 += 8) {
+      for (int k0 = 0; k0 < NM; k0 += 8) {
         if (k0 + 8 < q) continue;
 #pragma unroll
-        for (int k = k0; k < k0 + 8 && k < NV; ++k) y[k] = fma(-w, vk[k], y[k]);
+        for (int k = k0; k < k0 + 8 && k < NM; ++k) y[k] = fma(-w, vk[k], y[k]);
       }
     }
     WSYNC();
@@ -457,16 +458,16 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
   // ---- x_eq = J1 y1 - J2 (J2' g):  bg now holds J'g
   if (lane < 32) S.dv[lane] = (lane < qe) ? y1 : ((lane < n) ? -bg : 0.0);
   // J = J0 Q -> RB for the inequality phase; T = 0 in RA
-  if (lane < NV) {
+  if (lane < NM) {
 #pragma unroll
-    for (int k = 0; k < NV; k += 2) sts2(S.RB + lane * LDJ + k, y[k], y[k + 1]);
+    for (int k = 0; k < NM; k += 2) sts2(S.RB + lane * LDJ + k, y[k], y[k + 1]);
   }
-  for (int k = lane; k < NV * LDJ; k += 64) S.RA[k] = 0.0;
+  for (int k = lane; k < NM * LDJ; k += 64) S.RA[k] = 0.0;
   WSYNC();
   double x = 0.0, x2s = 0.0;
 #pragma unroll
-  for (int k = 0; k < NV; k += 2) { const double2a v2 = lds2(S.dv + k); x = fma(y[k], v2.x, x); x2s = fma(y[k + 1], v2.y, x2s); }
-  LDS_THEN_VALU(13, 26);
+  for (int k = 0; k < NM; k += 2) { const double2a v2 = lds2(S.dv + k); x = fma(y[k], v2.x, x); x2s = fma(y[k + 1], v2.y, x2s); }
+  LDS_THEN_VALU(NM / 2, NM);
   x += x2s;
   if (lane >= n) x = 0.0;
   double* const J = S.RB;
@@ -488,11 +489,11 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
     if (p > 0) {
       double v = 0.0, vb = 0.0;
 #pragma unroll
-      for (int k = 0; k < NV; k += 2) {
+      for (int k = 0; k < NM; k += 2) {
         const double2a c2 = lds2(Cm + (has_r ? lane : 0) * LDJ + k); const double2a x2 = lds2(S.xv + k);
         v = fma(c2.x, x2.x, v); vb = fma(c2.y, x2.y, vb);
       }
-      LDS_THEN_VALU(26, 26);
+      LDS_THEN_VALU(NM, NM);
       v += vb;
       if (has_r && !act_r && !eq_r) {
         if (clb > -QP_INF) { const double s = v - clb; if (s < -1e-9 * fmax(1.0, fabs(clb)) && s < best) { best = s; code = n + lane; } }
@@ -519,12 +520,12 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
       if (is_row) {
         double d2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < NV; i += 2) {
+        for (int i = 0; i < NM; i += 2) {
           const double2a c2 = lds2(Cm + rr * LDJ + i);
           d = fma(J[i * LDJ + li], c2.x, d);
           d2 = fma(J[(i + 1) * LDJ + li], c2.y, d2);
         }
-        LDS_THEN_VALU(39, 26);
+        LDS_THEN_VALU(NM + NM / 2, NM);
         d = (d + d2) * sgn;
       } else {
         d = sgn * J[ip * LDJ + li];
@@ -537,19 +538,19 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
       // inequality slots, so the full row product is the product over [qe, q))
       double z = 0.0, zb = 0.0, r = 0.0, rb = 0.0;
 #pragma unroll
-      for (int k = 0; k < NV; k += 2) {
+      for (int k = 0; k < NM; k += 2) {
         const double2a j2 = lds2(J + li * LDJ + k); const double2a y2 = lds2(S.yv + k);
         z = fma(j2.x, y2.x, z); zb = fma(j2.y, y2.y, zb);
       }
-      LDS_THEN_VALU(26, 26);
+      LDS_THEN_VALU(NM, NM);
       z += zb;
       if (q > qe) {
 #pragma unroll
-        for (int k = 0; k < NV; k += 2) {
+        for (int k = 0; k < NM; k += 2) {
           const double2a t2 = lds2(T + li * LDJ + k); const double2a d2 = lds2(S.dv + k);
           r = fma(t2.x, d2.x, r); rb = fma(t2.y, d2.y, rb);
         }
-        LDS_THEN_VALU(26, 26);
+        LDS_THEN_VALU(NM, NM);
         r += rb;
       }
       if (lane < qe || lane >= q) r = 0.0;
@@ -574,7 +575,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
         if (vv > 0.0) {
           const double w = (z - delta * J[li * LDJ + q]) * (2.0 / vv);
 #pragma unroll
-          for (int k = 0; k < NV; k += 2) {
+          for (int k = 0; k < NM; k += 2) {
             const double2a j2 = lds2(J + li * LDJ + k); const double2a y2 = lds2(S.yv + k);   // yv = d for k >= q, else 0
             const double v0 = (k == q) ? y2.x - delta : y2.x;
             const double v1 = (k + 1 == q) ? y2.y - delta : y2.y;
@@ -597,7 +598,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
         WSYNC();
         if (lane >= l && lane < q - 1) { u = S.yv[lane + 1]; a_code = (int)S.lv[lane + 1]; }
         if (lane == q - 1) { u = 0.0; a_code = 0; }
-        const int srow = (li >= l) ? ((li + 1 < NV) ? li + 1 : li) : li;   // old row feeding new row `lane`
+        const int srow = (li >= l) ? ((li + 1 < NM) ? li + 1 : li) : li;   // old row feeding new row `lane`
         double tx = T[srow * LDJ + l];
         double jx = J[li * LDJ + l];
         double hrun = T[l * LDJ + l];
@@ -892,12 +893,178 @@ __device__ __forceinline__ void fk_pass(Smem& S, double* const oMi, const double
 }
 
 // ------------------------------------------------------------------------------------------------
+// Structural presolve of the contact equalities (the MI355X-side replacement for carrying them through the factorisation).
+// A stance foot's rows  Jc_e qdot = 0  (EEConstraint, Robot_Wrapper4.py:757-761) touch the 6 base DoF and that leg's own
+// 3 DoF only, so the leg velocities are a linear function of the base velocity:  qdot_leg_e = G_e qdot_base,
+// G_e = -K_e^-1 B_e  with K_e the 3 x 3 leg block and B_e the 3 x 6 base block of Jc_e. Substituting x = Z y
+// (y = base + every DoF that is not an eliminated leg) gives an equivalent QP in n - 3 f unknowns with NO contact
+// equalities:  H' = Z'HZ, g' = Z'g, remaining rows C' = CZ, and the eliminated legs' velocity bounds become f x 3 general
+// rows  lb_leg <= G_e y_base <= ub_leg.  For A1 + wx200 with four stance feet: 26 unknowns / 12 equalities -> 14 / 0, and
+// the dense phases (Cholesky, L^-1, equality QR) shrink accordingly (qp_core<16>).
+// It is applied only where it costs no accuracy: when no active task touches the eliminated legs (the sim3 tick: Grip
+// task + posture; DevPlan.enabled, decided by wbc_batch_configure) H_ll = d^2 I and H_lf = 0 exactly, so
+// H' = H_ff + d^2 G'G on the base block — no cancellation. With foot / CoM tasks on, Z'HZ is 10^3 x worse conditioned than H
+// (|G| ~ 100 in the WORLD-frame rows) and the general path is kept. Falls back (returns false) at run time when a leg
+// block is numerically singular. Same minimiser as the full problem (tests compare both paths against the oracle).
+// LDS: G lives at RB[16 LDJ ..] (rows >= 16 of RB are never touched by qp_core<16>, so it survives the solve).
+// ------------------------------------------------------------------------------------------------
+constexpr int NR = WBC_PLAN_NR;        // compiled size cap of the reduced problem (16)
+constexpr int GS = 8;                  // row stride of G
+__device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
+                                                 const DevPlan& P, const double dpost, const double g, const double lb,
+                                                 const double ub, const double clb, const double cub, const int lane,
+                                                 unsigned long long* ts, QpResult& res) {
+  if (!A.presolve || !P.enabled) return false;
+  const int nv = M.nv, p = A.prows;
+  const int nelim = P.nelim, n_red = P.n_red, nl = 3 * nelim;
+  double* const Gm = S.RB + NR * LDJ;            // [12][GS]: row l = eliminated leg DoF l, columns = base DoF
+  double* const Cm = S.RC;
+  // the plan's index maps, fetched up front in one batch of scalar loads (loaded where they are used, each value costs
+  // its own s_load + full wait inside the dependent chain: profiles/r01_phase_cycles_v9a.json, 29k cycles of presolve)
+  int legd[12], Fd[NR], rowstart[4];
+#pragma unroll
+  for (int l = 0; l < 12; ++l) legd[l] = P.legd[l];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) Fd[k] = P.Fd[k];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) rowstart[f] = P.rowstart[f];
+  const unsigned elimrows = P.elimrows;
+#pragma unroll
+  for (int l = 0; l < 12; ++l) asm volatile("" : "+s"(legd[l]));
+#pragma unroll
+  for (int k = 0; k < NR; ++k) asm volatile("" : "+s"(Fd[k]));
+#pragma unroll
+  for (int f = 0; f < 4; ++f) asm volatile("" : "+s"(rowstart[f]));
+  // per-lane views of the maps by select chains over the SGPR copies (a per-lane global load of the plan stalled the
+  // wave for thousands of cycles): fj = DoF of reduced variable `lane`; for lane = DoF d: its reduced position or its
+  // eliminated-leg index; my_legd = leg DoF whose bound row is row `lane` of the reduced constraint matrix
+  const int p_keep = P.p_keep;
+  int fj = 0, my_pos = -1, my_l = -1, my_legd = 0;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) { fj = (lane == k) ? Fd[k] : fj; my_pos = (lane == Fd[k] && k < n_red) ? k : my_pos; }
+#pragma unroll
+  for (int l = 0; l < 12; ++l) { my_l = (lane == legd[l] && l < nl) ? l : my_l; my_legd = (lane - p_keep == l) ? legd[l] : my_legd; }
+  if (lane < 32) { S.npv[lane] = (lane < nv) ? g : 0.0; S.xv[lane] = lb; S.yv[lane] = ub; }
+
+  // ---- G_e = -K_e^-1 B_e per foot: K_e^-1 by the adjugate (uniform), lane c < 6 owns column c of B_e / G_e
+  bool singular = false;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    if (f < nelim) {
+      const int d0 = legd[3 * f], d1 = legd[3 * f + 1], d2 = legd[3 * f + 2];
+      const double* r0 = Cm + rowstart[f] * LDJ; const double* r1 = r0 + LDJ; const double* r2 = r1 + LDJ;
+      const double k00 = r0[d0], k01 = r0[d1], k02 = r0[d2], k10 = r1[d0], k11 = r1[d1], k12 = r1[d2],
+                   k20 = r2[d0], k21 = r2[d1], k22 = r2[d2];
+      const int c = lane < 6 ? lane : 0;
+      const double b0 = r0[c], b1 = r1[c], b2 = r2[c];
+      const double a00 = k11 * k22 - k12 * k21, a01 = k02 * k21 - k01 * k22, a02 = k01 * k12 - k02 * k11;
+      const double a10 = k12 * k20 - k10 * k22, a11 = k00 * k22 - k02 * k20, a12 = k02 * k10 - k00 * k12;
+      const double a20 = k10 * k21 - k11 * k20, a21 = k01 * k20 - k00 * k21, a22 = k00 * k11 - k01 * k10;
+      const double det = k00 * a00 + k01 * a10 + k02 * a20;
+      const double sc = fabs(k00) + fabs(k01) + fabs(k02) + fabs(k10) + fabs(k11) + fabs(k12) + fabs(k20) + fabs(k21) + fabs(k22);
+      if (!(fabs(det) > 1e-7 * sc * sc * sc)) singular = true;       // leg block (nearly) rank deficient: keep the general path
+      const double id = -1.0 / det;
+      if (lane < 6) {
+        Gm[(3 * f + 0) * GS + lane] = id * (a00 * b0 + a01 * b1 + a02 * b2);
+        Gm[(3 * f + 1) * GS + lane] = id * (a10 * b0 + a11 * b1 + a12 * b2);
+        Gm[(3 * f + 2) * GS + lane] = id * (a20 * b0 + a21 * b1 + a22 * b2);
+      }
+    } else if (lane < 6) {
+      Gm[(3 * f + 0) * GS + lane] = 0.0; Gm[(3 * f + 1) * GS + lane] = 0.0; Gm[(3 * f + 2) * GS + lane] = 0.0;
+    }
+  }
+  if (singular) return false;
+  WSYNC();
+  STAMP(ts, T_P1);
+  // per-lane column of G (lanes >= 6: zero), kept for H', g' and C'
+  double gcol[12];
+#pragma unroll
+  for (int l = 0; l < 12; ++l) gcol[l] = (lane < 6) ? Gm[l * GS + lane] : 0.0;   // rows >= nl are zero
+
+  // g' = Z'g
+  double g_red = S.npv[fj];
+#pragma unroll
+  for (int l = 0; l < 12; ++l) g_red = fma(gcol[l], S.npv[legd[l]], g_red);
+  if (lane >= n_red) g_red = 0.0;
+  STAMP(ts, T_P2);
+  // ---- C' = C Z for the rows that stay (in their order), then the eliminated legs' bounds as rows G_l
+  double nclb = 0.0, ncub = 0.0;
+  int i2 = 0;
+#pragma unroll 1
+  for (int i = 0; i < p; ++i) {
+    if ((elimrows >> i) & 1u) continue;
+    double v = (lane < n_red) ? Cm[i * LDJ + fj] : 0.0;
+#pragma unroll
+    for (int l = 0; l < 12; ++l) v = fma(gcol[l], Cm[i * LDJ + legd[l]], v);
+    const double bl = rdl(clb, i), bu = rdl(cub, i);
+    WSYNC();
+    if (lane < NV) Cm[i2 * LDJ + lane] = v;
+    if (lane == i2) { nclb = bl; ncub = bu; }
+    WSYNC();
+    ++i2;
+  }
+  if (cfg.use_bounds) {
+#pragma unroll
+    for (int l = 0; l < 12; ++l) {
+      if (l < nl) { if (lane < NV) Cm[(i2 + l) * LDJ + lane] = gcol[l]; }
+    }
+    if (lane >= i2 && lane < i2 + nl) { nclb = S.xv[my_legd]; ncub = S.yv[my_legd]; }
+    i2 += nl;
+  }
+  const double lb_red = (lane < n_red) ? S.xv[fj] : 0.0, ub_red = (lane < n_red) ? S.yv[fj] : 0.0;
+  WSYNC();
+  STAMP(ts, T_P3);
+  // ---- row `lane` of H' (lanes < n_red), identity padding up to NR:  H_ff  +  d^2 G'G on the base block
+  double hr[NR];
+  {
+    double gg[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int l = 0; l < 12; ++l) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) gg[c] = fma(gcol[l], Gm[l * GS + c], gg[c]);
+    }
+    const double d2 = dpost * dpost;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      double v = S.RA[fj * LDJ + Fd[k]];
+      if (k < 6) v = fma(d2, gg[k], v);
+      hr[k] = (lane < n_red && k < n_red) ? v : ((k == lane) ? 1.0 : 0.0);
+    }
+  }
+  WSYNC();
+  // ---- H' into RA (everything else of RA zero: the rotating loops of qp_core<NR> read up to column 2 NR - 2)
+  for (int k = lane; k < NV * LDJ; k += 64) S.RA[k] = 0.0;
+  WSYNC();
+  if (lane < NR) {
+#pragma unroll
+    for (int k = 0; k < NR; k += 2) sts2(S.RA + lane * LDJ + k, hr[k], hr[k + 1]);
+  }
+  WSYNC();
+  STAMP(ts, T_PRE);
+  res = qp_core<NR>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
+  res.iters += nl;                                   // the eliminated equalities, so that `iters` keeps its meaning
+  // ---- x = Z y
+  WSYNC();
+  if (lane < 32) S.xv[lane] = (lane < n_red) ? res.x : 0.0;
+  WSYNC();
+  double x = 0.0;
+  if (my_pos >= 0) x = S.xv[my_pos];
+  else if (my_l >= 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) x = fma(Gm[my_l * GS + c], S.xv[c], x);
+  }
+  res.x = (lane < nv) ? x : 0.0;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // One instance: FK -> Jacobians -> task stack -> H, g, C, bounds [-> QP -> qdot -> q_next]
 // (inputs already staged in S.in)
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
 __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
-                                                 const LaneConst& lc, const InRegs& inr, const int b, const int lane) {
+                                                 const DevPlan& P, const LaneConst& lc, const InRegs& inr, const int b,
+                                                 const int lane) {
   const int nv = M.nv, nq = M.nq, nj = M.njoints;
   const double dt = A.dt, inv_dt = 1.0 / A.dt;   // x * (1/dt) for x / dt: one rounding more than the reference's division
   (void)dt;
@@ -1210,7 +1377,12 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
   STAMP(ts, T_ASM);
 
   // ---- P7/P8: the QP (QP_Wrapper.py:23-73). Padded DoF (lane >= nv) carry no constraint and stay 0.
-  const QpResult res = qp_core(S, g, lb, ub, clb, cub, nv, A.prows, lane, ts);
+  QpResult res;
+#ifdef WBC_PROFILE
+  ts[T_PRE] = 0;
+#endif
+  if (!contact_presolve(S, A, M, cfg, P, dpost, g, lb, ub, clb, cub, lane, ts, res))
+    res = qp_core<NV>(S, g, lb, ub, clb, cub, nv, A.prows, lane, ts);
   if (A.out.qdot && lane < NV) A.out.qdot[(size_t)b * NV + lane] = (lane < nv) ? res.x : 0.0;
   if (lane == 0) {
     if (A.out.status) A.out.status[b] = res.status;
@@ -1237,6 +1409,11 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     atomicAdd(A.prof + 10, ts[T_A2] - ts[T_A1]);    // J'J + posture
     atomicAdd(A.prof + 11, ts[T_A3] - ts[T_A2]);    // constraint rows (incl. trunk Euler angles)
     atomicAdd(A.prof + 12, ts[T_ASM] - ts[T_A3]);   // damper bounds
+    if (ts[T_PRE]) {   // contact presolve (inside [3]): total, engaged count, then G / H' g' / C' rows / H' store
+      atomicAdd(A.prof + 13, ts[T_PRE] - ts[T_ASM]); atomicAdd(A.prof + 14, 1ull);
+      atomicAdd(A.prof + 16, ts[T_P1] - ts[T_ASM]); atomicAdd(A.prof + 17, ts[T_P2] - ts[T_P1]);
+      atomicAdd(A.prof + 18, ts[T_P3] - ts[T_P2]); atomicAdd(A.prof + 19, ts[T_PRE] - ts[T_P3]);
+    }
   }
 #endif
 }
@@ -1247,7 +1424,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, const DevModel* __restrict__ models,
-                                                         const WbcConfig* __restrict__ cfgs) {
+                                                         const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   // models / cfgs are separate __restrict__ const parameters so that the compiler may read them with scalar loads
   // (as members of A it must assume the kernel's own stores clobber them: every access became a vector load + full wait).
   // ONE instance per single-wave workgroup, no loop: inside a persistent loop the compiler hoists hundreds of
@@ -1268,7 +1445,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
   const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);   // L1/L2-resident 3 KB table
   stage_inputs(S, cur, lane, has2, has3);
   WSYNC();
-  process_instance<MODE>(S, A, models[mid], cfgs[mid], lc, cur, b, lane);
+  process_instance<MODE>(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane);
 }
 
 // Stand-alone QP (QP_Wrapper.QP.solveQP): H, g (or A, b) and constraints straight from HBM.
@@ -1348,7 +1525,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
     WSYNC();
     unsigned long long ts[T_NN];
     (void)ts;
-    const QpResult res = qp_core(S, g, lb, ub, clb, cub, n, p, lane, ts);
+    const QpResult res = qp_core<NV>(S, g, lb, ub, clb, cub, n, p, lane, ts);
     if (lane < n) A.x[(size_t)b * n + lane] = res.x;
     if (lane == 0) {
       if (A.status) A.status[b] = res.status;
@@ -1581,9 +1758,9 @@ static int check_launch(const char* what) {
 
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (mode == MODE_TICK) hipLaunchKernelGGL(wbc_tick_kernel<MODE_TICK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs);
-  else if (mode == MODE_ASSEMBLE) hipLaunchKernelGGL(wbc_tick_kernel<MODE_ASSEMBLE>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs);
-  else hipLaunchKernelGGL(wbc_tick_kernel<MODE_FK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs);
+  if (mode == MODE_TICK) hipLaunchKernelGGL(wbc_tick_kernel<MODE_TICK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
+  else if (mode == MODE_ASSEMBLE) hipLaunchKernelGGL(wbc_tick_kernel<MODE_ASSEMBLE>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
+  else hipLaunchKernelGGL(wbc_tick_kernel<MODE_FK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
   return check_launch("tick");
 }
 int launch_qp(const QpArgs& a, int grid, void* stream) {

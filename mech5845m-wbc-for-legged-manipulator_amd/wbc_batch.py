@@ -95,7 +95,7 @@ class WbcBatch:
 
     def debug_cycles(self):
         """per-phase cycle sums since the last call (profile build only; see include/wbc.h)."""
-        out = (C.c_uint64 * 16)()
+        out = (C.c_uint64 * 24)()
         capi.check(self.lib.wbc_debug_cycles(self._h, out), self.lib)
         return [int(v) for v in out]
 

@@ -229,6 +229,37 @@ def test_tick_custom_posture_and_q_con(wx200):
     bt.close()
 
 
+@pytest.mark.parametrize("cfg_name", ["c3", "c2", "everything", "hybrid_grip_com"])
+def test_contact_presolve_and_general_path_agree(wx200, px100, cfg_name):
+    """The structural elimination of the stance-foot equalities (default) and the general path (option presolve = 0)
+    solve the same QP: both within tolerance of the oracle, same status, on both morphologies (n' = 14 and 13)."""
+    B = 768
+    models = [wx200, px100]
+    cfgs = [common.config(cfg_name, m) for m in models]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=51 + i, with_rot=(cfg_name == "everything")) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    res = {}
+    for presolve in (1, 0):
+        bt.set_option("presolve", presolve)
+        res[presolve] = bt.tick(d, DT, want_q_next=True)
+        assert (res[presolve]["status"] == ref["status"]).all(), presolve
+    ok = ref["status"] == 0
+    assert ok.mean() > 0.9
+    e1 = np.abs(res[1]["qdot"] - ref["qdot"])[ok].max()
+    e0 = np.abs(res[0]["qdot"] - ref["qdot"])[ok].max()
+    print("%s: presolve err %.3e, general err %.3e, iters %.2f / %.2f / oracle %.2f" % (
+        cfg_name, e1, e0, res[1]["iters"][ok].mean(), res[0]["iters"][ok].mean(), ref["iters"][ok].mean()))
+    assert e1 < QDOT_TOL and e0 < QDOT_TOL
+    assert np.abs(res[1]["qdot"] - res[0]["qdot"])[ok].max() < QDOT_TOL
+    bt.close()
+
+
 def test_tick_mixed_morphology(wx200, px100):
     """BASELINE config 5: wx200 (nv 26) and px100 (nv 25, padded DoF) interleaved lane by lane."""
     B = 1024

@@ -18,6 +18,8 @@ bt = WbcBatch(model, B)
 assert b"PROFILE" in bt.lib.wbc_version(), "set WBC_HIP_LIB to the profile build"
 bt.configure(cfg)
 bt.set_option("jtj_mfma", int(mfma))
+if os.environ.get("WBC_PRESOLVE") is not None:
+    bt.set_option("presolve", int(os.environ["WBC_PRESOLVE"]))
 fk = lambda q: bt.fk(q, want=("oMf",))["oMf"]
 d = wbc_workload.make_tick_inputs(model, cfg, B, 0, fk)
 dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d.items()}
@@ -33,4 +35,6 @@ for i in range(1, 8):
     out[names[i]] = c[i] / n
 out["total"] = sum(c[1:8]) / n
 out["task_sub"] = dict(rows_targets=c[9] / n, jtj_posture=c[10] / n, constraint_rows=c[11] / n, damper=c[12] / n)
+e = max(1, c[14])
+out["presolve"] = dict(engaged_frac=c[14] / n, cycles=c[13] / e, G=c[16] / e, Hred_gred=c[17] / e, C_rows=c[18] / e, store=c[19] / e)
 print(json.dumps(out))
