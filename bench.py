@@ -91,6 +91,8 @@ def main():
     bt.configure(cfg)
     if args.jtj_mfma:
         bt.set_option("jtj_mfma", 1)
+    if os.environ.get("WBC_DBG_ALIAS"):
+        bt.set_option("dbg_alias_inputs", 1)
 
     class GpuFK:   # inputs are placed on the robot with the product's own FK (never the oracle's)
         def __call__(self, q):

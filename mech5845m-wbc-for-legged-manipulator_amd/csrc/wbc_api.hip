@@ -41,6 +41,7 @@ struct WbcBatch {
   int mrows, prows, mcart;
   int jtj_mfma;
   int presolve;
+  int dbg_alias;
   unsigned long long* d_prof;
   double *d_pu, *d_pq;   // qpJointb MANI/HYBRID results: u [max_batch][26], q_after [max_batch][27] (lazy)
   void* d_roll;          // wbc_rollout's mutable controller state for max_batch instances (lazy)
@@ -207,6 +208,17 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
   if (n_red > WBC_PLAN_NR || n_red < 6 || p_keep + (c.use_bounds ? 3 * nelim : 0) > WBC_MAX_P) return;
   int cnt = 0;
   for (int d = 0; d < M.nv; ++d) if (!((legmask >> d) & 1u)) { P->pos[d] = cnt; P->Fd[cnt++] = d; }
+  // kept rows in findConstraints order: CoM (whole-body support), trunk box (trunk frame), Grip contact
+  {
+    int r = 0;
+    if (c.con_com) { P->legrows |= 3u << r; r += 2; }
+    if (c.con_trunk) { if (M.frame_support[WBC_FR_TRUNK] & legmask) P->legrows |= 15u << r; r += 4; }
+    for (int e = 0; e < WBC_NEE; ++e) {
+      if (!c.con_ee[e]) continue;
+      if (!((P->elimrows >> r) & 1u) && (M.frame_support[WBC_FR_EE0 + e] & legmask)) P->legrows |= 7u << r;
+      r += 3;
+    }
+  }
   P->nelim = nelim; P->n_red = n_red; P->p_keep = p_keep; P->enabled = 1;
 }
 
@@ -246,6 +258,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!b || !name) return fail(WBC_E_ARG, "wbc_batch_set_option: null");
   if (!strcmp(name, "jtj_mfma")) { b->jtj_mfma = value; return WBC_OK; }
   if (!strcmp(name, "presolve")) { b->presolve = value; return WBC_OK; }
+  if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
   if (!strcmp(name, "grid")) { if (value < 1) return fail(WBC_E_ARG, "grid must be >= 1"); b->grid = value; return WBC_OK; }
   return fail(WBC_E_ARG, "unknown option %s", name);
 }
@@ -370,7 +383,7 @@ static int auto_posture(WbcBatch* b, KernelArgs& a, int B, void* stream) {
 static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
   memset(&a, 0, sizeof a);
   a.models = b->d_models; a.cfgs = b->d_cfgs; a.plans = b->d_plans;
-  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma; a.presolve = b->presolve; a.dt = dt;
+  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma; a.presolve = b->presolve; a.dbg_alias = b->dbg_alias; a.dt = dt;
   a.prof = b->d_prof;
   if (b->n_models > 0) { a.fk_nj = b->models[0]->blob.njoints; a.fk_nf = b->models[0]->blob.nframes; }
 }

@@ -34,7 +34,8 @@ struct DevModel {
 struct DevPlan {
   int32_t enabled, nelim, n_red, p_keep;
   uint32_t elimrows;                 // bit i: constraint row i belongs to an eliminated foot
-  int32_t pad_[3];
+  uint32_t legrows;                  // bit i: kept constraint row i has support on eliminated leg DoF (needs C Z)
+  int32_t pad_[2];
   int32_t rowstart[4];               // first constraint row of eliminated foot f
   int32_t legd[12];                  // DoF index of eliminated leg DoF l (feet in constraint order, DoF ascending)
   int32_t Fd[WBC_PLAN_NR];           // DoF index of reduced variable k (0 beyond n_red)
@@ -49,6 +50,7 @@ struct KernelArgs {
   const WbcConfig* cfgs;
   const DevPlan* plans;
   int32_t B, mrows, prows, mcart;   // mcart = Cartesian task rows (excludes the diagonal posture block)
+  int32_t dbg_alias, pad1_;         // diagnostic: every wave loads instance 0's inputs (isolates HBM input latency)
   int32_t jtj_mfma, presolve;  // presolve: structural elimination of the contact equalities (default on)
   int32_t fk_nj, fk_nf;             // oMi / oMf output strides (sizes of model 0)
   unsigned long long* prof;         // WBC_PROFILE builds: per-phase cycle sums [16] (else unused)

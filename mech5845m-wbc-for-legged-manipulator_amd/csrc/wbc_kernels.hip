@@ -57,7 +57,7 @@ constexpr int MAXE = NV;                // equalities the QR keeps in registers 
 #define STAMP(ts, i) do { } while (0)
 #endif
 enum { T_START = 0, T_FK = 1, T_ASM = 2, T_CHOL = 3, T_INV = 4, T_EQ = 5, T_INEQ = 6, T_END = 7, T_N = 8,
-       T_A1 = 8, T_A2 = 9, T_A3 = 10, T_PRE = 11, T_P1 = 12, T_P2 = 13, T_P3 = 14, T_NN = 15 };   // sub-stamps inside the task-stack phase (profile build)
+       T_A1 = 8, T_A2 = 9, T_A3 = 10, T_PRE = 11, T_P1 = 12, T_P2 = 13, T_P3 = 14, T_F1 = 15, T_F2 = 16, T_ENTRY = 17, T_NN = 18 };   // sub-stamps inside the task-stack phase (profile build)
 
 // ---------------------------------------------------------------------------------------------- lane helpers
 __device__ __forceinline__ double rfl(double v) {
@@ -844,9 +844,13 @@ __device__ __forceinline__ void jac_column(const double* const oMi, const LaneCo
 struct FkOut { double lin[3], ang[3], com[3], jc[3], Rtr[9], ptr[3]; };
 // P1..P3 + frames + CoM. oMi and (oMi + OFF_MC) are scratch in LDS; frame origins go to S.pf.
 __device__ __forceinline__ void fk_pass(Smem& S, double* const oMi, const double* const qv, const DevModel& M,
-                                        const LaneConst& lc, const bool need_com, const int lane, FkOut& o) {
+                                        const LaneConst& lc, const bool need_com, const int lane, FkOut& o,
+                                        unsigned long long* ts = nullptr) {
   const int nv = M.nv, nj = M.njoints;
   fk_levels(oMi, qv, M, lc, lane);
+#ifdef WBC_PROFILE
+  if (ts) STAMP(ts, T_F1);
+#endif
   // ---- P2: frame origins, pin.updateFramePlacements (Robot_Wrapper4.py:405); frames carry no rotation offset
   if (lane < M.nframes) {
     const double* Pj = oMi + lc.fj_off;
@@ -864,6 +868,9 @@ __device__ __forceinline__ void fk_pass(Smem& S, double* const oMi, const double
   }
   WSYNC();
   jac_column(oMi, lc, lane, nv, o.lin, o.ang);
+#ifdef WBC_PROFILE
+  if (ts) STAMP(ts, T_F2);
+#endif
   o.com[0] = o.com[1] = o.com[2] = 0.0; o.jc[0] = o.jc[1] = o.jc[2] = 0.0;   // whole-body CoM (uniform), column of Jcom
   if (need_com) {
     double ms = 0, s0 = 0, s1 = 0, s2 = 0;
@@ -928,7 +935,7 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
   for (int k = 0; k < NR; ++k) Fd[k] = P.Fd[k];
 #pragma unroll
   for (int f = 0; f < 4; ++f) rowstart[f] = P.rowstart[f];
-  const unsigned elimrows = P.elimrows;
+  const unsigned elimrows = P.elimrows, legrows = P.legrows;
 #pragma unroll
   for (int l = 0; l < 12; ++l) asm volatile("" : "+s"(legd[l]));
 #pragma unroll
@@ -946,31 +953,30 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
   for (int l = 0; l < 12; ++l) { my_l = (lane == legd[l] && l < nl) ? l : my_l; my_legd = (lane - p_keep == l) ? legd[l] : my_legd; }
   if (lane < 32) { S.npv[lane] = (lane < nv) ? g : 0.0; S.xv[lane] = lb; S.yv[lane] = ub; }
 
-  // ---- G_e = -K_e^-1 B_e per foot: K_e^-1 by the adjugate (uniform), lane c < 6 owns column c of B_e / G_e
+  // ---- G_e = -K_e^-1 B_e, all feet at once: lane 6 f + c owns column c of foot f (K_f^-1 by the adjugate, computed by
+  // each of the foot's six lanes)
   bool singular = false;
+  {
+    const int f = (lane < 24) ? lane / 6 : 0, c = (lane < 24) ? lane - 6 * f : 0;
+    int d0 = legd[0], d1 = legd[1], d2 = legd[2], rs = rowstart[0];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    if (f < nelim) {
-      const int d0 = legd[3 * f], d1 = legd[3 * f + 1], d2 = legd[3 * f + 2];
-      const double* r0 = Cm + rowstart[f] * LDJ; const double* r1 = r0 + LDJ; const double* r2 = r1 + LDJ;
-      const double k00 = r0[d0], k01 = r0[d1], k02 = r0[d2], k10 = r1[d0], k11 = r1[d1], k12 = r1[d2],
-                   k20 = r2[d0], k21 = r2[d1], k22 = r2[d2];
-      const int c = lane < 6 ? lane : 0;
-      const double b0 = r0[c], b1 = r1[c], b2 = r2[c];
-      const double a00 = k11 * k22 - k12 * k21, a01 = k02 * k21 - k01 * k22, a02 = k01 * k12 - k02 * k11;
-      const double a10 = k12 * k20 - k10 * k22, a11 = k00 * k22 - k02 * k20, a12 = k02 * k10 - k00 * k12;
-      const double a20 = k10 * k21 - k11 * k20, a21 = k01 * k20 - k00 * k21, a22 = k00 * k11 - k01 * k10;
-      const double det = k00 * a00 + k01 * a10 + k02 * a20;
-      const double sc = fabs(k00) + fabs(k01) + fabs(k02) + fabs(k10) + fabs(k11) + fabs(k12) + fabs(k20) + fabs(k21) + fabs(k22);
-      if (!(fabs(det) > 1e-7 * sc * sc * sc)) singular = true;       // leg block (nearly) rank deficient: keep the general path
-      const double id = -1.0 / det;
-      if (lane < 6) {
-        Gm[(3 * f + 0) * GS + lane] = id * (a00 * b0 + a01 * b1 + a02 * b2);
-        Gm[(3 * f + 1) * GS + lane] = id * (a10 * b0 + a11 * b1 + a12 * b2);
-        Gm[(3 * f + 2) * GS + lane] = id * (a20 * b0 + a21 * b1 + a22 * b2);
-      }
-    } else if (lane < 6) {
-      Gm[(3 * f + 0) * GS + lane] = 0.0; Gm[(3 * f + 1) * GS + lane] = 0.0; Gm[(3 * f + 2) * GS + lane] = 0.0;
+    for (int t = 1; t < 4; ++t) { const bool m = f == t; d0 = m ? legd[3 * t] : d0; d1 = m ? legd[3 * t + 1] : d1; d2 = m ? legd[3 * t + 2] : d2; rs = m ? rowstart[t] : rs; }
+    const double* r0 = Cm + rs * LDJ; const double* r1 = r0 + LDJ; const double* r2 = r1 + LDJ;
+    const double k00 = r0[d0], k01 = r0[d1], k02 = r0[d2], k10 = r1[d0], k11 = r1[d1], k12 = r1[d2],
+                 k20 = r2[d0], k21 = r2[d1], k22 = r2[d2];
+    const double b0 = r0[c], b1 = r1[c], b2 = r2[c];
+    const double a00 = k11 * k22 - k12 * k21, a01 = k02 * k21 - k01 * k22, a02 = k01 * k12 - k02 * k11;
+    const double a10 = k12 * k20 - k10 * k22, a11 = k00 * k22 - k02 * k20, a12 = k02 * k10 - k00 * k12;
+    const double a20 = k10 * k21 - k11 * k20, a21 = k01 * k20 - k00 * k21, a22 = k00 * k11 - k01 * k10;
+    const double det = k00 * a00 + k01 * a10 + k02 * a20;
+    const double sc = fabs(k00) + fabs(k01) + fabs(k02) + fabs(k10) + fabs(k11) + fabs(k12) + fabs(k20) + fabs(k21) + fabs(k22);
+    const bool live = lane < 6 * nelim;
+    singular = __ballot(live && !(fabs(det) > 1e-7 * sc * sc * sc)) != 0;   // a leg block (nearly) rank deficient: general path
+    const double id = -1.0 / det;
+    if (lane < 24) {
+      Gm[(3 * f + 0) * GS + c] = live ? id * (a00 * b0 + a01 * b1 + a02 * b2) : 0.0;
+      Gm[(3 * f + 1) * GS + c] = live ? id * (a10 * b0 + a11 * b1 + a12 * b2) : 0.0;
+      Gm[(3 * f + 2) * GS + c] = live ? id * (a20 * b0 + a21 * b1 + a22 * b2) : 0.0;
     }
   }
   if (singular) return false;
@@ -994,8 +1000,10 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
   for (int i = 0; i < p; ++i) {
     if ((elimrows >> i) & 1u) continue;
     double v = (lane < n_red) ? Cm[i * LDJ + fj] : 0.0;
+    if ((legrows >> i) & 1u) {                          // rows without leg support (the trunk box) need no G
 #pragma unroll
-    for (int l = 0; l < 12; ++l) v = fma(gcol[l], Cm[i * LDJ + legd[l]], v);
+      for (int l = 0; l < 12; ++l) v = fma(gcol[l], Cm[i * LDJ + legd[l]], v);
+    }
     const double bl = rdl(clb, i), bu = rdl(cub, i);
     WSYNC();
     if (lane < NV) Cm[i2 * LDJ + lane] = v;
@@ -1064,7 +1072,7 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
 template <int MODE>
 __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
                                                  const DevPlan& P, const LaneConst& lc, const InRegs& inr, const int b,
-                                                 const int lane) {
+                                                 const int lane, const unsigned long long t_entry = 0) {
   const int nv = M.nv, nq = M.nq, nj = M.njoints;
   const double dt = A.dt, inv_dt = 1.0 / A.dt;   // x * (1/dt) for x / dt: one rounding more than the reference's division
   (void)dt;
@@ -1072,12 +1080,18 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
   const double* const qv = S.in + IN_Q;
   unsigned long long ts[T_NN];
   (void)ts;
+#ifdef WBC_PROFILE
+  // drain the start-up loads before the first stamp: in this build the per-phase atomics congest the memory system and
+  // would otherwise be charged to the FK phase (measured: 22k of its 28k cycles). Load latency is measured on the
+  // shipped build instead (bench.py with option dbg_alias_inputs).
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
   STAMP(ts, T_START);
 
   // ---- P1..P3: forward kinematics, frames, Jacobian columns, CoM (updateState, Robot_Wrapper4.py:400-405, 670)
   const bool need_com = cfg.task_com || cfg.con_com || (MODE == MODE_FK && (A.fk.com || A.fk.Jcom));
   FkOut fo;
-  fk_pass(S, oMi, qv, M, lc, need_com, lane, fo);
+  fk_pass(S, oMi, qv, M, lc, need_com, lane, fo, ts);
   double (&lin)[3] = fo.lin; double (&ang)[3] = fo.ang; double (&com)[3] = fo.com; double (&jc)[3] = fo.jc;
   double (&Rtr)[9] = fo.Rtr; double (&ptr)[3] = fo.ptr;
 
@@ -1414,6 +1428,8 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
       atomicAdd(A.prof + 16, ts[T_P1] - ts[T_ASM]); atomicAdd(A.prof + 17, ts[T_P2] - ts[T_P1]);
       atomicAdd(A.prof + 18, ts[T_P3] - ts[T_P2]); atomicAdd(A.prof + 19, ts[T_PRE] - ts[T_P3]);
     }
+    atomicAdd(A.prof + 23, ts[T_START] - t_entry);   // kernel entry -> inputs staged (load latency)
+    atomicAdd(A.prof + 20, ts[T_F1] - ts[T_START]); atomicAdd(A.prof + 21, ts[T_F2] - ts[T_F1]); atomicAdd(A.prof + 22, ts[T_FK] - ts[T_F2]);
   }
 #endif
 }
@@ -1434,6 +1450,11 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
   __shared__ Smem S;
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
+#ifdef WBC_PROFILE
+  const unsigned long long t_entry = clock64();
+#else
+  const unsigned long long t_entry = 0;
+#endif
   S.cl[lane] = 0.0;                            // zero padding the rotating loops rely on (never written above entry 25)
   if (lane < LDJ) S.RApad[lane] = 0.0;
   const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
@@ -1441,11 +1462,11 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
   const bool has3 = A.in.ee_ref_rot != nullptr;
   // the model index is wave-uniform: say so, or every M.* / cfg.* access becomes a vector load
   const int mid = A.in.model_id ? __builtin_amdgcn_readfirstlane(A.in.model_id[b]) : 0;
-  const InRegs cur = load_inputs(A.in, b, lane, has2, has3);
+  const InRegs cur = load_inputs(A.in, A.dbg_alias ? 0 : b, lane, has2, has3);   // dbg_alias: diagnostic, every wave reads instance 0
   const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);   // L1/L2-resident 3 KB table
   stage_inputs(S, cur, lane, has2, has3);
   WSYNC();
-  process_instance<MODE>(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane);
+  process_instance<MODE>(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane, t_entry);
 }
 
 // Stand-alone QP (QP_Wrapper.QP.solveQP): H, g (or A, b) and constraints straight from HBM.

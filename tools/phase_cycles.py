@@ -37,4 +37,6 @@ out["total"] = sum(c[1:8]) / n
 out["task_sub"] = dict(rows_targets=c[9] / n, jtj_posture=c[10] / n, constraint_rows=c[11] / n, damper=c[12] / n)
 e = max(1, c[14])
 out["presolve"] = dict(engaged_frac=c[14] / n, cycles=c[13] / e, G=c[16] / e, Hred_gred=c[17] / e, C_rows=c[18] / e, store=c[19] / e)
+out["entry_to_start"] = c[23] / n
+out["fk_sub"] = dict(levels=c[20] / n, frames_columns=c[21] / n, com_trunk=c[22] / n)
 print(json.dumps(out))
