@@ -32,6 +32,7 @@ struct WbcBatch {
   int device_id, n_models, max_batch, grid;
   const WbcModel* models[WBC_MAX_MODELS];
   WbcConfig cfg_host[WBC_MAX_MODELS];
+  DevPlan plan_host[WBC_MAX_MODELS];
   bool configured[WBC_MAX_MODELS];
   DevModel* d_models;
   WbcConfig* d_cfgs;
@@ -41,6 +42,8 @@ struct WbcBatch {
   int mrows, prows, mcart;
   int jtj_mfma;
   int presolve;
+  int sim3_kernel;       // 1 (default): batches that qualify run on wbc_tick_sim3_kernel (compact LDS) + a deferred pass
+  int32_t* d_status;     // status buffer of our own when the caller passes none (the deferred pass needs one)
   int dbg_alias;
   unsigned long long* d_prof;
   double *d_pu, *d_pq;   // qpJointb MANI/HYBRID results: u [max_batch][26], q_after [max_batch][27] (lazy)
@@ -132,7 +135,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   WbcBatch* b = new (std::nothrow) WbcBatch;
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
-  b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1;
+  b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->sim3_kernel = 1;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
@@ -165,6 +168,7 @@ extern "C" void wbc_batch_destroy(WbcBatch* b) {
   if (b->d_pu) (void)hipFree(b->d_pu);
   if (b->d_pq) (void)hipFree(b->d_pq);
   if (b->d_roll) (void)hipFree(b->d_roll);
+  if (b->d_status) (void)hipFree(b->d_status);
   delete b;
 }
 
@@ -208,6 +212,9 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
   if (n_red > WBC_PLAN_NR || n_red < 6 || p_keep + (c.use_bounds ? 3 * nelim : 0) > WBC_MAX_P) return;
   int cnt = 0;
   for (int d = 0; d < M.nv; ++d) if (!((legmask >> d) & 1u)) { P->pos[d] = cnt; P->Fd[cnt++] = d; }
+  for (int f = 0; f < M.nframes; ++f)
+    for (int d = 0; d < M.nv; ++d)
+      if (((M.frame_support[f] >> d) & 1u) && P->pos[d] >= 0) P->redsup[f] |= 1u << P->pos[d];
   // kept rows in findConstraints order: CoM (whole-body support), trunk box (trunk frame), Grip contact
   {
     int r = 0;
@@ -243,10 +250,12 @@ extern "C" int wbc_batch_configure(WbcBatch* b, int mi, const WbcConfig* cfg) {
   HIP_TRY(hipSetDevice(b->device_id));
   b->cfg_host[mi] = *cfg;
   b->configured[mi] = true;
+  b->plan_host[mi] = DevPlan();
   b->mrows = m; b->prows = p; b->mcart = mcart;
   HIP_TRY(hipMemcpy(b->d_cfgs + mi, cfg, sizeof *cfg, hipMemcpyHostToDevice));
   DevPlan plan;
   build_plan(b->models[mi]->dev, *cfg, p, &plan);
+  b->plan_host[mi] = plan;
   HIP_TRY(hipMemcpy(b->d_plans + mi, &plan, sizeof plan, hipMemcpyHostToDevice));
   return WBC_OK;
 }
@@ -258,6 +267,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!b || !name) return fail(WBC_E_ARG, "wbc_batch_set_option: null");
   if (!strcmp(name, "jtj_mfma")) { b->jtj_mfma = value; return WBC_OK; }
   if (!strcmp(name, "presolve")) { b->presolve = value; return WBC_OK; }
+  if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
   if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
   if (!strcmp(name, "grid")) { if (value < 1) return fail(WBC_E_ARG, "grid must be >= 1"); b->grid = value; return WBC_OK; }
   return fail(WBC_E_ARG, "unknown option %s", name);
@@ -388,6 +398,35 @@ static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
   if (b->n_models > 0) { a.fk_nj = b->models[0]->blob.njoints; a.fk_nf = b->models[0]->blob.nframes; }
 }
 
+// The fused tick on the best kernel for the batch: wbc_tick_sim3_kernel (compact LDS, reduced QP only) when every
+// model's plan is enabled and the problem fits its layout, followed by an early-exit pass of the general kernel over
+// the instances it deferred (singular leg block); otherwise the general kernel alone. `a` holds device pointers.
+static bool sim3_eligible(const WbcBatch* b, const KernelArgs& a) {
+  if (!b->sim3_kernel || !b->presolve || b->n_models < 1) return false;
+  if (a.in.ee_ref_rot || a.in.com_target || a.in.com_target_vel) return false;
+  if (b->prows > WBC_SIM3_MAXP || b->mcart > 12) return false;
+  for (int i = 0; i < b->n_models; ++i) {
+    const DevPlan& P = b->plan_host[i];
+    if (!P.enabled || P.p_keep + (b->cfg_host[i].use_bounds ? 3 * P.nelim : 0) > WBC_SIM3_MAXP) return false;
+  }
+  return true;
+}
+static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
+  if (!sim3_eligible(b, a)) {
+    if (int e = launch_tick(a, MODE_TICK, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return WBC_OK;
+  }
+  if (!a.out.status) {
+    if (!b->d_status) HIP_TRY(hipMalloc((void**)&b->d_status, sizeof(int32_t) * (size_t)b->max_batch));
+    a.out.status = b->d_status;
+  }
+  if (int e = launch_tick_sim3(a, B, stream)) return fail(WBC_E_HIP, "sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  a.only_deferred = 1;
+  if (int e = launch_tick(a, MODE_TICK, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "tick kernel (deferred pass) launch failed: %s", hipGetErrorString((hipError_t)e));
+  a.only_deferred = 0;
+  return WBC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- entry points
 extern "C" int wbc_fk_jacobians(WbcBatch* b, int B, const double* q, const int32_t* model_id, int mem,
                                 const WbcFkOut* out, void* stream) {
@@ -450,7 +489,7 @@ extern "C" int wbc_tick(WbcBatch* b, int B, const WbcTickIn* in, double dt, int 
   st.out(&a.out.qdot, n * WBC_V_STRIDE); st.out(&a.out.status, n); st.out(&a.out.iters, n); st.out(&a.out.q_next, n * WBC_Q_STRIDE);
   if ((rc = st.stage())) return rc;
   if ((rc = auto_posture(b, a, B, stream))) return rc;
-  if (int e = launch_tick(a, MODE_TICK, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  if ((rc = launch_tick_auto(b, a, B, stream))) return rc;
   return st.finish();
 }
 
@@ -552,7 +591,7 @@ extern "C" int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, 
   for (int k = 0; k < r->ticks; ++k) {
     a.in = loop_in;                       // auto_posture fills posture_u / q_con afresh every tick
     if ((rc = auto_posture(b, a, B, stream))) return rc;
-    if (int e = launch_tick(a, MODE_TICK, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if ((rc = launch_tick_auto(b, a, B, stream))) return rc;
     u.grip_trace = ro.grip_trace ? ro.grip_trace + (size_t)k * n * 3 : nullptr;
     if (int e = launch_update(u, B, stream)) return fail(WBC_E_HIP, "update kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   }

@@ -31,6 +31,8 @@ struct DevModel {
 // Structural presolve plan of one (model, configuration): which stance feet's contact equalities are eliminated and
 // the index maps of the reduced problem (built by wbc_batch_configure, read with scalar loads by the tick kernel).
 #define WBC_PLAN_NR 16
+#define WBC_SIM3_MAXP 16                // constraint rows (original and reduced) the compact sim3 kernel holds
+constexpr int WBC_QP_DEFERRED = -1;     // internal status: set by wbc_tick_sim3_kernel, never visible to the caller
 struct DevPlan {
   int32_t enabled, nelim, n_red, p_keep;
   uint32_t elimrows;                 // bit i: constraint row i belongs to an eliminated foot
@@ -39,6 +41,7 @@ struct DevPlan {
   int32_t rowstart[4];               // first constraint row of eliminated foot f
   int32_t legd[12];                  // DoF index of eliminated leg DoF l (feet in constraint order, DoF ascending)
   int32_t Fd[WBC_PLAN_NR];           // DoF index of reduced variable k (0 beyond n_red)
+  uint32_t redsup[WBC_MAX_FRAMES];   // frame f: bit k = reduced variable k moves the frame (frame_support mapped through pos)
   int32_t pos[32];                   // DoF d -> reduced position (-1: eliminated / absent)
   int32_t lidx[32];                  // DoF d -> l (-1: not an eliminated leg DoF)
 };
@@ -50,7 +53,8 @@ struct KernelArgs {
   const WbcConfig* cfgs;
   const DevPlan* plans;
   int32_t B, mrows, prows, mcart;   // mcart = Cartesian task rows (excludes the diagonal posture block)
-  int32_t dbg_alias, pad1_;         // diagnostic: every wave loads instance 0's inputs (isolates HBM input latency)
+  int32_t dbg_alias;                // diagnostic: every wave loads instance 0's inputs (isolates HBM input latency)
+  int32_t only_deferred;            // general tick kernel, second pass: only the instances wbc_tick_sim3_kernel left as WBC_QP_DEFERRED
   int32_t jtj_mfma, presolve;  // presolve: structural elimination of the contact equalities (default on)
   int32_t fk_nj, fk_nf;             // oMi / oMf output strides (sizes of model 0)
   unsigned long long* prof;         // WBC_PROFILE builds: per-phase cycle sums [16] (else unused)
@@ -105,6 +109,8 @@ struct UpdateArgs {
 
 // launchers (wbc_kernels.hip); grid = min(B, waves) persistent single-wave workgroups
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream);
+int launch_tick_sim3(const KernelArgs& a, int grid, void* stream);
+int sim3_lds_bytes();
 int launch_qp(const QpArgs& a, int grid, void* stream);
 int launch_integrate(const IntegrateArgs& a, int grid, void* stream);
 int launch_posture(const PostureArgs& a, int grid, void* stream);

@@ -151,7 +151,8 @@ __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
 // Free-flyer part of pin.integrate (Robot_Wrapper4.py:441): M+ = M exp6(v), v = S.xv[0..5] (body twist * dt), current
 // placement from the quaternion / xyz staged in S.in; quaternion continuity + first-order renormalisation as in
 // pinocchio's SpecialEuclideanOperationTpl<3>::integrate_impl. Uniform arithmetic; lanes 0..6 store.
-__device__ __forceinline__ void integrate_ff(const Smem& S, const int lane, double* qn) {
+template <class SM>
+__device__ __forceinline__ void integrate_ff(const SM& S, const int lane, double* qn) {
   double R0[9];
   quat_to_R(S.in + IN_Q + 3, R0);
   const double p0[3] = {S.in[IN_Q], S.in[IN_Q + 1], S.in[IN_Q + 2]};
@@ -219,8 +220,10 @@ __device__ __forceinline__ void integrate_ff(const Smem& S, const int lane, doub
 // ------------------------------------------------------------------------------------------------
 struct QpResult { double x; int status; int iters; };
 
-template <int NM>   // NM = compiled problem-size cap (even, n <= NM <= NM): register-array sizes and loop trip counts
-__device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const double lb_in, const double ub_in,
+// NM = compiled problem-size cap (even, n <= NM <= 26): register-array sizes and loop trip counts; SM = LDS layout
+// (Smem or the compact SmemC); CS = row stride of the constraint matrix S.RC
+template <int NM, class SM = Smem, int CS = LDJ>
+__device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const double lb_in, const double ub_in,
                                             const double clb_in, const double cub_in, const int n, const int p, const int lane,
                                             unsigned long long* ts) {
   const int li = lane < NM ? lane : NM - 1;
@@ -245,7 +248,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
       double gs = 0.0, cs = 0.0;
 #pragma unroll
       for (int k = 0; k < NM; k += 2) {
-        const double2a h2 = lds2(S.RA + li * LDJ + k); const double2a c2 = lds2(S.RC + ((lane < p) ? lane : 0) * LDJ + k);
+        const double2a h2 = lds2(S.RA + li * LDJ + k); const double2a c2 = lds2(S.RC + ((lane < p) ? lane : 0) * CS + k);
         const double2a f2 = lds2(S.yv + k);
         gs = fma(h2.x, f2.x, fma(h2.y, f2.y, gs)); cs = fma(c2.x, f2.x, fma(c2.y, f2.y, cs));
       }
@@ -258,7 +261,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
     while (m) {
       const int k = ctz64(m); m &= m - 1;
       if (lane < NM) S.RA[lane * LDJ + k] = 0.0;
-      if (lane < p) S.RC[lane * LDJ + k] = 0.0;
+      if (lane < p) S.RC[lane * CS + k] = 0.0;
     }
     if (fixb) {
 #pragma unroll
@@ -322,7 +325,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
   double y[NM];
   {
     const int rl = lane - NM;                           // which right-hand side this lane carries
-    const double* src = (rl >= 0 && rl < p) ? (S.RC + rl * LDJ) : S.npv;
+    const double* src = (rl >= 0 && rl < p) ? (S.RC + rl * CS) : S.npv;
     const bool from_lds = (rl >= 0 && rl <= p);
     double sqn = 0.0;
 #pragma unroll
@@ -490,7 +493,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
       double v = 0.0, vb = 0.0;
 #pragma unroll
       for (int k = 0; k < NM; k += 2) {
-        const double2a c2 = lds2(Cm + (has_r ? lane : 0) * LDJ + k); const double2a x2 = lds2(S.xv + k);
+        const double2a c2 = lds2(Cm + (has_r ? lane : 0) * CS + k); const double2a x2 = lds2(S.xv + k);
         v = fma(c2.x, x2.x, v); vb = fma(c2.y, x2.y, vb);
       }
       LDS_THEN_VALU(NM, NM);
@@ -521,7 +524,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
         double d2 = 0.0;
 #pragma unroll
         for (int i = 0; i < NM; i += 2) {
-          const double2a c2 = lds2(Cm + rr * LDJ + i);
+          const double2a c2 = lds2(Cm + rr * CS + i);
           d = fma(J[i * LDJ + li], c2.x, d);
           d2 = fma(J[(i + 1) * LDJ + li], c2.y, d2);
         }
@@ -623,7 +626,7 @@ __device__ __forceinline__ QpResult qp_core(Smem& S, const double g_in, const do
         if (lane < n) J[lane * LDJ + q - 1] = jx;
         --q;
         WSYNC();
-        const double v = is_row ? wsum(lane < n ? Cm[rr * LDJ + li] * x : 0.0) : rdl(x, ip);
+        const double v = is_row ? wsum(lane < n ? Cm[rr * CS + li] * x : 0.0) : rdl(x, ip);
         s_ip = sgn * v - b_ip;
       }
     }
@@ -783,7 +786,8 @@ __device__ __forceinline__ InRegs load_inputs(const WbcTickIn& in, const int b, 
   }
   return r;
 }
-__device__ __forceinline__ void stage_inputs(Smem& S, const InRegs& r, const int lane, const bool has2, const bool has3) {
+template <class SM>
+__device__ __forceinline__ void stage_inputs(SM& S, const InRegs& r, const int lane, const bool has2, const bool has3) {
   S.in[lane] = r.g1;
   if (has2 && lane < 24) S.in[64 + lane] = r.g2;
   if (has3 && lane < 45) { S.in[IN_ERR + lane] = r.g3a; S.in[IN_EPR + lane] = r.g3b; }
@@ -843,7 +847,8 @@ __device__ __forceinline__ void jac_column(const double* const oMi, const LaneCo
 }
 struct FkOut { double lin[3], ang[3], com[3], jc[3], Rtr[9], ptr[3]; };
 // P1..P3 + frames + CoM. oMi and (oMi + OFF_MC) are scratch in LDS; frame origins go to S.pf.
-__device__ __forceinline__ void fk_pass(Smem& S, double* const oMi, const double* const qv, const DevModel& M,
+template <class SM>
+__device__ __forceinline__ void fk_pass(SM& S, double* const oMi, const double* const qv, const DevModel& M,
                                         const LaneConst& lc, const bool need_com, const int lane, FkOut& o,
                                         unsigned long long* ts = nullptr) {
   const int nv = M.nv, nj = M.njoints;
@@ -1457,6 +1462,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
 #endif
   S.cl[lane] = 0.0;                            // zero padding the rotating loops rely on (never written above entry 25)
   if (lane < LDJ) S.RApad[lane] = 0.0;
+  if (MODE == MODE_TICK && A.only_deferred && __builtin_amdgcn_readfirstlane(A.out.status[b]) != WBC_QP_DEFERRED) return;
   const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
                     A.in.com_target || A.in.com_target_vel;
   const bool has3 = A.in.ee_ref_rot != nullptr;
@@ -1467,6 +1473,419 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
   stage_inputs(S, cur, lane, has2, has3);
   WSYNC();
   process_instance<MODE>(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane, t_entry);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The sim3-tick kernel (compact LDS, 12 workgroups per CU instead of 8): for batches whose every (model, configuration)
+// has a structural presolve plan (DevPlan.enabled: no task touches the stance legs), at most WBC_SIM3_MAXP constraint
+// rows and no orientation references. Same arithmetic as process_instance + contact_presolve, but the QP is assembled
+// directly in its reduced form: the task stack is stored by REDUCED variable (At[k][row], k = DevPlan.pos[dof]), H' is
+// accumulated as a 16 x 16 matrix, the original constraint rows pass through a scratch image (RB) from which G and
+// C' = C Z are read. Only qp_core<16> is compiled in. An instance whose presolve cannot be applied (singular leg block)
+// is marked WBC_QP_DEFERRED and redone by the general kernel in an early-exit second pass.
+// ------------------------------------------------------------------------------------------------
+constexpr int CSC = 18;                      // row stride of the reduced constraint matrix (18 = 2 mod 4, >= NR)
+constexpr int PC = WBC_SIM3_MAXP;            // rows of the reduced constraint matrix (kept rows + leg-bound rows)
+struct __attribute__((aligned(16))) SmemC {
+  double RA[NR * LDJ];                  // oMi + m c (FK) -> H' -> Lt -> B columns -> T
+  double RApad[LDJ];                    // stays zero
+  double RB[NR * LDJ];                  // At[k][row] (task stack by reduced variable) -> second-pass oMi -> original C rows -> J
+  double RC[PC * CSC];                  // C' (reduced constraint rows)
+  double in[128];                       // this instance's inputs (groups 1 and 2)
+  double pf[WBC_MAX_FRAMES * 3];
+  double dv[32], xv[32], npv[32], lv[32], dinv[32], yv[32];
+  double cl[48];                        // Cholesky column broadcast; entries 16..47 stay zero
+  double Gm[12 * GS];                   // G: eliminated leg DoF l (row) x base DoF (column)
+};
+
+// H'[lane][k] += sum_r At[k][row0 + r] At[lane][row0 + r] for the reduced variables k in `mask`
+template <int NRW>
+__device__ __forceinline__ void jtj_block_c(SmemC& S, const double* At, const int mtp, const int row0, unsigned mask,
+                                            const int lane) {
+  const int li = lane < NR ? lane : NR - 1;
+  double a[NRW];
+#pragma unroll
+  for (int r = 0; r < NRW; ++r) a[r] = At[li * mtp + row0 + r];
+#pragma unroll 1
+  while (mask) {
+    const int i0 = __ffs((int)mask) - 1;
+    mask &= mask - 1;
+    const bool two = mask != 0;
+    const int i1 = two ? __ffs((int)mask) - 1 : i0;
+    mask &= mask - 1;
+    double s0 = S.RA[li * LDJ + i0], s1 = S.RA[li * LDJ + i1];
+#pragma unroll
+    for (int r = 0; r < NRW; ++r) { s0 = fma(At[i0 * mtp + row0 + r], a[r], s0); s1 = fma(At[i1 * mtp + row0 + r], a[r], s1); }
+    if (lane < NR) { S.RA[lane * LDJ + i0] = s0; if (two) S.RA[lane * LDJ + i1] = s1; }
+  }
+}
+
+__device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
+                                             const DevPlan& P, const LaneConst& lc, const InRegs& inr, const int b,
+                                             const int lane) {
+  const int nv = M.nv, nq = M.nq;
+  const double dt = A.dt, inv_dt = 1.0 / A.dt;
+  const double* const qv = S.in + IN_Q;
+  unsigned long long* ts = nullptr;
+  // ---- P1..P3 (updateState, Robot_Wrapper4.py:400-405)
+  FkOut fo;
+  fk_pass(S, S.RA, qv, M, lc, cfg.con_com != 0, lane, fo);
+  double (&lin)[3] = fo.lin; double (&ang)[3] = fo.ang; double (&com)[3] = fo.com; double (&jc)[3] = fo.jc;
+  double (&Rtr)[9] = fo.Rtr; double (&ptr)[3] = fo.ptr;
+
+  // ---- the plan's index maps: one batch of scalar loads, per-lane views by select chains
+  const int nelim = P.nelim, n_red = P.n_red, nl = 3 * nelim, p_keep = P.p_keep, p = A.prows;
+  int legd[12], Fd[NR], rowstart[4];
+#pragma unroll
+  for (int l = 0; l < 12; ++l) legd[l] = P.legd[l];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) Fd[k] = P.Fd[k];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) rowstart[f] = P.rowstart[f];
+  const unsigned elimrows = P.elimrows, legrows = P.legrows;
+#pragma unroll
+  for (int l = 0; l < 12; ++l) asm volatile("" : "+s"(legd[l]));
+#pragma unroll
+  for (int k = 0; k < NR; ++k) asm volatile("" : "+s"(Fd[k]));
+#pragma unroll
+  for (int f = 0; f < 4; ++f) asm volatile("" : "+s"(rowstart[f]));
+  int fj = 0, my_pos = -1, my_l = -1, my_legd = 0;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) { fj = (lane == k) ? Fd[k] : fj; my_pos = (lane == Fd[k] && k < n_red) ? k : my_pos; }
+#pragma unroll
+  for (int l = 0; l < 12; ++l) { my_l = (lane == legd[l] && l < nl) ? l : my_l; my_legd = (lane - p_keep == l) ? legd[l] : my_legd; }
+
+  // ---- task stack, pass 1 (qpA / qpb, Robot_Wrapper4.py:1271-1294): lane = DoF; its column goes to At[pos][row]
+  WSYNC();   // every lane is done reading oMi: RA becomes H'
+  double g = 0.0;
+  double* const At = S.RB;
+  const int mtp = (A.mcart + 3) / 4 * 4 + 2;
+  int row = 0;
+  if (lane < NR) {
+#pragma unroll
+    for (int k = 0; k < NR; k += 2) sts2(S.RA + lane * LDJ + k, 0.0, 0.0);
+#pragma unroll
+    for (int k = NR; k < LDJ; k += 2) sts2(S.RA + lane * LDJ + k, 0.0, 0.0);   // the rotating loops read past column 15
+  }
+  const bool stores = my_pos >= 0;
+  const int arow = (stores ? my_pos : 0) * mtp;
+#pragma unroll 1
+  for (int e = 0; e < WBC_NEE; ++e) {
+    if (!cfg.task_ee[e]) continue;
+    const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_EE0 + e] >> lane) & 1u);
+    const double pfe[3] = {S.pf[3 * e], S.pf[3 * e + 1], S.pf[3 * e + 2]};
+    double a[6];
+    {  // endEffectorA2 (Robot_Wrapper4.py:474-484): LOCAL_WORLD_ALIGNED: lin + ang x p_f
+      double wxp[3];
+      cross3(ang, pfe, wxp);
+      const double w = cfg.ee_w[e];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        a[r] = sup ? cfg.ee_W[e][r] * ((lin[r] + wxp[r]) * w) : 0.0;
+        a[3 + r] = sup ? cfg.ee_W[e][3 + r] * (ang[r] * w) : 0.0;
+      }
+    }
+    const double* xt = S.in + IN_EET + 3 * e;
+    const double* xp = S.in + IN_EEP + 3 * e;
+    double vel[6] = {0, 0, 0, 0, 0, 0};   // calcTargetVelEE3 (:1052-1157) with R* == R*_prev (no orientation references here)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) * inv_dt + cfg.ee_gain[e][i] * ((xt[i] - pfe[i]) * inv_dt);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double br = vel[r] * cfg.ee_w[e];                  // EndEffectorB2 (:907-910)
+      g = fma(-a[r], br, g);
+      if (stores) At[arow + row + r] = a[r];
+    }
+    row += 6;
+  }
+  if (cfg.task_trunk) {   // trunkA (Robot_Wrapper4.py:487-490, WORLD), calcTargetVelTrunk2 (:948-1015)
+    const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_TRUNK] >> lane) & 1u);
+    double a[6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      a[r] = sup ? (cfg.trunk_W[r] * lin[r]) * cfg.trunk_w : 0.0;
+      a[3 + r] = sup ? (cfg.trunk_W[3 + r] * ang[r]) * cfg.trunk_w : 0.0;
+    }
+    const double* xt = S.in + IN_TT;
+    const double* xp = S.in + IN_TP;
+    double vel[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) * inv_dt + cfg.trunk_gain[i] * ((xt[i] - ptr[i]) * inv_dt);
+    double fq[4], rq[4], Rs[9];
+    R_to_quat(Rtr, fq);
+    const double* er = S.in + IN_TRE;
+    {
+#pragma unroll 1
+      for (int i = 0; i < 6; ++i) {
+        const SinCos t = sincos_cw(i < 3 ? er[i] : 0.5 * er[i - 3]);
+        if (lane == 0) { S.yv[2 * i] = t.s; S.yv[2 * i + 1] = t.c; }
+      }
+      WSYNC();
+      const double sa = S.yv[0], ca = S.yv[1], sb = S.yv[2], cb = S.yv[3], sc = S.yv[4], cc = S.yv[5];
+      Rs[0] = cc * cb; Rs[1] = cc * sb * sa - sc * ca; Rs[2] = cc * sb * ca + sc * sa;
+      Rs[3] = sc * cb; Rs[4] = sc * sb * sa + cc * ca; Rs[5] = sc * sb * ca - cc * sa;
+      Rs[6] = -sb;     Rs[7] = cb * sa;                Rs[8] = cb * ca;
+      const double qx[4] = {S.yv[6], 0, 0, S.yv[7]}, qy[4] = {0, S.yv[8], 0, S.yv[9]}, qz[4] = {0, 0, S.yv[10], S.yv[11]};
+      double tq[4];
+      quat_mul(qy, qx, tq);
+      quat_mul(qz, tq, rq);
+    }
+    const double qe0 = fq[3] * rq[0] - fq[0] * rq[3] + fq[1] * rq[2] - fq[2] * rq[1];   // :974
+    const double qe1 = fq[3] * rq[1] - fq[1] * rq[3] - fq[0] * rq[2] + fq[2] * rq[0];   // :975
+    const double qe2 = fq[3] * rq[2] - fq[3] * rq[2] + fq[0] * rq[1] - fq[1] * rq[0];   // :976 (sic)
+    const double* Ro = S.in + IN_TPR;
+    double D[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) D[i] = (Rs[i] - Ro[i]) * inv_dt;
+    vel[3] = (D[6] * Rs[1] + D[7] * Rs[4] + D[8] * Rs[7]) + cfg.trunk_gain[3] * qe0;
+    vel[4] = (D[0] * Rs[2] + D[1] * Rs[5] + D[2] * Rs[8]) + cfg.trunk_gain[4] * qe1;
+    vel[5] = (D[3] * Rs[0] + D[4] * Rs[3] + D[5] * Rs[6]) + cfg.trunk_gain[5] * qe2;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double br = vel[r] * cfg.trunk_w;                  // TrunkB (:914-920)
+      g = fma(-a[r], br, g);
+      if (stores) At[arow + row + r] = a[r];
+    }
+    row += 6;
+  }
+  if (lane >= n_red && lane < NR) {   // padded reduced variables carry no task rows
+#pragma unroll 1
+    for (int r = 0; r < A.mcart; ++r) At[lane * mtp + r] = 0.0;
+  }
+  WSYNC();
+  // ---- pass 2: H'[lane][k] = sum_r At[k][r] At[lane][r], block by block over each block's reduced support
+  {
+    int r0 = 0;
+#pragma unroll 1
+    for (int e = 0; e < WBC_NEE; ++e) {
+      if (!cfg.task_ee[e]) continue;
+      jtj_block_c<6>(S, At, mtp, r0, P.redsup[WBC_FR_EE0 + e], lane);
+      r0 += 6;
+    }
+    if (cfg.task_trunk) { jtj_block_c<6>(S, At, mtp, r0, P.redsup[WBC_FR_TRUNK], lane); r0 += 6; }
+  }
+  // posture rows: qpJointA (Robot_Wrapper4.py:1199-1206), qpJointb (:1209-1268); lane = DoF
+  const double dpost = (1.0 / nv) * cfg.joint_w;
+  {
+    double upost = 0.0;
+    if (cfg.task_joint == WBC_JOINT_PREV && lane < nv) upost = qv[lane < 6 ? lane : lane + 1];
+    if (cfg.task_joint >= WBC_JOINT_MANI && lane < nv) upost = inr.pu;
+    const double bj = (1.0 / nv) * upost * cfg.joint_w;
+    if (lane < nv) g = fma(-dpost, bj, g);
+  }
+  if (lane >= nv) g = 0.0;
+  if (lane < NR) S.RA[lane * LDJ + lane] += (lane < n_red) ? dpost * dpost : 1.0;
+  WSYNC();   // At is dead: RB may be reused
+  if (A.in.q_con) {   // the configuration qpJointb MANI/HYBRID left behind: constraints, bounds, integrate see it
+    if (lane < NQ) S.in[IN_Q + lane] = inr.qc;
+    WSYNC();
+    fk_pass(S, S.RB, qv, M, lc, cfg.con_com != 0, lane, fo);
+    WSYNC();
+  }
+
+  // ---- original constraint rows (findConstraints order, Robot_Wrapper4.py:764-836) into the scratch image Co = RB [p][26]
+  double* const Co = S.RB;
+  double clb = 0.0, cub = 0.0;
+  int prow = 0;
+  if (cfg.con_com) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (lane < NV) Co[(prow + r) * LDJ + lane] = jc[r];
+      const double lo = ((S.pf[3 * 2 + r] - com[r]) * inv_dt) * cfg.com_box_scale;
+      const double hi = ((S.pf[3 * 1 + r] - com[r]) * inv_dt) * cfg.com_box_scale;
+      if (lane == prow + r) { clb = lo; cub = hi; }
+    }
+    prow += 2;
+  }
+  if (cfg.con_trunk) {
+    const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_TRUNK] >> lane) & 1u);
+    double wxp[3];
+    cross3(ang, ptr, wxp);
+    const double rowv[4] = {sup ? lin[2] + wxp[2] : 0.0, sup ? ang[0] : 0.0, sup ? ang[1] : 0.0, sup ? ang[2] : 0.0};
+    const double* bc = S.in + IN_BOX;
+    const double ay = (lane == 0) ? Rtr[7] : ((lane == 1) ? -Rtr[6] : Rtr[3]);
+    const double ax = (lane == 0) ? Rtr[8] : ((lane == 1) ? sqrt(fma(Rtr[7], Rtr[7], Rtr[8] * Rtr[8])) : Rtr[0]);
+    const double eul = atan2(ay, ax);
+    const double cur[4] = {ptr[2], rdl(eul, 0), rdl(eul, 1), rdl(eul, 2)};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (lane < NV) Co[(prow + r) * LDJ + lane] = rowv[r];
+    {
+      const int r = lane - prow;
+      const double bcr = (r == 0) ? bc[0] : (r == 1) ? bc[1] : (r == 2) ? bc[2] : bc[3];
+      const double cr = (r == 0) ? cur[0] : (r == 1) ? cur[1] : (r == 2) ? cur[2] : cur[3];
+      const double vr = (r == 0) ? bc[0] * cfg.trunk_box_z_frac : cfg.trunk_box_ang;
+      if (r >= 0 && r < 4) {
+        clb = (((bcr - vr) - cr) * inv_dt) * cfg.trunk_box_scale;
+        cub = (((bcr + vr) - cr) * inv_dt) * cfg.trunk_box_scale;
+      }
+    }
+    prow += 4;
+  }
+#pragma unroll 1
+  for (int e = 0; e < WBC_NEE; ++e) {
+    if (!cfg.con_ee[e]) continue;
+    const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_EE0 + e] >> lane) & 1u);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      if (lane < NV) Co[(prow + r) * LDJ + lane] = sup ? lin[r] : 0.0;
+      if (lane == prow + r) { clb = 0.0; cub = 0.0; }
+    }
+    prow += 3;
+  }
+  // ---- velDamperJointConstraints (Robot_Wrapper4.py:572-637), lane = DoF
+  double lb = 0.0, ub = 0.0;
+  if (lane < nv) {
+    if (!cfg.use_bounds) { lb = -1e30; ub = 1e30; }
+    else {
+      const double qi = qv[lc.dq_idx], lo = lc.d_lo, hi = lc.d_hi, vm = lc.d_vm;
+      if (qi <= lo + cfg.damper_qi) {
+        lb = -cfg.damper_coef * (qi - lo - cfg.damper_qs) / (cfg.damper_qi - cfg.damper_qs);
+        if (lb > vm) lb = vm;
+        if (lb < -vm) lb = -vm;
+      } else lb = -vm;
+      if (qi >= hi - cfg.damper_qi) {
+        ub = cfg.damper_coef * (hi - qi - cfg.damper_qs) / (cfg.damper_qi - cfg.damper_qs);
+        if (ub < -vm) ub = -vm;
+        if (ub > vm) ub = vm;
+      } else ub = vm;
+      if (lb > 0) lb = -lb;
+      if (ub < 0) ub = -ub;
+      if (lane >= cfg.lock_from) { lb = 0.0; ub = 0.0; }
+    }
+  }
+  if (lane < 32) { S.npv[lane] = g; S.xv[lane] = lb; S.yv[lane] = ub; }
+  WSYNC();
+
+  // ---- G_e = -K_e^-1 B_e, all feet at once (see contact_presolve)
+  double* const Gm = S.Gm;
+  bool singular = false;
+  {
+    const int f = (lane < 24) ? lane / 6 : 0, c = (lane < 24) ? lane - 6 * f : 0;
+    int d0 = legd[0], d1 = legd[1], d2 = legd[2], rs = rowstart[0];
+#pragma unroll
+    for (int t = 1; t < 4; ++t) { const bool m = f == t; d0 = m ? legd[3 * t] : d0; d1 = m ? legd[3 * t + 1] : d1; d2 = m ? legd[3 * t + 2] : d2; rs = m ? rowstart[t] : rs; }
+    const double* r0 = Co + rs * LDJ; const double* r1 = r0 + LDJ; const double* r2 = r1 + LDJ;
+    const double k00 = r0[d0], k01 = r0[d1], k02 = r0[d2], k10 = r1[d0], k11 = r1[d1], k12 = r1[d2],
+                 k20 = r2[d0], k21 = r2[d1], k22 = r2[d2];
+    const double b0 = r0[c], b1 = r1[c], b2 = r2[c];
+    const double a00 = k11 * k22 - k12 * k21, a01 = k02 * k21 - k01 * k22, a02 = k01 * k12 - k02 * k11;
+    const double a10 = k12 * k20 - k10 * k22, a11 = k00 * k22 - k02 * k20, a12 = k02 * k10 - k00 * k12;
+    const double a20 = k10 * k21 - k11 * k20, a21 = k01 * k20 - k00 * k21, a22 = k00 * k11 - k01 * k10;
+    const double det = k00 * a00 + k01 * a10 + k02 * a20;
+    const double sc = fabs(k00) + fabs(k01) + fabs(k02) + fabs(k10) + fabs(k11) + fabs(k12) + fabs(k20) + fabs(k21) + fabs(k22);
+    const bool live = lane < 6 * nelim;
+    singular = __ballot(live && !(fabs(det) > 1e-7 * sc * sc * sc)) != 0;
+    const double id = -1.0 / det;
+    if (lane < 24) {
+      Gm[(3 * f + 0) * GS + c] = live ? id * (a00 * b0 + a01 * b1 + a02 * b2) : 0.0;
+      Gm[(3 * f + 1) * GS + c] = live ? id * (a10 * b0 + a11 * b1 + a12 * b2) : 0.0;
+      Gm[(3 * f + 2) * GS + c] = live ? id * (a20 * b0 + a21 * b1 + a22 * b2) : 0.0;
+    }
+  }
+  if (singular) {   // left to the general kernel's second pass
+    if (lane == 0) A.out.status[b] = WBC_QP_DEFERRED;
+    WSYNC();
+    return;
+  }
+  WSYNC();
+  double gcol[12];
+#pragma unroll
+  for (int l = 0; l < 12; ++l) gcol[l] = (lane < 6) ? Gm[l * GS + lane] : 0.0;   // rows >= nl are zero
+  // g' = Z'g
+  double g_red = S.npv[fj];
+#pragma unroll
+  for (int l = 0; l < 12; ++l) g_red = fma(gcol[l], S.npv[legd[l]], g_red);
+  if (lane >= n_red) g_red = 0.0;
+  // ---- C' = C Z for the rows that stay, then the eliminated legs' bounds as rows G_l
+  double* const Cm = S.RC;
+  double nclb = 0.0, ncub = 0.0;
+  int i2 = 0;
+#pragma unroll 1
+  for (int i = 0; i < p; ++i) {
+    if ((elimrows >> i) & 1u) continue;
+    double v = (lane < n_red) ? Co[i * LDJ + fj] : 0.0;
+    if ((legrows >> i) & 1u) {
+#pragma unroll
+      for (int l = 0; l < 12; ++l) v = fma(gcol[l], Co[i * LDJ + legd[l]], v);
+    }
+    if (lane < CSC) Cm[i2 * CSC + lane] = v;
+    const double bl = rdl(clb, i), bu = rdl(cub, i);
+    if (lane == i2) { nclb = bl; ncub = bu; }
+    ++i2;
+  }
+  if (cfg.use_bounds) {
+#pragma unroll
+    for (int l = 0; l < 12; ++l) {
+      if (l < nl) { if (lane < CSC) Cm[(i2 + l) * CSC + lane] = gcol[l]; }
+    }
+    if (lane >= i2 && lane < i2 + nl) { nclb = S.xv[my_legd]; ncub = S.yv[my_legd]; }
+    i2 += nl;
+  }
+  const double lb_red = (lane < n_red) ? S.xv[fj] : 0.0, ub_red = (lane < n_red) ? S.yv[fj] : 0.0;
+  // ---- H' += d^2 G'G on the base block (H_ll = d^2 I, H_lf = 0: DevPlan.enabled)
+  {
+    double gg[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int l = 0; l < 12; ++l) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) gg[c] = fma(gcol[l], Gm[l * GS + c], gg[c]);
+    }
+    const double d2 = dpost * dpost;
+    if (lane < 6) {
+#pragma unroll
+      for (int c = 0; c < 6; c += 2) {
+        const double2a h2 = lds2(S.RA + lane * LDJ + c);
+        sts2(S.RA + lane * LDJ + c, fma(d2, gg[c], h2.x), fma(d2, gg[c + 1], h2.y));
+      }
+    }
+  }
+  WSYNC();
+  QpResult res = qp_core<NR, SmemC, CSC>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
+  res.iters += nl;
+  // ---- x = Z y
+  WSYNC();
+  if (lane < 32) S.xv[lane] = (lane < n_red) ? res.x : 0.0;
+  WSYNC();
+  double x = 0.0;
+  if (my_pos >= 0) x = S.xv[my_pos];
+  else if (my_l >= 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) x = fma(Gm[my_l * GS + c], S.xv[c], x);
+  }
+  if (lane >= nv) x = 0.0;
+  if (A.out.qdot && lane < NV) A.out.qdot[(size_t)b * NV + lane] = x;
+  if (lane == 0) {
+    A.out.status[b] = res.status;
+    if (A.out.iters) A.out.iters[b] = res.iters;
+  }
+  // ---- jointVelocitiestoConfig (Robot_Wrapper4.py:440-441)
+  if (A.out.q_next) {
+    double* qn = A.out.q_next + (size_t)b * NQ;
+    const double v = x * dt;
+    WSYNC();
+    if (lane < 32) S.xv[lane] = (lane < nv) ? v : 0.0;
+    WSYNC();
+    integrate_ff(S, lane, qn);
+    if (lane >= 6 && lane < nv) qn[lc.col_q] = qv[lc.col_q] + v;
+    if (lane >= nq && lane < NQ) qn[lane] = 0.0;
+    WSYNC();
+  }
+}
+
+__global__ void __launch_bounds__(64, 3) wbc_tick_sim3_kernel(const KernelArgs A, const DevModel* __restrict__ models,
+                                                              const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
+  __shared__ SmemC S;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  if (lane < 48) S.cl[lane] = 0.0;
+  if (lane < LDJ) S.RApad[lane] = 0.0;
+  const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot;
+  const int mid = A.in.model_id ? __builtin_amdgcn_readfirstlane(A.in.model_id[b]) : 0;
+  const InRegs cur = load_inputs(A.in, A.dbg_alias ? 0 : b, lane, has2, false);
+  const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);
+  stage_inputs(S, cur, lane, has2, false);
+  WSYNC();
+  process_sim3(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane);
 }
 
 // Stand-alone QP (QP_Wrapper.QP.solveQP): H, g (or A, b) and constraints straight from HBM.
@@ -1784,6 +2203,11 @@ int launch_tick(const KernelArgs& a, int mode, int grid, void* stream) {
   else hipLaunchKernelGGL(wbc_tick_kernel<MODE_FK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
   return check_launch("tick");
 }
+int launch_tick_sim3(const KernelArgs& a, int grid, void* stream) {
+  hipLaunchKernelGGL(wbc_tick_sim3_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  return check_launch("tick_sim3");
+}
+int sim3_lds_bytes() { return (int)sizeof(SmemC); }
 int launch_qp(const QpArgs& a, int grid, void* stream) {
   hipLaunchKernelGGL(wbc_qp_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a);
   return check_launch("qp");

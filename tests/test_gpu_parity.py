@@ -245,18 +245,51 @@ def test_contact_presolve_and_general_path_agree(wx200, px100, cfg_name):
     for i, c in enumerate(cfgs):
         bt.configure(c, i)
     res = {}
-    for presolve in (1, 0):
-        bt.set_option("presolve", presolve)
-        res[presolve] = bt.tick(d, DT, want_q_next=True)
-        assert (res[presolve]["status"] == ref["status"]).all(), presolve
+    # (presolve, sim3_kernel): compact sim3 kernel + deferred pass / general kernel with presolve / general path only
+    for key in ((1, 1), (1, 0), (0, 0)):
+        bt.set_option("presolve", key[0])
+        bt.set_option("sim3_kernel", key[1])
+        res[key] = bt.tick(d, DT, want_q_next=True)
+        assert (res[key]["status"] == ref["status"]).all(), key
     ok = ref["status"] == 0
     assert ok.mean() > 0.9
-    e1 = np.abs(res[1]["qdot"] - ref["qdot"])[ok].max()
-    e0 = np.abs(res[0]["qdot"] - ref["qdot"])[ok].max()
-    print("%s: presolve err %.3e, general err %.3e, iters %.2f / %.2f / oracle %.2f" % (
-        cfg_name, e1, e0, res[1]["iters"][ok].mean(), res[0]["iters"][ok].mean(), ref["iters"][ok].mean()))
-    assert e1 < QDOT_TOL and e0 < QDOT_TOL
-    assert np.abs(res[1]["qdot"] - res[0]["qdot"])[ok].max() < QDOT_TOL
+    errs = {k: np.abs(v["qdot"] - ref["qdot"])[ok].max() for k, v in res.items()}
+    print("%s: sim3 kernel err %.3e, presolve err %.3e, general err %.3e, iters %.2f / %.2f / %.2f / oracle %.2f" % (
+        cfg_name, errs[(1, 1)], errs[(1, 0)], errs[(0, 0)], res[(1, 1)]["iters"][ok].mean(), res[(1, 0)]["iters"][ok].mean(),
+        res[(0, 0)]["iters"][ok].mean(), ref["iters"][ok].mean()))
+    assert max(errs.values()) < QDOT_TOL
+    assert np.abs(res[(1, 1)]["qdot"] - res[(0, 0)]["qdot"])[ok].max() < QDOT_TOL
+    assert np.abs(res[(1, 1)]["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    if cfg_name == "c3":
+        assert np.abs(res[(1, 1)]["qdot"] - res[(1, 0)]["qdot"])[ok].max() < 1e-9      # same reduced QP on both kernels
+    bt.close()
+
+
+def test_sim3_kernel_defers_singular_leg_blocks(wx200):
+    """A stance leg whose 3 x 3 WORLD-frame block is singular cannot be eliminated: the compact kernel defers the instance
+    to the general kernel's second pass. Built by brute force: search random poses for the smallest |det K|, then shrink
+    it further along the gradient-free direction of one calf angle; whatever is left must still match the oracle."""
+    import wbc_workload
+    B = 4096
+    cfg = common.config("c3", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=77)
+    # FR leg block of the FR contact rows (constraint rows 4..6, DoF 9..11 in compat order): make it singular by zeroing
+    # the moment arm: put the base so that the FR foot's WORLD-frame columns are parallel -> use the oracle's C to pick
+    a = oracle.assemble([wx200], [cfg], d, DT, B)
+    K = a["C"][:, 4:7, 9:12]
+    det = np.abs(np.linalg.det(K))
+    scale = np.abs(K).sum(axis=(1, 2)) ** 3
+    ratio = det / scale
+    idx = np.argsort(ratio)[:64]
+    sub = {k: v[idx] for k, v in d.items()}
+    ref = oracle.tick([wx200], [cfg], sub, DT, len(idx), nthreads=8)
+    bt = WbcBatch(wx200, len(idx))
+    bt.configure(cfg)
+    got = bt.tick(sub, DT)
+    assert (got["status"] == ref["status"]).all() and (got["status"] >= 0).all()
+    ok = ref["status"] == 0
+    assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+    print("smallest |det K| / scale^3 in the sample: %.2e" % ratio[idx[0]])
     bt.close()
 
 
