@@ -35,18 +35,19 @@ ALGO_FLOP_PER_TICK = 5.5e4     # + ~1e4 per working-set change
 
 
 def pmc_traffic_bytes():
-    """HBM bytes per launch of the tick kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_summary_v8.txt: FETCH_SIZE and WRITE_SIZE in KiB, separate --pmc runs, tools/gpu_profile.sh).
-    8-byte-per-lane accesses: the gfx950 x2 FETCH_SIZE correction for 16-byte streams does not apply (uncalibrated width)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_v8.txt")
+    """HBM bytes per bench step from the committed rocprofv3 PMC passes of this same command (profiles/r01_pmc_summary_v10.txt:
+    FETCH_SIZE and WRITE_SIZE in KiB, separate --pmc runs, tools/gpu_profile.sh), summed over the kernels one step launches
+    (the sim3 tick kernel + the deferred pass). 8-byte-per-lane accesses: the gfx950 x2
+    FETCH_SIZE correction for 16-byte streams does not apply (uncalibrated width)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_v10.txt")
     try:
-        vals = {}
+        total = 0.0
         for line in open(path):
-            if "tick_kernel<0>" in line:
+            if "wbc_tick_sim3_kernel" in line or "wbc_tick_deferred_kernel" in line:
                 for key in ("FETCH_SIZE", "WRITE_SIZE"):
                     if " %s " % key in line:
-                        vals[key] = float(line.split("per_dispatch=")[1])
-        return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+                        total += float(line.split("per_dispatch=")[1])
+        return total * 1024.0 if total else None
     except Exception:
         return None
 
@@ -159,7 +160,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "dt": DT, "parallelism": "shard%d (no collective)" % world,
                        "jtj": "mfma_f64" if args.jtj_mfma else "valu_f64"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes(), "traffic_unit": "bytes/launch (PMC, batch 65536)", "kernel": "wbc_tick_kernel<0>", "kernel_ms": kernel_ms,
+                         "traffic": pmc_traffic_bytes(), "traffic_unit": "bytes/launch (PMC, batch 65536)", "kernel": "wbc_tick_sim3_kernel (+ wbc_tick_deferred_kernel)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_tick": ALGO_BYTES_PER_TICK, "streamed_bytes_per_tick": ACTUAL_BYTES_PER_TICK,
                          "fp64_tflops": ALGO_FLOP_PER_TICK * B / (kernel_ms * 1e-3) / 1e12,
                          "fp64_frac": ALGO_FLOP_PER_TICK * B / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,

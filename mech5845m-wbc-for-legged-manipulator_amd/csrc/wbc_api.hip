@@ -42,6 +42,7 @@ struct WbcBatch {
   int mrows, prows, mcart;
   int jtj_mfma;
   int presolve;
+  double sing_tol;
   int sim3_kernel;       // 1 (default): batches that qualify run on wbc_tick_sim3_kernel (compact LDS) + a deferred pass
   int32_t* d_status;     // status buffer of our own when the caller passes none (the deferred pass needs one)
   int dbg_alias;
@@ -135,7 +136,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   WbcBatch* b = new (std::nothrow) WbcBatch;
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
-  b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->sim3_kernel = 1;
+  b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
@@ -267,6 +268,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!b || !name) return fail(WBC_E_ARG, "wbc_batch_set_option: null");
   if (!strcmp(name, "jtj_mfma")) { b->jtj_mfma = value; return WBC_OK; }
   if (!strcmp(name, "presolve")) { b->presolve = value; return WBC_OK; }
+  if (!strcmp(name, "presolve_tol_exp")) { double t = 1.0; for (int i = 0; i < value; ++i) t *= 0.1; b->sing_tol = t; return WBC_OK; }
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
   if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
   if (!strcmp(name, "grid")) { if (value < 1) return fail(WBC_E_ARG, "grid must be >= 1"); b->grid = value; return WBC_OK; }
@@ -393,13 +395,13 @@ static int auto_posture(WbcBatch* b, KernelArgs& a, int B, void* stream) {
 static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
   memset(&a, 0, sizeof a);
   a.models = b->d_models; a.cfgs = b->d_cfgs; a.plans = b->d_plans;
-  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma; a.presolve = b->presolve; a.dbg_alias = b->dbg_alias; a.dt = dt;
+  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma; a.presolve = b->presolve; a.sing_tol = b->sing_tol; a.dbg_alias = b->dbg_alias; a.dt = dt;
   a.prof = b->d_prof;
   if (b->n_models > 0) { a.fk_nj = b->models[0]->blob.njoints; a.fk_nf = b->models[0]->blob.nframes; }
 }
 
 // The fused tick on the best kernel for the batch: wbc_tick_sim3_kernel (compact LDS, reduced QP only) when every
-// model's plan is enabled and the problem fits its layout, followed by an early-exit pass of the general kernel over
+// model's plan is enabled and the problem fits its layout, followed by wbc_tick_deferred_kernel (general path) over
 // the instances it deferred (singular leg block); otherwise the general kernel alone. `a` holds device pointers.
 static bool sim3_eligible(const WbcBatch* b, const KernelArgs& a) {
   if (!b->sim3_kernel || !b->presolve || b->n_models < 1) return false;
@@ -421,9 +423,7 @@ static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
     a.out.status = b->d_status;
   }
   if (int e = launch_tick_sim3(a, B, stream)) return fail(WBC_E_HIP, "sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-  a.only_deferred = 1;
-  if (int e = launch_tick(a, MODE_TICK, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "tick kernel (deferred pass) launch failed: %s", hipGetErrorString((hipError_t)e));
-  a.only_deferred = 0;
+  if (int e = launch_tick_deferred(a, stream)) return fail(WBC_E_HIP, "deferred tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return WBC_OK;
 }
 

@@ -54,11 +54,12 @@ struct KernelArgs {
   const DevPlan* plans;
   int32_t B, mrows, prows, mcart;   // mcart = Cartesian task rows (excludes the diagonal posture block)
   int32_t dbg_alias;                // diagnostic: every wave loads instance 0's inputs (isolates HBM input latency)
-  int32_t only_deferred;            // general tick kernel, second pass: only the instances wbc_tick_sim3_kernel left as WBC_QP_DEFERRED
+  int32_t pad1_;
   int32_t jtj_mfma, presolve;  // presolve: structural elimination of the contact equalities (default on)
   int32_t fk_nj, fk_nf;             // oMi / oMf output strides (sizes of model 0)
   unsigned long long* prof;         // WBC_PROFILE builds: per-phase cycle sums [16] (else unused)
   double dt;
+  double sing_tol;                  // a stance-leg block with |det K| <= sing_tol (sum|K_ij|)^3 is not eliminated
   WbcTickIn in;
   WbcTickOut out;
   WbcQpData qp;
@@ -110,6 +111,7 @@ struct UpdateArgs {
 // launchers (wbc_kernels.hip); grid = min(B, waves) persistent single-wave workgroups
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream);
 int launch_tick_sim3(const KernelArgs& a, int grid, void* stream);
+int launch_tick_deferred(const KernelArgs& a, void* stream);   // general path for the instances the sim3 kernel deferred
 int sim3_lds_bytes();
 int launch_qp(const QpArgs& a, int grid, void* stream);
 int launch_integrate(const IntegrateArgs& a, int grid, void* stream);

@@ -976,7 +976,7 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
     const double det = k00 * a00 + k01 * a10 + k02 * a20;
     const double sc = fabs(k00) + fabs(k01) + fabs(k02) + fabs(k10) + fabs(k11) + fabs(k12) + fabs(k20) + fabs(k21) + fabs(k22);
     const bool live = lane < 6 * nelim;
-    singular = __ballot(live && !(fabs(det) > 1e-7 * sc * sc * sc)) != 0;   // a leg block (nearly) rank deficient: general path
+    singular = __ballot(live && !(fabs(det) > A.sing_tol * sc * sc * sc)) != 0;   // a leg block (nearly) rank deficient: general path
     const double id = -1.0 / det;
     if (lane < 24) {
       Gm[(3 * f + 0) * GS + c] = live ? id * (a00 * b0 + a01 * b1 + a02 * b2) : 0.0;
@@ -1462,7 +1462,6 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
 #endif
   S.cl[lane] = 0.0;                            // zero padding the rotating loops rely on (never written above entry 25)
   if (lane < LDJ) S.RApad[lane] = 0.0;
-  if (MODE == MODE_TICK && A.only_deferred && __builtin_amdgcn_readfirstlane(A.out.status[b]) != WBC_QP_DEFERRED) return;
   const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
                     A.in.com_target || A.in.com_target_vel;
   const bool has3 = A.in.ee_ref_rot != nullptr;
@@ -1774,7 +1773,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     const double det = k00 * a00 + k01 * a10 + k02 * a20;
     const double sc = fabs(k00) + fabs(k01) + fabs(k02) + fabs(k10) + fabs(k11) + fabs(k12) + fabs(k20) + fabs(k21) + fabs(k22);
     const bool live = lane < 6 * nelim;
-    singular = __ballot(live && !(fabs(det) > 1e-7 * sc * sc * sc)) != 0;
+    singular = __ballot(live && !(fabs(det) > A.sing_tol * sc * sc * sc)) != 0;
     const double id = -1.0 / det;
     if (lane < 24) {
       Gm[(3 * f + 0) * GS + c] = live ? id * (a00 * b0 + a01 * b1 + a02 * b2) : 0.0;
@@ -1886,6 +1885,37 @@ __global__ void __launch_bounds__(64, 3) wbc_tick_sim3_kernel(const KernelArgs A
   stage_inputs(S, cur, lane, has2, false);
   WSYNC();
   process_sim3(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane);
+}
+
+// Second pass after wbc_tick_sim3_kernel: the instances it deferred (rare: a singular stance-leg block) are redone on the
+// general path. One wave inspects 64 statuses with one coalesced load and walks the flagged ones; a sequential loop is
+// fine here (speed is irrelevant for a handful of instances per batch, and every wave reaches the loop exit).
+__global__ void __launch_bounds__(64, 2) wbc_tick_deferred_kernel(const KernelArgs A, const DevModel* __restrict__ models,
+                                                                  const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
+  __shared__ Smem S;
+  const int lane0 = threadIdx.x;
+  const int cand = blockIdx.x * 64 + lane0;
+  unsigned long long todo = __ballot(cand < A.B && A.out.status[cand < A.B ? cand : 0] == WBC_QP_DEFERRED);
+  if (!todo) return;
+  const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
+                    A.in.com_target || A.in.com_target_vel;
+  const bool has3 = A.in.ee_ref_rot != nullptr;
+#pragma unroll 1
+  while (todo) {
+    const int b = blockIdx.x * 64 + ctz64(todo);
+    todo &= todo - 1;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    S.cl[lane] = 0.0;
+    if (lane < LDJ) S.RApad[lane] = 0.0;
+    const int mid = A.in.model_id ? __builtin_amdgcn_readfirstlane(A.in.model_id[b]) : 0;
+    const InRegs cur = load_inputs(A.in, b, lane, has2, has3);
+    const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);
+    stage_inputs(S, cur, lane, has2, has3);
+    WSYNC();
+    process_instance<MODE_TICK>(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane, 0ull);
+    WSYNC();
+  }
 }
 
 // Stand-alone QP (QP_Wrapper.QP.solveQP): H, g (or A, b) and constraints straight from HBM.
@@ -2206,6 +2236,10 @@ int launch_tick(const KernelArgs& a, int mode, int grid, void* stream) {
 int launch_tick_sim3(const KernelArgs& a, int grid, void* stream) {
   hipLaunchKernelGGL(wbc_tick_sim3_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   return check_launch("tick_sim3");
+}
+int launch_tick_deferred(const KernelArgs& a, void* stream) {
+  hipLaunchKernelGGL(wbc_tick_deferred_kernel, dim3((a.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  return check_launch("tick_deferred");
 }
 int sim3_lds_bytes() { return (int)sizeof(SmemC); }
 int launch_qp(const QpArgs& a, int grid, void* stream) {

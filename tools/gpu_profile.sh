@@ -32,7 +32,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = c
 for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        if "wbc_tick_kernel" not in k: continue
+        if "wbc_tick" not in k: continue
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         calls[(k, row["Counter_Name"])] += 1
 with open(os.path.join(out, "pmc_summary.txt"), "w") as w:
