@@ -83,7 +83,7 @@ extern "C" int wbc_model_create(const WbcModelBlob* b, WbcModel** out) {
     if (j == 1 && (b->place_p[1][0] != 0 || b->place_p[1][1] != 0 || b->place_p[1][2] != 0)) { delete m; return fail(WBC_E_UNSUPPORTED, "root joint placement must be identity"); }
     depth[j] = depth[b->parent[j]] + 1;
     if (depth[j] > d.maxdepth) d.maxdepth = depth[j];
-    d.parent[j] = b->parent[j]; d.depth[j] = depth[j]; d.jtype[j] = t; d.idx_q[j] = b->idx_q[j];
+    d.parent[j] = b->parent[j]; d.depth[j] = depth[j]; d.jtype[j] = t; d.idx_q[j] = b->idx_q[j]; d.idx_v_of[j] = b->idx_v[j];
     const int a = (t >= WBC_JT_RX && t <= WBC_JT_RZ) ? t - WBC_JT_RX : (t >= WBC_JT_PX ? t - WBC_JT_PX : 0);
     d.ax0[j] = a; d.ax1[j] = (a + 1) % 3; d.ax2[j] = (a + 2) % 3;
     d.tp[j][0] = b->place_p[j][d.ax0[j]]; d.tp[j][1] = b->place_p[j][d.ax1[j]]; d.tp[j][2] = b->place_p[j][d.ax2[j]];

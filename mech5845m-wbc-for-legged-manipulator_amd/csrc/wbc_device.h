@@ -21,6 +21,7 @@ struct DevModel {
   // column lanes
   int32_t col_joint[NL], col_lin[NL], col_ang[NL], col_q[NL];   // local axis index (-1: none); q index of 1-DoF joints
   uint32_t col_subtree[NL];            // joints in the subtree of the column's joint (CoM Jacobian)
+  int32_t idx_v_of[NL];                // joint -> its first velocity column
   // controller frames (role order WBC_FR_*)
   int32_t frame_joint[WBC_MAX_FRAMES];
   double frame_p[WBC_MAX_FRAMES][3];

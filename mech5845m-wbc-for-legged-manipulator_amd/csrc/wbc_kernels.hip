@@ -2118,12 +2118,21 @@ __global__ void __launch_bounds__(64) wbc_posture_kernel(const PostureArgs A, co
       const int qi = literal ? i : ((i < 6) ? i : i + 1);                                   // q[i]: the VELOCITY index (:1231, :1252)
       const double keep = P.q[qi];
       WSYNC();
+      // Which joint's angle is q[qi]? The LWA Jacobian of joint_id is built from the axes and origins of its PROPER
+      // ancestors and its own origin/axis, none of which the FK derives from the angle of joint_id itself or of any joint
+      // outside its ancestor chain (the axis column is an exact copy of the parent's, the origin does not involve the
+      // angle). For such a perturbation f1 and f2 are computed from bit-identical inputs, so u_i = 0.5 (f1 - f2)/dq = 0
+      // exactly — the twelve FK sweeps of the reference's HYBRID indices all fall in this class.
+      const unsigned long long own = __ballot(lc.is_joint && lc.q_idx == qi && lane >= 2);
+      const int jp = own ? ctz64(own) : 1;                                                 // qi < 7: the free-flyer (affects everything)
+      const bool matters = (jp == 1) || (jp != joint_id && ((M.col_subtree[M.idx_v_of[jp]] >> joint_id) & 1u));
       if (lane == 0) P.q[qi] = keep + dq;
       WSYNC();
-      const double f1 = manipulability(P, M, lc, joint_id, lane);
+      double f1 = 0.0, f2 = 0.0;
+      if (matters) f1 = manipulability(P, M, lc, joint_id, lane);
       if (lane == 0) P.q[qi] = (keep + dq) - (dq * 2);
       WSYNC();
-      const double f2 = manipulability(P, M, lc, joint_id, lane);
+      if (matters) f2 = manipulability(P, M, lc, joint_id, lane);
       if (lane == i) u = 0.5 * (f1 - f2) / dq;
       if (!literal) { if (lane == 0) P.q[qi] = keep; WSYNC(); }
     }
