@@ -52,6 +52,25 @@ def pmc_traffic_bytes():
         return None
 
 
+def pmc_issue_busy():
+    """VALU / LDS busy fractions of the sim3 tick kernel from the same committed PMC passes: SQ_ACTIVE_INST_VALU and
+    SQ_LDS_IDX_ACTIVE per CU-cycle (GRBM_GUI_ACTIVE counts the 8 XCDs' cycles; 256 CUs)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_v10.txt")
+    try:
+        v = {}
+        for line in open(path):
+            if "wbc_tick_sim3_kernel" in line:
+                for key in ("SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVES"):
+                    if " %s " % key in line:
+                        v[key] = float(line.split("per_dispatch=")[1])
+        cu_cycles = 256.0 * v["GRBM_GUI_ACTIVE"] / 8.0
+        return {"valu_busy": v["SQ_ACTIVE_INST_VALU"] / cu_cycles, "lds_busy": v["SQ_LDS_IDX_ACTIVE"] / cu_cycles,
+                "valu_insts_per_tick": v["SQ_INSTS_VALU"] / v["SQ_WAVES"], "lds_insts_per_tick": v["SQ_INSTS_LDS"] / v["SQ_WAVES"],
+                "salu_insts_per_tick": v["SQ_INSTS_SALU"] / v["SQ_WAVES"], "source": "profiles/r01_pmc_summary_v10.txt"}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +183,7 @@ def main():
                          "algorithmic_bytes_per_tick": ALGO_BYTES_PER_TICK, "streamed_bytes_per_tick": ACTUAL_BYTES_PER_TICK,
                          "fp64_tflops": ALGO_FLOP_PER_TICK * B / (kernel_ms * 1e-3) / 1e12,
                          "fp64_frac": ALGO_FLOP_PER_TICK * B / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                         "issue": pmc_issue_busy(),
                          "note": "tiny-dense LDS-resident fp64 work: VALU- and LDS-issue bound, neither HBM nor MFMA is approachable (SURVEY.md §8d); see profiles/"},
             "solver": {"optimal_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
                        "iters_p95": float(np.percentile(iters, 95)), "iters_max": int(iters.max())},

@@ -109,7 +109,7 @@ struct UpdateArgs {
   int32_t *status_max, *iters_sum;
 };
 
-// launchers (wbc_kernels.hip); grid = min(B, waves) persistent single-wave workgroups
+// launchers (wbc_kernels.hip): single-wave workgroups; tick kernels take grid = B, the QP / integrate kernels min(B, resident waves)
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream);
 int launch_tick_sim3(const KernelArgs& a, int grid, void* stream);
 int launch_tick_deferred(const KernelArgs& a, void* stream);   // general path for the instances the sim3 kernel deferred

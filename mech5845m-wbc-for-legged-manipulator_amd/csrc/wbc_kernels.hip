@@ -1,6 +1,6 @@
 // wbc_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the batched whole-body-control tick.
 //
-// One robot instance per 64-lane wavefront, one wavefront per workgroup, persistent over the batch:
+// One robot instance per 64-lane wavefront, one wavefront per workgroup, one workgroup per instance (grid = B):
 //   lane j  <-> joint j          during forward kinematics (level-synchronous over the tree depth),
 //   lane k  <-> velocity DoF k   everywhere else (column k of every Jacobian, row/column k of H, J, T).
 // All per-instance matrices live in LDS (row stride 26 doubles: 26 ≡ 2 mod 4 makes both the "lane = row,
@@ -10,7 +10,11 @@
 // code, so the waves of a CU, each in a different phase, share the 64 KB instruction cache without evicting each
 // other (the first, fully unrolled register-resident version was 82 KB of code and instruction-fetch bound:
 // profiles/r01_*_v1.*). Wave reductions use DPP row operations + v_readlane, never the LDS crossbar.
-// HBM traffic per tick is the instance's own inputs/outputs (~0.7 KB, coalesced), prefetched one tick ahead.
+// HBM traffic per tick is the instance's own inputs/outputs (~0.7 KB, coalesced).
+// Kernels: wbc_tick_kernel<MODE> (general path: tick / assemble / FK outputs), wbc_tick_sim3_kernel (+ wbc_tick_deferred_kernel:
+// the benchmark path — contact equalities eliminated structurally, reduced QP assembled directly, compact LDS, 3 waves per
+// SIMD), wbc_posture_kernel (MANI/HYBRID posture target), wbc_update_kernel (updateState + trunkWorldPos, roll-out state),
+// wbc_qp_kernel (QP(A, b, ...) boundary), wbc_integrate_kernel.
 //
 // Reference semantics (file:line relative to the reference repo) are cited at each stage; the CPU restatement the
 // tests compare against is oracle/wbc_oracle.c (never linked here); the algebra of the QP variant is stated in
@@ -45,7 +49,6 @@ struct __attribute__((aligned(16))) Smem {
 };
 constexpr int OFF_OMI = 0;              // RA: oMi[24][12] (dead before H is accumulated)
 constexpr int OFF_MC = 24 * 12;         // RA: m*c per joint [32][4]
-constexpr int MAXE = NV;                // equalities the QR keeps in registers (at most n can be independent)
 
 #define WSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
@@ -1440,8 +1443,8 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// kernels: single-wave workgroups, persistent over the batch (exit: b >= B, reached by every wave);
-// the next instance's inputs are fetched from HBM while the current one is being solved.
+// kernels: single-wave workgroups, one per instance for the tick kernels (the QP / integrate kernels walk the batch with a
+// grid-stride loop whose exit, b >= B, every wave reaches).
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, const DevModel* __restrict__ models,
