@@ -1528,13 +1528,19 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   const int nv = M.nv, nq = M.nq;
   const double dt = A.dt, inv_dt = 1.0 / A.dt;
   const double* const qv = S.in + IN_Q;
-  unsigned long long* ts = nullptr;
+  unsigned long long ts[T_NN];
+  (void)ts;
+#ifdef WBC_PROFILE
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // see process_instance: start-up loads are not charged to FK
+#endif
+  STAMP(ts, T_START);
   // ---- P1..P3 (updateState, Robot_Wrapper4.py:400-405)
   FkOut fo;
   fk_pass(S, S.RA, qv, M, lc, cfg.con_com != 0, lane, fo);
   double (&lin)[3] = fo.lin; double (&ang)[3] = fo.ang; double (&com)[3] = fo.com; double (&jc)[3] = fo.jc;
   double (&Rtr)[9] = fo.Rtr; double (&ptr)[3] = fo.ptr;
 
+  STAMP(ts, T_FK);
   // ---- the plan's index maps: one batch of scalar loads, per-lane views by select chains
   const int nelim = P.nelim, n_red = P.n_red, nl = 3 * nelim, p_keep = P.p_keep, p = A.prows;
   int legd[12], Fd[NR], rowstart[4];
@@ -1655,6 +1661,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     for (int r = 0; r < A.mcart; ++r) At[lane * mtp + r] = 0.0;
   }
   WSYNC();
+  STAMP(ts, T_A1);
   // ---- pass 2: H'[lane][k] = sum_r At[k][r] At[lane][r], block by block over each block's reduced support
   {
     int r0 = 0;
@@ -1678,6 +1685,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   if (lane >= nv) g = 0.0;
   if (lane < NR) S.RA[lane * LDJ + lane] += (lane < n_red) ? dpost * dpost : 1.0;
   WSYNC();   // At is dead: RB may be reused
+  STAMP(ts, T_A2);
   if (A.in.q_con) {   // the configuration qpJointb MANI/HYBRID left behind: constraints, bounds, integrate see it
     if (lane < NQ) S.in[IN_Q + lane] = inr.qc;
     WSYNC();
@@ -1734,6 +1742,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     }
     prow += 3;
   }
+  STAMP(ts, T_A3);
   // ---- velDamperJointConstraints (Robot_Wrapper4.py:572-637), lane = DoF
   double lb = 0.0, ub = 0.0;
   if (lane < nv) {
@@ -1757,6 +1766,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   }
   if (lane < 32) { S.npv[lane] = g; S.xv[lane] = lb; S.yv[lane] = ub; }
   WSYNC();
+  STAMP(ts, T_ASM);
 
   // ---- G_e = -K_e^-1 B_e, all feet at once (see contact_presolve)
   double* const Gm = S.Gm;
@@ -1790,6 +1800,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     return;
   }
   WSYNC();
+  STAMP(ts, T_P1);
   double gcol[12];
 #pragma unroll
   for (int l = 0; l < 12; ++l) gcol[l] = (lane < 6) ? Gm[l * GS + lane] : 0.0;   // rows >= nl are zero
@@ -1798,6 +1809,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
 #pragma unroll
   for (int l = 0; l < 12; ++l) g_red = fma(gcol[l], S.npv[legd[l]], g_red);
   if (lane >= n_red) g_red = 0.0;
+  STAMP(ts, T_P2);
   // ---- C' = C Z for the rows that stay, then the eliminated legs' bounds as rows G_l
   double* const Cm = S.RC;
   double nclb = 0.0, ncub = 0.0;
@@ -1824,6 +1836,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     i2 += nl;
   }
   const double lb_red = (lane < n_red) ? S.xv[fj] : 0.0, ub_red = (lane < n_red) ? S.yv[fj] : 0.0;
+  STAMP(ts, T_P3);
   // ---- H' += d^2 G'G on the base block (H_ll = d^2 I, H_lf = 0: DevPlan.enabled)
   {
     double gg[6] = {0, 0, 0, 0, 0, 0};
@@ -1842,6 +1855,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     }
   }
   WSYNC();
+  STAMP(ts, T_PRE);
   QpResult res = qp_core<NR, SmemC, CSC>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
   res.iters += nl;
   // ---- x = Z y
@@ -1872,6 +1886,19 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     if (lane >= nq && lane < NQ) qn[lane] = 0.0;
     WSYNC();
   }
+#ifdef WBC_PROFILE
+  STAMP(ts, T_END);
+  if (A.prof && lane == 0 && res.status == WBC_QP_OPTIMAL) {   // same slots as process_instance ([3] includes the presolve)
+    for (int i = 1; i < T_N; ++i) atomicAdd(A.prof + i, ts[i] - ts[i - 1]);
+    atomicAdd(A.prof + 0, 1ull);
+    atomicAdd(A.prof + 8, (unsigned long long)res.iters);
+    atomicAdd(A.prof + 9, ts[T_A1] - ts[T_FK]); atomicAdd(A.prof + 10, ts[T_A2] - ts[T_A1]);
+    atomicAdd(A.prof + 11, ts[T_A3] - ts[T_A2]); atomicAdd(A.prof + 12, ts[T_ASM] - ts[T_A3]);
+    atomicAdd(A.prof + 13, ts[T_PRE] - ts[T_ASM]); atomicAdd(A.prof + 14, 1ull);
+    atomicAdd(A.prof + 16, ts[T_P1] - ts[T_ASM]); atomicAdd(A.prof + 17, ts[T_P2] - ts[T_P1]);
+    atomicAdd(A.prof + 18, ts[T_P3] - ts[T_P2]); atomicAdd(A.prof + 19, ts[T_PRE] - ts[T_P3]);
+  }
+#endif
 }
 
 __global__ void __launch_bounds__(64, 3) wbc_tick_sim3_kernel(const KernelArgs A, const DevModel* __restrict__ models,

@@ -35,7 +35,26 @@ def make(name, cfg_name, B, seed, mixed=False):
     print(name, "status", np.bincount(out["status"]), "iters", out["iters"].tolist())
 
 
+def make_rollout(name, cfg_name, B, seed, K):
+    """K closed-loop ticks: inputs, per-tick steps and the oracle's final state / gripper trace."""
+    wx, _ = common.models()
+    cfg = common.config(cfg_name, wx)
+    d = common.tick_inputs(wx, cfg, B, seed)
+    rng = np.random.default_rng(seed)
+    step = np.zeros((B, 5, 3))
+    step[:, 4] = rng.normal(0, 1e-4, (B, 3))
+    imu = d["q"][:, 3:7].copy()
+    out = oracle.rollout([wx], [cfg], d, DT, B, K, ee_target_step=step, imu=imu)
+    np.savez_compressed(os.path.join(HERE, "golden", name + ".npz"), **{"in_" + k: v for k, v in d.items()},
+                        step=step, imu=imu, ticks=K, **{"out_" + k: v for k, v in out.items()})
+    print(name, "status", np.bincount(out["status"]), "iters", out["iters"].tolist())
+
+
 if __name__ == "__main__":
+    make("tick_c3_hybrid", "c3_hybrid", 8, 7)
+    make("tick_c3_mani", "c3_mani", 4, 8)
+    make_rollout("rollout_c3", "c3", 8, 9, 6)
+    make_rollout("rollout_c3_hybrid", "c3_hybrid", 4, 10, 4)
     make("tick_c1", "c1", 1, 1)
     make("tick_c2", "c2", 8, 2)
     make("tick_c3", "c3", 16, 3)

@@ -44,7 +44,27 @@ def test_qp_class_matches_reference_surface_and_oracle():
     assert np.abs(qm.solveQP() - ref["qdot"][0]).max() < 1e-5
 
 
-@pytest.mark.parametrize("name", ["tick_c1", "tick_c2", "tick_c3", "tick_c5_mixed", "tick_everything"])
+GOLDEN_CFG = {"tick_c1": "c1", "tick_c2": "c2", "tick_c3": "c3", "tick_c5_mixed": "c3", "tick_everything": "everything",
+              "tick_c3_hybrid": "c3_hybrid", "tick_c3_mani": "c3_mani"}
+
+
+@pytest.mark.parametrize("name,cfg_name", [("rollout_c3", "c3"), ("rollout_c3_hybrid", "c3_hybrid")])
+def test_hip_rollout_reproduces_golden_fixtures(name, cfg_name):
+    from wbc_batch import WbcBatch
+    z = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    wx, _ = common.models()
+    d = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    B = d["q"].shape[0]
+    bt = WbcBatch(wx, B)
+    bt.configure(common.config(cfg_name, wx))
+    out = bt.rollout(d, DT, int(z["ticks"]), ee_target_step=z["step"], imu=z["imu"])
+    assert (out["status"] == z["out_status"]).all()
+    assert np.abs(out["q"] - z["out_q"]).max() < 1e-6 and np.abs(out["grip_trace"] - z["out_grip_trace"]).max() < 1e-6
+    assert np.abs(out["qdot"] - z["out_qdot"]).max() < 1e-4
+    bt.close()
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN_CFG))
 def test_hip_path_reproduces_golden_fixtures(name):
     from wbc_batch import WbcBatch
     z = np.load(os.path.join(HERE, "golden", name + ".npz"))
@@ -53,7 +73,7 @@ def test_hip_path_reproduces_golden_fixtures(name):
     B = d["q"].shape[0]
     mixed = "model_id" in d
     models = [wx, px] if mixed else [wx]
-    cfg_name = {"tick_c1": "c1", "tick_c2": "c2", "tick_c3": "c3", "tick_c5_mixed": "c3", "tick_everything": "everything"}[name]
+    cfg_name = GOLDEN_CFG[name]
     bt = WbcBatch(models, B)
     for i, m in enumerate(models):
         bt.configure(common.config(cfg_name, m), i)
@@ -63,7 +83,7 @@ def test_hip_path_reproduces_golden_fixtures(name):
     if not mixed:
         a = bt.assemble(d, DT)
         for k in ("H", "g", "C", "lb", "ub"):
-            assert np.abs(a[k] - z["asm_" + k]).max() < 1e-11 * max(1, np.abs(z["asm_" + k]).max())
+            assert np.abs(a[k] - z["asm_" + k]).max() < (1e-9 if "mani" in name else 1e-11) * max(1, np.abs(z["asm_" + k]).max())
     bt.close()
 
 

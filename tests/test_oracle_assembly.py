@@ -152,7 +152,11 @@ def test_velocity_damper_bounds_both_index_maps(wx, compat):
         assert a["ub"][0, 6] <= 5.0       # vel_lim[6] = 5 quirk (:590-593): FL_hip's 52.4 rad/s is overwritten
 
 
-@pytest.mark.parametrize("name", ["tick_c1", "tick_c2", "tick_c3", "tick_c5_mixed", "tick_everything"])
+GOLDEN_CFG = {"tick_c1": "c1", "tick_c2": "c2", "tick_c3": "c3", "tick_c5_mixed": "c3", "tick_everything": "everything",
+              "tick_c3_hybrid": "c3_hybrid", "tick_c3_mani": "c3_mani"}
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN_CFG))
 def test_oracle_reproduces_golden_fixtures(name):
     """Regression anchor (tests/golden/README.md): the oracle's outputs on the committed seeded inputs."""
     z = np.load(os.path.join(HERE, "golden", name + ".npz"))
@@ -161,8 +165,7 @@ def test_oracle_reproduces_golden_fixtures(name):
     B = d["q"].shape[0]
     mixed = "model_id" in d
     models = [wx, px] if mixed else [wx]
-    cfg_name = {"tick_c1": "c1", "tick_c2": "c2", "tick_c3": "c3", "tick_c5_mixed": "c3", "tick_everything": "everything"}[name]
-    cfgs = [common.config(cfg_name, m) for m in models]
+    cfgs = [common.config(GOLDEN_CFG[name], m) for m in models]
     out = oracle.tick(models, cfgs, d, DT, B)
     assert (out["status"] == z["out_status"]).all()
     assert np.abs(out["qdot"] - z["out_qdot"]).max() < 1e-9
@@ -232,3 +235,14 @@ def test_hybrid_posture_is_prev_plus_zero_gradient(wx):
     assert (u[:, :20] == np.delete(q, 6, axis=1)[:, :20]).all()
     assert np.abs(u[:, 20:]).max() < 1e-9
     assert np.allclose((qa - q)[:, 20:26], -0.0002, rtol=1e-9, atol=0) and (qa[:, :20] == q[:, :20]).all()
+
+
+@pytest.mark.parametrize("name,cfg_name", [("rollout_c3", "c3"), ("rollout_c3_hybrid", "c3_hybrid")])
+def test_oracle_reproduces_rollout_fixtures(name, cfg_name):
+    z = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    wx, _ = common.models()
+    cfg = common.config(cfg_name, wx)
+    d = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    out = oracle.rollout([wx], [cfg], d, DT, d["q"].shape[0], int(z["ticks"]), ee_target_step=z["step"], imu=z["imu"])
+    assert (out["status"] == z["out_status"]).all() and (out["iters"] == z["out_iters"]).all()
+    assert np.abs(out["q"] - z["out_q"]).max() < 1e-10 and np.abs(out["grip_trace"] - z["out_grip_trace"]).max() < 1e-10
