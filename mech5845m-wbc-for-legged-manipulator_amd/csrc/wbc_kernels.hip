@@ -736,24 +736,37 @@ struct LaneConst {
 };
 
 __device__ __forceinline__ LaneConst load_lane_const(const DevModel& M, const WbcConfig& cfg, const int lane_true) {
+  // Every table entry is fetched unconditionally (clamped index) and selected afterwards: loads behind `cond ? table[i] : 0`
+  // were compiled into exec-masked blocks with a full wait between them — three serialised memory round trips at the top
+  // of every tick instead of one batch.
   LaneConst c;
   const int ll = lane_true & 31;
-  const int jt = M.jtype[ll];
-  c.is_joint = (lane_true >= 2 && lane_true < M.njoints) ? 1 : 0;
+  const int jt = M.jtype[ll], par = M.parent[ll], dep = M.depth[ll], iq = M.idx_q[ll];
+  const int x0 = M.ax0[ll], x1 = M.ax1[ll], x2 = M.ax2[ll];
+  const double t0 = M.tp[ll][0], t1 = M.tp[ll][1], t2 = M.tp[ll][2];
+  const double ms = M.mass[ll], c0 = M.com[ll][0], c1 = M.com[ll][1], c2 = M.com[ll][2];
+  const int lf = lane_true & 15;
+  const int fjn = M.frame_joint[lf];
+  const double f0 = M.frame_p[lf][0], f1 = M.frame_p[lf][1], f2 = M.frame_p[lf][2];
+  const int cj = M.col_joint[ll], cl_ = M.col_lin[ll], ca = M.col_ang[ll], cq = M.col_q[ll];
+  const unsigned st = M.col_subtree[ll];
+  const int ld = lane_true < NV ? lane_true : NV - 1;
+  const int dq = cfg.damper_qidx[ld];
+  const double dlo = cfg.damper_lo[ld], dhi = cfg.damper_hi[ld], dvm = cfg.damper_vmax[ld];
+  const int njoints = M.njoints, nv = M.nv;
+  c.is_joint = (lane_true >= 2 && lane_true < njoints) ? 1 : 0;
   c.rev = (c.is_joint && jt >= WBC_JT_RX && jt <= WBC_JT_RZ) ? 1 : 0;
   c.pris = (c.is_joint && !c.rev) ? 1 : 0;
-  c.par_off = 12 * (c.is_joint ? M.parent[ll] : 1);
-  c.depth = c.is_joint ? M.depth[ll] : 0;
-  c.q_idx = c.is_joint ? M.idx_q[ll] : 0;
-  c.a0 = 3 * M.ax0[ll]; c.a1 = 3 * M.ax1[ll]; c.a2 = 3 * M.ax2[ll];
-  c.t0 = M.tp[ll][0]; c.t1 = M.tp[ll][1]; c.t2 = M.tp[ll][2];
-  c.mass = M.mass[ll]; c.c0 = M.com[ll][0]; c.c1 = M.com[ll][1]; c.c2 = M.com[ll][2];
-  const int lf = lane_true & 15;
-  c.fj_off = 12 * M.frame_joint[lf]; c.f0 = M.frame_p[lf][0]; c.f1 = M.frame_p[lf][1]; c.f2 = M.frame_p[lf][2];
-  c.cj_off = 12 * M.col_joint[ll]; c.col_lin = M.col_lin[ll]; c.col_ang = M.col_ang[ll]; c.col_q = M.col_q[ll];
-  c.subtree = (lane_true < M.nv) ? M.col_subtree[ll] : 0u;
-  const int ld = lane_true < NV ? lane_true : NV - 1;
-  c.dq_idx = cfg.damper_qidx[ld]; c.d_lo = cfg.damper_lo[ld]; c.d_hi = cfg.damper_hi[ld]; c.d_vm = cfg.damper_vmax[ld];
+  c.par_off = 12 * (c.is_joint ? par : 1);
+  c.depth = c.is_joint ? dep : 0;
+  c.q_idx = c.is_joint ? iq : 0;
+  c.a0 = 3 * x0; c.a1 = 3 * x1; c.a2 = 3 * x2;
+  c.t0 = t0; c.t1 = t1; c.t2 = t2;
+  c.mass = ms; c.c0 = c0; c.c1 = c1; c.c2 = c2;
+  c.fj_off = 12 * fjn; c.f0 = f0; c.f1 = f1; c.f2 = f2;
+  c.cj_off = 12 * cj; c.col_lin = cl_; c.col_ang = ca; c.col_q = cq;
+  c.subtree = (lane_true < nv) ? st : 0u;
+  c.dq_idx = dq; c.d_lo = dlo; c.d_hi = dhi; c.d_vm = dvm;
   return c;
 }
 
@@ -2191,15 +2204,28 @@ __global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, cons
   const int mid = A.model_id ? __builtin_amdgcn_readfirstlane(A.model_id[b]) : 0;
   const DevModel& M = models[mid];
   const WbcConfig& cfg = cfgs[mid];
-  const LaneConst lc = load_lane_const(M, cfg, lane);
-  const int nq = M.nq;
+  // ---- every global read of the wave is issued here, before the FK (one memory round trip instead of a chain of them)
   // config = [current base xyz, base_config (IMU quaternion), new joint angles]  (:388-389)
+  const int nq = M.nq;
   double c = 0.0;
   if (lane < 3) c = A.q_cur[(size_t)b * NQ + lane];
   else if (lane < 7) c = A.imu ? A.imu[(size_t)b * 4 + (lane - 3)] : A.q_next[(size_t)b * NQ + lane];
   else if (lane < nq) c = A.q_next[(size_t)b * NQ + lane];
+  const double ft = (lane < 12) ? A.foot_targets[(size_t)b * 15 + lane] : 0.0;
+  const double eet = (A.ee_target && lane < 15) ? A.ee_target[(size_t)b * 15 + lane] : 0.0;
+  const double ees = (A.ee_target && A.ee_step && lane < 15) ? A.ee_step[(size_t)b * 15 + lane] : 0.0;
+  const double rref = (A.ee_prev_rot && A.ee_ref_rot && lane < 45) ? A.ee_ref_rot[(size_t)b * 45 + lane] : 0.0;
+  const double tt = (A.trunk_target && lane < 3) ? A.trunk_target[(size_t)b * 3 + lane] : 0.0;
+  const double tts = (A.trunk_target && A.trunk_step && lane < 3) ? A.trunk_step[(size_t)b * 3 + lane] : 0.0;
+  const double ter = (A.trunk_prev_rot && A.trunk_ref_euler && lane < 3) ? A.trunk_ref_euler[(size_t)b * 3 + lane] : 0.0;
+  int st = 0, stm = 0, it = 0, its = 0;
+  if (lane == 0) {
+    if (A.status_max) { st = A.status[b]; stm = A.status_max[b]; }
+    if (A.iters_sum) { it = A.iters[b]; its = A.iters_sum[b]; }
+  }
+  const LaneConst lc = load_lane_const(M, cfg, lane);
   if (lane < 32) U.q[lane] = c;
-  if (lane < 12) U.ft[lane] = A.foot_targets[(size_t)b * 15 + lane];
+  if (lane < 12) U.ft[lane] = ft;
   WSYNC();
   fk_levels(U.oMi, U.q, M, lc, lane);
   if (lane < M.nframes) {
@@ -2225,29 +2251,28 @@ __global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, cons
     const double d = (lane == 0) ? base[0] - U.q[0] : (lane == 1) ? base[1] - U.q[1] : base[2] - U.q[2];
     A.grip_trace[(size_t)b * 3 + lane] = U.pf[3 * (WBC_FR_EE0 + 4) + lane] + d;
   }
-  if (A.status_max && lane == 0) { const int s = A.status[b]; if (s > A.status_max[b]) A.status_max[b] = s; }
-  if (A.iters_sum && lane == 0) A.iters_sum[b] += A.iters[b];
+  if (lane == 0) {
+    if (A.status_max && st > stm) A.status_max[b] = st;
+    if (A.iters_sum) A.iters_sum[b] = its + it;
+  }
   // ---- side effects of qpb() on the reference state, then the targets move on
   if (A.ee_target && lane < 15) {
     const int e = lane / 3;
     const size_t i = (size_t)b * 15 + lane;
-    const double t = A.ee_target[i];
-    if (cfg.task_ee[e] && A.prev_ee_target) A.prev_ee_target[i] = t;                 // prev_EE_pos[i] = target (:1151)
-    if (A.ee_step) A.ee_target[i] = t + A.ee_step[i];
+    if (cfg.task_ee[e] && A.prev_ee_target) A.prev_ee_target[i] = eet;               // prev_EE_pos[i] = target (:1151)
+    if (A.ee_step) A.ee_target[i] = eet + ees;
   }
   if (A.ee_prev_rot && A.ee_ref_rot && lane < 45) {
     const int e = lane / 9;
-    if (cfg.task_ee[e]) A.ee_prev_rot[(size_t)b * 45 + lane] = A.ee_ref_rot[(size_t)b * 45 + lane];   // prev_EE_CoM_rot[i] = R* (:1152)
+    if (cfg.task_ee[e]) A.ee_prev_rot[(size_t)b * 45 + lane] = rref;                 // prev_EE_CoM_rot[i] = R* (:1152)
   }
   if (A.trunk_target && lane < 3) {
     const size_t i = (size_t)b * 3 + lane;
-    const double t = A.trunk_target[i];
-    if (cfg.task_trunk && A.prev_trunk_target) A.prev_trunk_target[i] = t;           // prev_trunk_ref = target (:995)
-    if (A.trunk_step) A.trunk_target[i] = t + A.trunk_step[i];
+    if (cfg.task_trunk && A.prev_trunk_target) A.prev_trunk_target[i] = tt;          // prev_trunk_ref = target (:995)
+    if (A.trunk_step) A.trunk_target[i] = tt + tts;
   }
   if (cfg.task_trunk && A.trunk_prev_rot && A.trunk_ref_euler) {                      // old_ref_trunk_rot_matrix = R* (:996)
-    const double* er = A.trunk_ref_euler + (size_t)b * 3;
-    const SinCos a = sincos_cw(er[0]), bb = sincos_cw(er[1]), cc = sincos_cw(er[2]);
+    const SinCos a = sincos_cw(rdl(ter, 0)), bb = sincos_cw(rdl(ter, 1)), cc = sincos_cw(rdl(ter, 2));
     double Rs[9];
     Rs[0] = cc.c * bb.c; Rs[1] = cc.c * bb.s * a.s - cc.s * a.c; Rs[2] = cc.c * bb.s * a.c + cc.s * a.s;
     Rs[3] = cc.s * bb.c; Rs[4] = cc.s * bb.s * a.s + cc.c * a.c; Rs[5] = cc.s * bb.s * a.c - cc.c * a.s;

@@ -434,3 +434,70 @@ def test_full_size_properties(wx200):
     good = ref["status"] == 0
     assert np.abs(ref["qdot"] - x[idx])[good].max() < QDOT_TOL
     bt.close()
+
+
+def test_api_misuse_is_refused_with_a_message(wx200, px100):
+    """Return-code contract of include/wbc.h: misuse gives a negative code + wbc_last_error(), never a launch."""
+    B = 8
+    cfg = common.config("c3", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=1)
+    bt = WbcBatch(wx200, B)
+    with pytest.raises(capi.WbcError, match="no configuration"):
+        bt.tick(d, DT)                                               # tick before wbc_batch_configure
+    bt.configure(cfg)
+    with pytest.raises(capi.WbcError, match="dt > 0"):
+        bt.tick(d, 0.0)
+    big = common.tick_inputs(wx200, cfg, B + 1, seed=1)
+    with pytest.raises(capi.WbcError, match="max_batch"):
+        bt.tick(big, DT)                                             # B beyond the handle's workspace
+    bad = {k: v for k, v in d.items() if k != "trunk_box_center"}
+    with pytest.raises(capi.WbcError, match="trunk_box_center"):
+        bt.tick(bad, DT)                                             # trunk constraint without its box centre
+    bad = {k: v for k, v in d.items() if k != "prev_ee_target"}
+    with pytest.raises(capi.WbcError, match="prev_ee_target"):
+        bt.tick(bad, DT)
+    off = wbc_model.sim3_config(wx200, Joint=False)
+    with pytest.raises(capi.WbcError, match="posture task must be on"):
+        bt.configure(off)                                            # H = J'J alone is singular (RW4:1199-1206)
+    with pytest.raises(capi.WbcError, match="unknown option"):
+        bt.set_option("no_such_knob", 1)
+    with pytest.raises(capi.WbcError, match="ticks >= 1"):
+        bt.rollout(d, DT, 0)
+    H = np.eye(27)[None]
+    with pytest.raises(capi.WbcError, match="out of range"):
+        bt.qp_solve(H, np.zeros((1, 27)))                            # n > 26
+    # two morphologies must share the switches, and a mixed batch needs model_id
+    b2 = WbcBatch([wx200, px100], B)
+    b2.configure(common.config("c3", wx200), 0)
+    with pytest.raises(capi.WbcError, match="share the task/constraint switches"):
+        b2.configure(common.config("c2", px100), 1)
+    b2.configure(common.config("c3", px100), 1)
+    with pytest.raises(capi.WbcError, match="model_id is required"):
+        b2.tick(d, DT)
+    # a status of its own is never visible: WBC_QP_DEFERRED is internal to the two-pass tick
+    out = bt.tick(d, DT)
+    assert out["status"].min() >= 0
+    bt.close()
+    b2.close()
+
+
+def test_infeasible_and_degenerate_instances_agree_with_the_oracle(wx200):
+    """Instances the QP cannot satisfy (trunk far outside its box: the box rows contradict the bounds) must be flagged
+    exactly like the oracle flags them, and must not disturb their neighbours in the batch."""
+    B = 256
+    cfg = common.config("c3", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=61)
+    d["trunk_box_center"] = d["trunk_box_center"].copy()
+    d["trunk_box_center"][::7, 0] *= 3.0            # box centre z three times the trunk height: |rate| >> velocity bounds
+    d["trunk_box_center"][3::11, 1] += 1.0          # roll box one radian away
+    ref = oracle.tick([wx200], [cfg], d, DT, B, nthreads=8)
+    assert (ref["status"] == capi.QP_INFEASIBLE).sum() > 10 and (ref["status"] == 0).sum() > 100
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    for sim3 in (1, 0):
+        bt.set_option("sim3_kernel", sim3)
+        got = bt.tick(d, DT)
+        assert (got["status"] == ref["status"]).all(), sim3
+        ok = ref["status"] == 0
+        assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+    bt.close()
