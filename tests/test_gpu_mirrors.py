@@ -244,3 +244,28 @@ def test_headless_replay_equals_the_mirror_loop():
     assert np.abs(out["real"] - np.array(reals)).max() < 5e-6
     assert np.abs(out["target"][-1] - (start + (K - 1) * step)).max() < 1e-12
     assert (out["q"][0] == out["q"][1]).all() and (out["q"][0] == out["q"][2]).all()      # identical instances stay identical
+
+
+def test_hip_reproduces_kinematics_and_qp_fixtures():
+    """The committed kinematics poses (neutral, stand, mocap, random) and the adversarial QPs through the C-ABI."""
+    from wbc_batch import WbcBatch
+    wx, _ = common.models()
+    z = np.load(os.path.join(HERE, "golden", "kinematics_wx200.npz"))
+    bt = WbcBatch(wx, 32)
+    got = bt.fk(z["q"])
+    for k in ("oMf", "J", "com", "Jcom"):
+        assert np.abs(got[k] - z[k]).max() < 1e-12, k
+    # the LWA end-effector Jacobians = the Grip/foot task rows with unit weights (endEffectorA2, RW4:474-484)
+    cfg = wbc_model.make_config(wx, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=True)
+    bt.configure(cfg)
+    d = common.tick_inputs(wx, cfg, len(z["q"]), seed=0)
+    d["q"] = z["q"]
+    A = bt.assemble(d, DT, want=("A",))["A"]
+    assert np.abs(A[:, :30].reshape(-1, 5, 6, 26) - z["Jee_lwa"]).max() < 1e-12
+    zq = np.load(os.path.join(HERE, "golden", "qp_cases.npz"))
+    x, st, it = bt.qp_solve(zq["H"], zq["g"], zq["C"], zq["lb"], zq["ub"], zq["Clb"], zq["Cub"])
+    assert (st == zq["status"]).all(), dict(zip(zq["names"].tolist(), st.tolist()))
+    ok = zq["status"] == 0
+    assert np.abs(x - zq["x"])[ok].max() < 1e-9
+    assert (it == zq["iters"])[ok].all()
+    bt.close()

@@ -140,3 +140,19 @@ def test_fk_against_hand_geometry(wx):
     oMf = oracle.fk([wx], wx.neutral()[None], want_com=False)["oMf"][0]
     assert np.abs(oMf[capi.FR_EE0 + 4, 9:] - np.array([0.453, 0.0, 0.362825])).max() < 1e-15
     assert np.abs(oMf[capi.FR_EE0 + 0, 9:] - np.array([0.183, -0.13205, -0.4])).max() < 1e-15   # FR foot
+
+
+def test_kinematics_fixture():
+    """tests/golden/kinematics_wx200.npz: neutral, Robot_Wrapper.py:28's stand_joint_config, 8 mocap rows,
+    8 random poses -> oMf, data.J, the five LWA end-effector Jacobians, com, Jcom."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kinematics_wx200.npz"))
+    wx = wbc_model.load_model("a1_wx200")
+    out = oracle.fk([wx], z["q"])
+    for k in ("oMf", "J", "com", "Jcom"):
+        assert np.abs(out[k] - z[k]).max() < 1e-13, k
+    Jee = np.array([[oracle.frame_jacobian(wx, qq, frame=e, rf=2) for e in range(5)] for qq in z["q"]])
+    assert np.abs(Jee - z["Jee_lwa"]).max() < 1e-13
+    # sanity of the stored numbers themselves: at the stand pose the four feet are ~0.28 m below the trunk, level within 2 cm
+    feet_z = z["oMf"][1, :4, 11]
+    assert feet_z.max() - feet_z.min() < 0.02 and -0.33 < feet_z.mean() < -0.22

@@ -130,3 +130,28 @@ def test_tick_problems_satisfy_kkt():
             viol, stat = common.kkt_residuals(a["H"][b], a["g"][b], a["C"][b], a["lb"][b], a["ub"][b], a["Clb"][b], a["Cub"][b], x, act_tol=1e-6)
             scale = 1 + np.abs(a["g"][b]).max()
             assert viol < 1e-7 and stat / scale < 1e-7, (name, b, viol, stat)
+
+
+def test_adversarial_qp_fixture():
+    """tests/golden/qp_cases.npz: every bound active, duplicated and contradictory equality rows, an
+    infeasible box, locked DoF — the oracle reproduces its stored answers, and each feasible answer carries a
+    solver-independent KKT certificate with multipliers of the right sign."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qp_cases.npz"))
+    names = [str(s) for s in z["names"]]
+    x, st, it = oracle.qp_solve(z["H"], z["g"], z["C"], z["lb"], z["ub"], z["Clb"], z["Cub"])
+    assert (st == z["status"]).all() and (it == z["iters"]).all()
+    assert dict(zip(names, st.tolist())) == {"all_bounds_active": 0, "bounds_only": 0, "contradictory_equalities": 2,
+                                             "duplicate_equalities": 0, "infeasible_box": 2, "locked_and_mixed": 0,
+                                             "unconstrained": 0}
+    for i, nm in enumerate(names):
+        if st[i] != 0:
+            continue
+        assert np.abs(x[i] - z["x"][i]).max() < 1e-10, nm
+        viol, stat = common.kkt_residuals(z["H"][i], z["g"][i], z["C"][i], z["lb"][i], z["ub"][i], z["Clb"][i], z["Cub"][i], x[i])
+        scale = max(1.0, np.abs(z["H"][i] @ x[i]).max())
+        assert viol < 1e-8 and stat < 1e-7 * scale, (nm, viol, stat)
+    i = names.index("all_bounds_active")
+    assert (np.abs(z["active"][i][:26]) == 1).all()                      # every variable sits on a bound
+    i = names.index("unconstrained")
+    assert np.abs(x[i] + np.linalg.solve(z["H"][i], z["g"][i])).max() < 1e-9 and not z["active"][i].any()
