@@ -60,13 +60,17 @@ def pmc_issue_busy():
         v = {}
         for line in open(path):
             if "wbc_tick_sim3_kernel" in line:
-                for key in ("SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVES"):
+                for key in ("SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVES",
+                            "SQ_LDS_BANK_CONFLICT"):
                     if " %s " % key in line:
                         v[key] = float(line.split("per_dispatch=")[1])
         cu_cycles = 256.0 * v["GRBM_GUI_ACTIVE"] / 8.0
         return {"valu_busy": v["SQ_ACTIVE_INST_VALU"] / cu_cycles, "lds_busy": v["SQ_LDS_IDX_ACTIVE"] / cu_cycles,
                 "valu_insts_per_tick": v["SQ_INSTS_VALU"] / v["SQ_WAVES"], "lds_insts_per_tick": v["SQ_INSTS_LDS"] / v["SQ_WAVES"],
-                "salu_insts_per_tick": v["SQ_INSTS_SALU"] / v["SQ_WAVES"], "source": "profiles/r01_pmc_summary_v10.txt"}
+                "salu_insts_per_tick": v["SQ_INSTS_SALU"] / v["SQ_WAVES"],
+                "lds_bank_conflict_rate": v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"],
+                "lds_bytes_per_instance": 13264, "vgprs": 168, "waves_per_simd": 3,      # tools/kernel_stats.sh (wbc_tick_sim3_kernel)
+                "source": "profiles/r01_pmc_summary_v10.txt"}
     except Exception:
         return None
 

@@ -287,42 +287,15 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   // Column j is broadcast through S.cl (zero above entry 25); L is stored transposed, Lt[j][i] = L[i][j].
   double* const Lt = S.RA;
   double pmin = 1.0;
-#pragma unroll 1
-  for (int j = 0; j < NM; ++j) {
-    const double pj = rdl(h[0], j);
-    pmin = fmin(pmin, pj);
-    const double rinv = rsqrt(pj);
-    const double l = h[0] * rinv;
-    if (lane < NM) { S.cl[lane] = l; Lt[j * LDJ + lane] = (lane >= j) ? l : 0.0; }
-    if (lane == 0) S.dinv[j] = rinv;
-    WSYNC();
-    const double* cj = S.cl + j;
-    double cm[NM];
-#pragma unroll
-    for (int r = 1; r < NM; ++r) cm[r] = cj[r];
-#pragma unroll
-    for (int r = 1; r < NM; ++r) h[r - 1] = fma(-l, cm[r], h[r]);
-    LDS_THEN_VALU(NM - 1, NM - 1);
-    h[NM - 1] = 0.0;
-    WSYNC();
-  }
-  STAMP(ts, T_CHOL);
-  if (!(pmin > 0.0)) { res.status = WBC_QP_NUMERICAL; return res; }
-
-  // ---- constraint bookkeeping
-  const bool has_b = lane < n, has_r = lane < p;
-  const bool eq_b = has_b && (lb == ub) && (fabs(lb) < QP_INF);
-  const bool eq_r = has_r && (clb == cub) && (fabs(clb) < QP_INF);
-  const unsigned long long eqm_b = __ballot(eq_b), eqm_r = __ballot(eq_r);
-  const int nbe = __popcll(eqm_b), ne = nbe + __popcll(eqm_r);
-  if (ne > NM) { res.status = WBC_QP_NUMERICAL; return res; }   // more equalities than unknowns
-
-  // ---- forward substitutions L y = rhs, one right-hand side per lane, ROTATING registers (same trick):
-  //   lane c < 26        : e_c        -> y = column c of L^-1 = row c of J0 = L^-T
-  //   lane 26 + r, r < p : C_r'       -> y = L^-1 C_r'   (column of B = J0' N for constraint row r)
-  //   lane 26 + p        : g          -> y = L^-1 g
-  // The multipliers Lt[k][k + q] are wave-uniform LDS reads; entries past the diagonal block are zero, so finished
-  // outputs ride along the rotation unchanged.
+  // Forward substitutions L y = rhs, one right-hand side per lane, ROTATING registers (same trick):
+  //   lane c < NM        : e_c        -> y = column c of L^-1 = row c of J0 = L^-T
+  //   lane NM + r, r < p : C_r'       -> y = L^-1 C_r'   (column of B = J0' N for constraint row r)
+  //   lane NM + p        : g          -> y = L^-1 g
+  // Step k needs column k of L — exactly what Cholesky step k broadcasts. For the small instantiation the two sweeps are
+  // therefore FUSED: one loop, one broadcast per step, L never stored (the separate substitution sweep re-read it from LDS:
+  // a quarter of the reduced tick's LDS instructions). NM = 26 keeps two sweeps: h, y and the broadcast together would not
+  // fit the register file.
+  constexpr bool FUSE = NM <= 16;
   if (lane < 32) S.npv[lane] = (lane < n) ? g : 0.0;
   WSYNC();
   double y[NM];
@@ -342,17 +315,57 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   }
   WSYNC();
 #pragma unroll 1
-  for (int k = 0; k < NM; ++k) {
-    const double* lk = Lt + k * LDJ + k;
-    double lm[NM];
-    const double dk = S.dinv[k];
+  for (int j = 0; j < NM; ++j) {
+    const double pj = rdl(h[0], j);
+    pmin = fmin(pmin, pj);
+    const double rinv = rsqrt(pj);
+    const double l = h[0] * rinv;
+    if (lane < NM) { S.cl[lane] = l; if (!FUSE) Lt[j * LDJ + lane] = (lane >= j) ? l : 0.0; }
+    if (!FUSE && lane == 0) S.dinv[j] = rinv;
+    WSYNC();
+    const double* cj = S.cl + j;
+    double cm[NM];
 #pragma unroll
-    for (int q2 = 1; q2 < NM; ++q2) lm[q2] = lk[q2];
-    const double yk = y[0] * dk;
+    for (int r = 1; r < NM; ++r) cm[r] = cj[r];
 #pragma unroll
-    for (int q2 = 1; q2 < NM; ++q2) y[q2 - 1] = fma(-lm[q2], yk, y[q2]);
-    LDS_THEN_VALU(NM, NM);
-    y[NM - 1] = yk;
+    for (int r = 1; r < NM; ++r) h[r - 1] = fma(-l, cm[r], h[r]);
+    if (FUSE) {
+      const double yk = y[0] * rinv;
+#pragma unroll
+      for (int r = 1; r < NM; ++r) y[r - 1] = fma(-cm[r], yk, y[r]);
+      y[NM - 1] = yk;
+      LDS_THEN_VALU(NM - 1, 2 * NM - 1);
+    } else {
+      LDS_THEN_VALU(NM - 1, NM - 1);
+    }
+    h[NM - 1] = 0.0;
+    WSYNC();
+  }
+  STAMP(ts, T_CHOL);
+  if (!(pmin > 0.0)) { res.status = WBC_QP_NUMERICAL; return res; }
+
+  // ---- constraint bookkeeping
+  const bool has_b = lane < n, has_r = lane < p;
+  const bool eq_b = has_b && (lb == ub) && (fabs(lb) < QP_INF);
+  const bool eq_r = has_r && (clb == cub) && (fabs(clb) < QP_INF);
+  const unsigned long long eqm_b = __ballot(eq_b), eqm_r = __ballot(eq_r);
+  const int nbe = __popcll(eqm_b), ne = nbe + __popcll(eqm_r);
+  if (ne > NM) { res.status = WBC_QP_NUMERICAL; return res; }   // more equalities than unknowns
+
+  if (!FUSE) {
+#pragma unroll 1
+    for (int k = 0; k < NM; ++k) {
+      const double* lk = Lt + k * LDJ + k;
+      double lm[NM];
+      const double dk = S.dinv[k];
+#pragma unroll
+      for (int q2 = 1; q2 < NM; ++q2) lm[q2] = lk[q2];
+      const double yk = y[0] * dk;
+#pragma unroll
+      for (int q2 = 1; q2 < NM; ++q2) y[q2 - 1] = fma(-lm[q2], yk, y[q2]);
+      LDS_THEN_VALU(NM, NM);
+      y[NM - 1] = yk;
+    }
   }
   // lanes < 26: y = row `lane` of J0.  jf2 = |J0|_F^2
   double sq = 0.0;
