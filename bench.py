@@ -115,6 +115,10 @@ def main():
     bt.configure(cfg)
     if args.jtj_mfma:
         bt.set_option("jtj_mfma", 1)
+    if os.environ.get("WBC_PRESOLVE") is not None:        # diagnostic A/B: 0 = general path only (no structural presolve, no sim3 kernel)
+        bt.set_option("presolve", int(os.environ["WBC_PRESOLVE"]))
+    if os.environ.get("WBC_SIM3_KERNEL") is not None:     # diagnostic A/B: 0 = presolve inside the general kernel
+        bt.set_option("sim3_kernel", int(os.environ["WBC_SIM3_KERNEL"]))
     if os.environ.get("WBC_DBG_ALIAS"):
         bt.set_option("dbg_alias_inputs", 1)
 

@@ -37,8 +37,7 @@ constexpr int IN_ERR = 96, IN_EPR = 141;                                        
 constexpr int IN_SIZE = 192;
 
 struct __attribute__((aligned(16))) Smem {
-  double RA[NV * LDJ];                  // H -> Lt (Cholesky, Lt[j][i] = L[i][j]) -> B columns -> T = R^-1 (inequality slots)
-  double RApad[LDJ];                    // stays zero: the rotating substitution reads one row past Lt
+  double RA[NV * LDJ];                  // oMi (FK) -> H -> B columns (rows) and L^-1 g -> T = R^-1 (inequality slots)
   double RB[NV * LDJ];                  // J0 = L^-T, then J = J0 Q ; during assembly (with RC): At, the task stack by DoF
   double RC[PMAX * LDJ];                // Cm: constraint rows (p x 26)
   double in[IN_SIZE];                   // this instance's inputs (q, targets, controller state)
@@ -284,18 +283,15 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
 
   // ---- Cholesky H = L L', right-looking, ROTATING registers: at step j register r holds column j + r of the row,
   // so the body is the same for every j (a real loop, ~100 instructions) and the row never leaves the VGPRs.
-  // Column j is broadcast through S.cl (zero above entry 25); L is stored transposed, Lt[j][i] = L[i][j].
-  double* const Lt = S.RA;
+  // Column j is broadcast through S.cl (zero above entry NM - 1); L itself is never stored (the substitutions ride along).
   double pmin = 1.0;
   // Forward substitutions L y = rhs, one right-hand side per lane, ROTATING registers (same trick):
   //   lane c < NM        : e_c        -> y = column c of L^-1 = row c of J0 = L^-T
   //   lane NM + r, r < p : C_r'       -> y = L^-1 C_r'   (column of B = J0' N for constraint row r)
   //   lane NM + p        : g          -> y = L^-1 g
-  // Step k needs column k of L — exactly what Cholesky step k broadcasts. For the small instantiation the two sweeps are
-  // therefore FUSED: one loop, one broadcast per step, L never stored (the separate substitution sweep re-read it from LDS:
-  // a quarter of the reduced tick's LDS instructions). NM = 26 keeps two sweeps: h, y and the broadcast together would not
-  // fit the register file.
-  constexpr bool FUSE = NM <= 16;
+  // Step k needs column k of L — exactly what Cholesky step k broadcasts. The two sweeps are therefore FUSED: one loop,
+  // one broadcast per step, L never stored (the separate substitution sweep re-read it from LDS: a quarter of the reduced
+  // tick's LDS instructions; +14 % ticks/s on the sim3 kernel, +16 % on the general path).
   if (lane < 32) S.npv[lane] = (lane < n) ? g : 0.0;
   WSYNC();
   double y[NM];
@@ -320,8 +316,7 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
     pmin = fmin(pmin, pj);
     const double rinv = rsqrt(pj);
     const double l = h[0] * rinv;
-    if (lane < NM) { S.cl[lane] = l; if (!FUSE) Lt[j * LDJ + lane] = (lane >= j) ? l : 0.0; }
-    if (!FUSE && lane == 0) S.dinv[j] = rinv;
+    if (lane < NM) S.cl[lane] = l;
     WSYNC();
     const double* cj = S.cl + j;
     double cm[NM];
@@ -329,15 +324,11 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
     for (int r = 1; r < NM; ++r) cm[r] = cj[r];
 #pragma unroll
     for (int r = 1; r < NM; ++r) h[r - 1] = fma(-l, cm[r], h[r]);
-    if (FUSE) {
-      const double yk = y[0] * rinv;
+    const double yk = y[0] * rinv;
 #pragma unroll
-      for (int r = 1; r < NM; ++r) y[r - 1] = fma(-cm[r], yk, y[r]);
-      y[NM - 1] = yk;
-      LDS_THEN_VALU(NM - 1, 2 * NM - 1);
-    } else {
-      LDS_THEN_VALU(NM - 1, NM - 1);
-    }
+    for (int r = 1; r < NM; ++r) y[r - 1] = fma(-cm[r], yk, y[r]);
+    y[NM - 1] = yk;
+    LDS_THEN_VALU(NM - 1, 2 * NM - 1);
     h[NM - 1] = 0.0;
     WSYNC();
   }
@@ -352,21 +343,6 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   const int nbe = __popcll(eqm_b), ne = nbe + __popcll(eqm_r);
   if (ne > NM) { res.status = WBC_QP_NUMERICAL; return res; }   // more equalities than unknowns
 
-  if (!FUSE) {
-#pragma unroll 1
-    for (int k = 0; k < NM; ++k) {
-      const double* lk = Lt + k * LDJ + k;
-      double lm[NM];
-      const double dk = S.dinv[k];
-#pragma unroll
-      for (int q2 = 1; q2 < NM; ++q2) lm[q2] = lk[q2];
-      const double yk = y[0] * dk;
-#pragma unroll
-      for (int q2 = 1; q2 < NM; ++q2) y[q2 - 1] = fma(-lm[q2], yk, y[q2]);
-      LDS_THEN_VALU(NM, NM);
-      y[NM - 1] = yk;
-    }
-  }
   // lanes < 26: y = row `lane` of J0.  jf2 = |J0|_F^2
   double sq = 0.0;
 #pragma unroll
@@ -1074,7 +1050,9 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
     }
   }
   WSYNC();
-  // ---- H' into RA (everything else of RA zero: the rotating loops of qp_core<NR> read up to column 2 NR - 2)
+  // ---- H' into RA (rows and columns < NR are all qp_core<NR> reads; the rest is cleared so that nothing of the 26-wide
+  // H survives next to it — and, as a side effect, this store burst keeps hipcc's register allocation of the general
+  // kernel at 200 VGPRs: without it the same code spills 20)
   for (int k = lane; k < NV * LDJ; k += 64) S.RA[k] = 0.0;
   WSYNC();
   if (lane < NR) {
@@ -1490,7 +1468,6 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
   const unsigned long long t_entry = 0;
 #endif
   S.cl[lane] = 0.0;                            // zero padding the rotating loops rely on (never written above entry 25)
-  if (lane < LDJ) S.RApad[lane] = 0.0;
   const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
                     A.in.com_target || A.in.com_target_vel;
   const bool has3 = A.in.ee_ref_rot != nullptr;
@@ -1515,8 +1492,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
 constexpr int CSC = 18;                      // row stride of the reduced constraint matrix (18 = 2 mod 4, >= NR)
 constexpr int PC = WBC_SIM3_MAXP;            // rows of the reduced constraint matrix (kept rows + leg-bound rows)
 struct __attribute__((aligned(16))) SmemC {
-  double RA[NR * LDJ];                  // oMi + m c (FK) -> H' -> Lt -> B columns -> T
-  double RApad[LDJ];                    // stays zero
+  double RA[NR * LDJ];                  // oMi + m c (FK) -> H' -> B columns -> T
   double RB[NR * LDJ];                  // At[k][row] (task stack by reduced variable) -> second-pass oMi -> original C rows -> J
   double RC[PC * CSC];                  // C' (reduced constraint rows)
   double in[128];                       // this instance's inputs (groups 1 and 2)
@@ -1598,8 +1574,6 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   if (lane < NR) {
 #pragma unroll
     for (int k = 0; k < NR; k += 2) sts2(S.RA + lane * LDJ + k, 0.0, 0.0);
-#pragma unroll
-    for (int k = NR; k < LDJ; k += 2) sts2(S.RA + lane * LDJ + k, 0.0, 0.0);   // the rotating loops read past column 15
   }
   const bool stores = my_pos >= 0;
   const int arow = (stores ? my_pos : 0) * mtp;
@@ -1933,7 +1907,6 @@ __global__ void __launch_bounds__(64, 3) wbc_tick_sim3_kernel(const KernelArgs A
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   if (lane < 48) S.cl[lane] = 0.0;
-  if (lane < LDJ) S.RApad[lane] = 0.0;
   const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot;
   const int mid = A.in.model_id ? __builtin_amdgcn_readfirstlane(A.in.model_id[b]) : 0;
   const InRegs cur = load_inputs(A.in, A.dbg_alias ? 0 : b, lane, has2, false);
@@ -1963,8 +1936,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_deferred_kernel(const KernelAr
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     S.cl[lane] = 0.0;
-    if (lane < LDJ) S.RApad[lane] = 0.0;
-    const int mid = A.in.model_id ? __builtin_amdgcn_readfirstlane(A.in.model_id[b]) : 0;
+      const int mid = A.in.model_id ? __builtin_amdgcn_readfirstlane(A.in.model_id[b]) : 0;
     const InRegs cur = load_inputs(A.in, b, lane, has2, has3);
     const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);
     stage_inputs(S, cur, lane, has2, has3);
@@ -1978,7 +1950,6 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_deferred_kernel(const KernelAr
 __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
   __shared__ Smem S;
   S.cl[threadIdx.x] = 0.0;
-  if (threadIdx.x < LDJ) S.RApad[threadIdx.x] = 0.0;
 #pragma unroll 1
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     int lane = threadIdx.x, n = A.n, p = A.p, m = A.m;
