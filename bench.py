@@ -157,7 +157,7 @@ def main():
 
     # closed loop: K chained ticks on the device = tick + updateState/trunkWorldPos + reference-state advance
     closed = None
-    if args.rollout_ticks > 0:
+    if args.rollout_ticks > 0 and world == 1:     # extra leg, single-GPU runs only
         step_t = torch.zeros((B, 5, 3), dtype=torch.float64, device=dev)
         step_t[:, 4, 0] = 1e-4
         bt.rollout(dev_in, DT, 2, ee_target_step=step_t, want_trace=False)
@@ -198,7 +198,7 @@ def main():
         }
         if closed is not None:
             line["closed_loop"] = closed
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle   # checker / yardstick only
             cores = len(os.sched_getaffinity(0))
