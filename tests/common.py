@@ -102,3 +102,54 @@ def kkt_residuals(H, g, C, lb, ub, cl, cu, x, act_tol=1e-7):
     else:
         stat = np.abs(r).max()
     return viol, stat
+
+
+def exact_kkt(H, g, rows, rhs):
+    """Exact (rational) solution of  H x + N'lam = -g,  N x = rhs  for double-precision data; returns (x, lam) as floats."""
+    from fractions import Fraction
+    n, p = len(g), len(rhs)
+    N = n + p
+    M = [[Fraction(0)] * (N + 1) for _ in range(N)]
+    for i in range(n):
+        for j in range(n):
+            M[i][j] = Fraction(float(H[i, j]))
+        for j in range(p):
+            M[i][n + j] = M[n + j][i] = Fraction(float(rows[j][i]))
+        M[i][N] = Fraction(float(-g[i]))
+    for j in range(p):
+        M[n + j][N] = Fraction(float(rhs[j]))
+    for c in range(N):
+        piv = max(range(c, N), key=lambda r: abs(M[r][c]))
+        assert M[piv][c] != 0, "active rows are dependent"
+        M[c], M[piv] = M[piv], M[c]
+        inv = 1 / M[c][c]
+        for r in range(N):
+            if r != c and M[r][c] != 0:
+                f = M[r][c] * inv
+                M[r] = [a - f * b for a, b in zip(M[r], M[c])]
+    sol = [float(M[i][N] / M[i][i]) for i in range(N)]
+    return np.array(sol[:n]), np.array(sol[n:])
+
+
+
+def exact_optimum(H, g, C, lb, ub, Clb, Cub, x_float):
+    """The exact optimum of the double-precision QP data on the active set read off `x_float`, with the optimality checks
+    (primal feasibility, multiplier signs) asserted. Returns x_exact."""
+    n = len(g)
+    lo, hi = np.concatenate([lb, Clb]), np.concatenate([ub, Cub])
+    Nall = np.vstack([np.eye(n), C])
+    v = Nall @ x_float
+    rows, rhs, kind = [], [], []
+    for i in range(len(lo)):
+        if lo[i] == hi[i]:
+            rows.append(Nall[i]); rhs.append(lo[i]); kind.append(0)
+        elif abs(v[i] - lo[i]) < 1e-7 * max(1, abs(lo[i])):
+            rows.append(Nall[i]); rhs.append(lo[i]); kind.append(-1)
+        elif abs(v[i] - hi[i]) < 1e-7 * max(1, abs(hi[i])):
+            rows.append(Nall[i]); rhs.append(hi[i]); kind.append(+1)
+    x, lam = exact_kkt(H, g, rows, rhs)
+    vx = Nall @ x
+    assert (vx >= lo - 1e-9 * np.maximum(1, np.abs(lo))).all() and (vx <= hi + 1e-9 * np.maximum(1, np.abs(hi))).all()
+    for k, l in zip(kind, lam):              # H x + g + N'lam = 0: at a lower bound lam <= 0, at an upper bound lam >= 0
+        assert not (k == -1 and l > 1e-9 * (1 + abs(l))) and not (k == +1 and l < -1e-9 * (1 + abs(l)))
+    return x

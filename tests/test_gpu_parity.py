@@ -501,3 +501,24 @@ def test_infeasible_and_degenerate_instances_agree_with_the_oracle(wx200):
         ok = ref["status"] == 0
         assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
     bt.close()
+
+
+def test_gpu_solution_against_the_exact_optimum(wx200):
+    """The device's q̇ against the EXACT (rational-arithmetic) optimum of the double-precision QP data it assembled itself:
+    no oracle in between. Both kernels (compact sim3 kernel / general path) must be as close to the truth as the oracle is."""
+    cfg = common.config("c3", wx200)
+    B = 3
+    d = common.tick_inputs(wx200, cfg, B, seed=71)
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    a = bt.assemble(d, DT)
+    for sim3 in (1, 0):
+        bt.set_option("sim3_kernel", sim3)
+        bt.set_option("presolve", sim3)
+        got = bt.tick(d, DT)
+        for b in range(B):
+            assert got["status"][b] == 0
+            x = common.exact_optimum(a["H"][b], a["g"][b], a["C"][b], a["lb"][b], a["ub"][b], a["Clb"][b], a["Cub"][b], got["qdot"][b])
+            err = np.abs(got["qdot"][b] - x).max()
+            assert err < 2e-6, (sim3, b, err)
+    bt.close()

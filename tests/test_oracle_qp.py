@@ -157,33 +157,6 @@ def test_adversarial_qp_fixture():
     assert np.abs(x[i] + np.linalg.solve(z["H"][i], z["g"][i])).max() < 1e-9 and not z["active"][i].any()
 
 
-def _exact_kkt(H, g, rows, rhs):
-    """Exact (rational) solution of  H x + N'lam = -g,  N x = rhs  for double-precision data; returns (x, lam) as floats."""
-    from fractions import Fraction
-    n, p = len(g), len(rhs)
-    N = n + p
-    M = [[Fraction(0)] * (N + 1) for _ in range(N)]
-    for i in range(n):
-        for j in range(n):
-            M[i][j] = Fraction(float(H[i, j]))
-        for j in range(p):
-            M[i][n + j] = M[n + j][i] = Fraction(float(rows[j][i]))
-        M[i][N] = Fraction(float(-g[i]))
-    for j in range(p):
-        M[n + j][N] = Fraction(float(rhs[j]))
-    for c in range(N):
-        piv = max(range(c, N), key=lambda r: abs(M[r][c]))
-        assert M[piv][c] != 0, "active rows are dependent"
-        M[c], M[piv] = M[piv], M[c]
-        inv = 1 / M[c][c]
-        for r in range(N):
-            if r != c and M[r][c] != 0:
-                f = M[r][c] * inv
-                M[r] = [a - f * b for a, b in zip(M[r], M[c])]
-    sol = [float(M[i][N] / M[i][i]) for i in range(N)]
-    return np.array(sol[:n]), np.array(sol[n:])
-
-
 def test_oracle_solution_is_the_exact_optimum_on_benchmark_ticks():
     """Strongest solver-independent pin available here: for ticks of the benchmark configuration, take the active set the
     oracle ended with, solve the KKT system of the double-precision QP data EXACTLY (rational arithmetic), and check that
@@ -199,24 +172,5 @@ def test_oracle_solution_is_the_exact_optimum_on_benchmark_ticks():
     for b in range(B):
         assert t["status"][b] == 0
         H, g, C = a["H"][b], a["g"][b], a["C"][b]
-        lo = np.concatenate([a["lb"][b], a["Clb"][b]])
-        hi = np.concatenate([a["ub"][b], a["Cub"][b]])
-        Nall = np.vstack([np.eye(26), C])
-        v = Nall @ t["qdot"][b]
-        rows, rhs, kind = [], [], []
-        for i in range(len(lo)):
-            if lo[i] == hi[i]:
-                rows.append(Nall[i]); rhs.append(lo[i]); kind.append(0)
-            elif abs(v[i] - lo[i]) < 1e-7 * max(1, abs(lo[i])):
-                rows.append(Nall[i]); rhs.append(lo[i]); kind.append(-1)
-            elif abs(v[i] - hi[i]) < 1e-7 * max(1, abs(hi[i])):
-                rows.append(Nall[i]); rhs.append(hi[i]); kind.append(+1)
-        x, lam = _exact_kkt(H, g, rows, rhs)
-        vx = Nall @ x
-        assert (vx >= lo - 1e-9 * np.maximum(1, np.abs(lo))).all() and (vx <= hi + 1e-9 * np.maximum(1, np.abs(hi))).all()
-        for k, l in zip(kind, lam):          # H x + g + N'lam = 0:  at a lower bound lam <= 0, at an upper bound lam >= 0
-            if k == -1:
-                assert l <= 1e-9 * (1 + abs(l))
-            if k == +1:
-                assert l >= -1e-9 * (1 + abs(l))
+        x = common.exact_optimum(H, g, C, a["lb"][b], a["ub"][b], a["Clb"][b], a["Cub"][b], t["qdot"][b])
         assert np.abs(t["qdot"][b] - x).max() < 2e-6, np.abs(t["qdot"][b] - x).max()
