@@ -191,8 +191,42 @@ static int rows_con(const WbcConfig& c) {
 // Enabled only when (1) every contact foot's rows are supported by the 6 base DoF + 3 own leg DoF, the leg sets disjoint,
 // (2) NO active task touches an eliminated leg DoF (then H_ll = d^2 I, H_lf = 0 and the reduction costs no accuracy),
 // (3) the reduced problem fits qp_core<16>.
+// qpJointb "MANI"/"HYBRID" (Robot_Wrapper4.py:1220-1260) analysed on the tree: DoF i differentiates joint_id with respect to
+// q[qi]; that finite difference is exactly zero unless q[qi] belongs to the free-flyer or to a PROPER ancestor of joint_id
+// (wbc_posture_kernel makes the same test per sweep). If no sweep matters the tick kernels need no posture kernel at all.
+static void build_posture_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) {
+  const int mode = c.task_joint;
+  if (mode != WBC_JOINT_MANI && mode != WBC_JOINT_HYBRID) return;
+  const int literal = c.posture_literal;
+  uint32_t zero = 0, pert = 0;
+  for (int i = 0; i < M.nv; ++i) {
+    int joint_id;
+    if (mode == WBC_JOINT_MANI) joint_id = (i < 6) ? 1 : i - 4;
+    else { joint_id = i - 6; if (joint_id < c.arm_base_id) continue; }
+    if (joint_id >= M.njoints) continue;
+    const int qi = literal ? i : ((i < 6) ? i : i + 1);
+    if (qi < 7) return;                                    // the free-flyer moves everything: the sweeps are needed
+    int jp = -1;
+    for (int j = 2; j < M.njoints; ++j) if (M.idx_q[j] == qi) jp = j;
+    if (jp < 0) return;
+    if (jp != joint_id && ((M.col_subtree[M.idx_v_of[jp]] >> joint_id) & 1u)) return;   // a proper ancestor: matters
+    zero |= 1u << i;
+    if (literal) pert |= 1u << qi;
+  }
+  if (mode == WBC_JOINT_MANI) return;                      // (MANI starts from u = 0, not PREV; it never gets here anyway: i < 6)
+  P->post_static = 1; P->post_zero = zero; P->post_pert = pert;
+  // does an active constraint depend on a perturbed joint? (then the second FK pass is needed)
+  uint32_t dofs = 0;
+  for (int k = 0; k < M.nv; ++k) if ((pert >> M.col_q[k]) & 1u) dofs |= 1u << k;
+  bool dep = c.con_com != 0 && dofs != 0;
+  if (c.con_trunk && (M.frame_support[WBC_FR_TRUNK] & dofs)) dep = true;
+  for (int e = 0; e < WBC_NEE; ++e) if (c.con_ee[e] && (M.frame_support[WBC_FR_EE0 + e] & dofs)) dep = true;
+  P->post_fk2 = dep ? 1 : 0;
+}
+
 static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan* P) {
   memset(P, 0, sizeof *P);
+  build_posture_plan(M, c, P);
   for (int i = 0; i < 32; ++i) { P->pos[i] = -1; P->lidx[i] = -1; }
   uint32_t legmask = 0;
   int prow = (c.con_com ? 2 : 0) + (c.con_trunk ? 4 : 0), nelim = 0, l = 0;
@@ -382,6 +416,15 @@ static int auto_posture(WbcBatch* b, KernelArgs& a, int B, void* stream) {
     if (tj == WBC_JOINT_MANI || tj == WBC_JOINT_HYBRID) { need = true; literal |= b->cfg_host[i].posture_literal != 0; }
   }
   if (!need || a.in.posture_u) return WBC_OK;
+  if (b->presolve) {   // every sweep structurally zero on every model: the tick derives u and the leaked state itself
+    bool all_static = true;
+    for (int i = 0; i < b->n_models; ++i) {
+      const int tj = b->cfg_host[i].task_joint;
+      if ((tj == WBC_JOINT_MANI || tj == WBC_JOINT_HYBRID) && !b->plan_host[i].post_static) all_static = false;
+      if (tj != WBC_JOINT_MANI && tj != WBC_JOINT_HYBRID && tj >= WBC_JOINT_MANI) all_static = false;
+    }
+    if (all_static && !a.in.q_con) { a.post_static = 1; return WBC_OK; }
+  }
   if (!b->d_pu) {
     HIP_TRY(hipMalloc((void**)&b->d_pu, sizeof(double) * WBC_V_STRIDE * (size_t)b->max_batch));
     HIP_TRY(hipMalloc((void**)&b->d_pq, sizeof(double) * WBC_Q_STRIDE * (size_t)b->max_batch));

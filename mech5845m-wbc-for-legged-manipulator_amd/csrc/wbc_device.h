@@ -38,7 +38,13 @@ struct DevPlan {
   int32_t enabled, nelim, n_red, p_keep;
   uint32_t elimrows;                 // bit i: constraint row i belongs to an eliminated foot
   uint32_t legrows;                  // bit i: kept constraint row i has support on eliminated leg DoF (needs C Z)
-  int32_t pad_[2];
+  // qpJointb "MANI"/"HYBRID" when EVERY finite difference is structurally zero (the perturbed joint is not a proper ancestor
+  // of the differentiated joint — all twelve sweeps of the reference's HYBRID indices): no posture kernel is launched, the
+  // tick derives u and the leaked state itself.
+  int32_t post_static;               // 1: u_i = post_zero bit ? 0 : PREV_i, q_con = q with the post_pert entries at (q+d)-2d
+  int32_t post_fk2;                  // 1: an active constraint depends on a perturbed joint -> second FK pass needed
+  uint32_t post_zero;                // DoF bits
+  uint32_t post_pert;                // q-index bits (literal mode only; 0 when the configuration is restored)
   int32_t rowstart[4];               // first constraint row of eliminated foot f
   int32_t legd[12];                  // DoF index of eliminated leg DoF l (feet in constraint order, DoF ascending)
   int32_t Fd[WBC_PLAN_NR];           // DoF index of reduced variable k (0 beyond n_red)
@@ -54,6 +60,7 @@ struct KernelArgs {
   const WbcConfig* cfgs;
   const DevPlan* plans;
   int32_t B, mrows, prows, mcart;   // mcart = Cartesian task rows (excludes the diagonal posture block)
+  int32_t post_static;              // every model's DevPlan.post_static (then no posture kernel runs)
   int32_t dbg_alias;                // diagnostic: every wave loads instance 0's inputs (isolates HBM input latency)
   int32_t pad1_;
   int32_t jtj_mfma, presolve;  // presolve: structural elimination of the contact equalities (default on)

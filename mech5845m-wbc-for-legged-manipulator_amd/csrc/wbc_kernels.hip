@@ -1278,7 +1278,10 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
   if (cfg.task_joint) {
     dpost = (1.0 / nv) * cfg.joint_w;
     if (cfg.task_joint == WBC_JOINT_PREV && lane < nv) upost = qv[lane < 6 ? lane : lane + 1];   // np.delete(q, 6)
-    if (cfg.task_joint >= WBC_JOINT_MANI && lane < nv) upost = inr.pu;   // MANI / HYBRID (:1220-1260): wbc_posture_kernel's u
+    if (cfg.task_joint >= WBC_JOINT_MANI && lane < nv) {               // MANI / HYBRID (:1220-1260)
+      if (A.post_static) upost = ((P.post_zero >> lane) & 1u) ? 0.0 : qv[lane < 6 ? lane : lane + 1];   // see DevPlan.post_static
+      else upost = inr.pu;                                              // wbc_posture_kernel's u (or the caller's)
+    }
     const double bj = (1.0 / nv) * upost * cfg.joint_w;
     if (lane < nv) g = fma(-dpost, bj, g);
     upost = bj;
@@ -1314,6 +1317,12 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     WSYNC();
     fk_pass(S, S.RB, qv, M, lc, cfg.con_com != 0, lane, fo);
     WSYNC();
+  } else if (A.post_static && P.post_pert) {
+    // the same state leak when every finite difference of qpJointb is structurally zero (DevPlan.post_static): each
+    // perturbed entry is left at (q + d) - 2 d, and the kinematics are redone only if an active constraint depends on one
+    if (lane < NQ && ((P.post_pert >> lane) & 1u)) S.in[IN_Q + lane] = (qv[lane] + 0.0002) - (0.0002 * 2);
+    WSYNC();
+    if (P.post_fk2) { fk_pass(S, S.RB, qv, M, lc, cfg.con_com != 0, lane, fo); WSYNC(); }
   }
 
   // ---- P6: constraints in order CoM, Trunk, FR, FL, RR, RL, Grip: findConstraints (Robot_Wrapper4.py:764-836)
@@ -1678,7 +1687,10 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   {
     double upost = 0.0;
     if (cfg.task_joint == WBC_JOINT_PREV && lane < nv) upost = qv[lane < 6 ? lane : lane + 1];
-    if (cfg.task_joint >= WBC_JOINT_MANI && lane < nv) upost = inr.pu;
+    if (cfg.task_joint >= WBC_JOINT_MANI && lane < nv) {
+      if (A.post_static) upost = ((P.post_zero >> lane) & 1u) ? 0.0 : qv[lane < 6 ? lane : lane + 1];   // see DevPlan.post_static
+      else upost = inr.pu;
+    }
     const double bj = (1.0 / nv) * upost * cfg.joint_w;
     if (lane < nv) g = fma(-dpost, bj, g);
   }
@@ -1691,6 +1703,10 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     WSYNC();
     fk_pass(S, S.RB, qv, M, lc, cfg.con_com != 0, lane, fo);
     WSYNC();
+  } else if (A.post_static && P.post_pert) {   // same leak, structurally-zero gradients (see process_instance)
+    if (lane < NQ && ((P.post_pert >> lane) & 1u)) S.in[IN_Q + lane] = (qv[lane] + 0.0002) - (0.0002 * 2);
+    WSYNC();
+    if (P.post_fk2) { fk_pass(S, S.RB, qv, M, lc, cfg.con_com != 0, lane, fo); WSYNC(); }
   }
 
   // ---- original constraint rows (findConstraints order, Robot_Wrapper4.py:764-836) into the scratch image Co = RB [p][26]
