@@ -522,3 +522,24 @@ def test_gpu_solution_against_the_exact_optimum(wx200):
             err = np.abs(got["qdot"][b] - x).max()
             assert err < 2e-6, (sim3, b, err)
     bt.close()
+
+
+@pytest.mark.parametrize("B", [1, 63, 64, 65, 1000])
+def test_ragged_batch_sizes(wx200, B):
+    """Batch sizes around the 64-status granularity of the deferred pass and a handle larger than the batch: every
+    instance is solved, nothing beyond B is touched."""
+    cfg = common.config("c3", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=90 + B)
+    ref = oracle.tick([wx200], [cfg], d, DT, B, nthreads=8)
+    bt = WbcBatch(wx200, 1024)                       # max_batch > B
+    bt.configure(cfg)
+    guard = 7
+    out = dict(qdot=np.full((B + guard, 26), -77.0), status=np.full(B + guard, -5, dtype=np.int32),
+               iters=np.full(B + guard, -5, dtype=np.int32), q_next=np.full((B + guard, 27), -77.0))
+    views = {k: v[:B] for k, v in out.items()}
+    got = bt.tick(d, DT, out=views)
+    assert (got["status"] == ref["status"]).all()
+    ok = ref["status"] == 0
+    assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+    assert (out["qdot"][B:] == -77.0).all() and (out["status"][B:] == -5).all() and (out["q_next"][B:] == -77.0).all()
+    bt.close()
