@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Soak comparison (GPU box): large seeded batches of the benchmark configurations through the HIP path and the CPU oracle;
+reports status agreement and the q̇ error distribution. Not a pytest (minutes of CPU time): python tools/soak.py [B] [seeds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "mech5845m-wbc-for-legged-manipulator_amd")]
+import numpy as np, oracle, common, wbc_model
+from wbc_batch import WbcBatch
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+wx, px = common.models()
+threads = len(os.sched_getaffinity(0))
+worst = 0.0
+for cfg_name in ("c3", "c3_hybrid", "c2", "everything"):
+    for mixed in (False, True):
+        if mixed and cfg_name != "c3":
+            continue
+        models = [wx, px] if mixed else [wx]
+        cfgs = [common.config(cfg_name, m) for m in models]
+        bt = WbcBatch(models, B)
+        for i, c in enumerate(cfgs):
+            bt.configure(c, i)
+        for seed in range(seeds):
+            n = B if cfg_name in ("c3", "c3_hybrid") else B // 8
+            if mixed:
+                mid = (np.arange(n) % 2).astype(np.int32)
+                parts = [common.tick_inputs(m, c, n, 1000 + seed + 17 * k) for k, (m, c) in enumerate(zip(models, cfgs))]
+                d = {k: np.where(mid.reshape((n,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+                d["model_id"] = mid
+            else:
+                d = common.tick_inputs(wx, cfgs[0], n, 1000 + seed, with_rot=(cfg_name == "everything"))
+            t0 = time.perf_counter()
+            ref = oracle.tick(models, cfgs, d, 0.002, n, nthreads=threads, want_q_next=False)
+            t1 = time.perf_counter()
+            got = bt.tick(d, 0.002)
+            ok = (ref["status"] == 0) & (got["status"] == 0)
+            err = np.abs(got["qdot"] - ref["qdot"]).max(axis=1)
+            agree = (ref["status"] == got["status"]).mean()
+            bad = int((~np.isfinite(got["qdot"])).any(axis=1).sum())
+            worst = max(worst, err[ok].max())
+            print("%-11s mixed=%d seed %d n=%d: status agree %.6f (optimal %.4f, infeasible %.4f), qdot err max %.2e p99.9 %.2e, "
+                  "non-finite rows %d, oracle %.1f s" % (cfg_name, mixed, seed, n, agree, (ref["status"] == 0).mean(),
+                                                          (ref["status"] == 2).mean(), err[ok].max(), np.quantile(err[ok], 0.999), bad, t1 - t0), flush=True)
+        bt.close()
+print("worst qdot error over all optimal instances: %.3e" % worst)
