@@ -125,6 +125,13 @@ def load_library(path=None):
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise WbcError("HIP extension not built: %s is missing (run `python __graft_entry__.py build`)" % p)
+    # PyTorch ships its own copy of the HIP runtime. If this library (linked against /opt/rocm's) is loaded first and torch
+    # afterwards, the process ends up with two runtimes and the second one to initialise sees no device. Loading torch
+    # first makes both share one runtime; without torch installed there is only ours.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
