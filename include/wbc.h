@@ -22,6 +22,8 @@
  * PyBullet and scipy; Jacobian rows are linear 0-2, angular 3-5 (pinocchio Motion order).
  * Buffers are caller-allocated; `mem` says whether the pointers are host (the library stages them
  * through its own device workspace) or device pointers (used in place, zero copies).
+ * With device pointers every call only enqueues kernels (and, on first use of a feature, allocates its workspace):
+ * after one warm-up call the same call sequence can be captured into a hipGraph on the caller's stream.
  * Return value: 0 = ok, negative = API-level failure (message via wbc_last_error()).  Per-instance
  * solver outcome goes to the `status` array.  No global state except the thread-local error string;
  * handles are not thread-safe, independent handles may be used concurrently.
