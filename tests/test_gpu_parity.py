@@ -543,3 +543,38 @@ def test_ragged_batch_sizes(wx200, B):
     assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
     assert (out["qdot"][B:] == -77.0).all() and (out["status"][B:] == -5).all() and (out["q_next"][B:] == -77.0).all()
     bt.close()
+
+
+def test_tick_can_be_captured_into_a_graph(wx200):
+    """include/wbc.h: with device pointers a call only enqueues kernels, so after one warm-up call it can be captured on
+    the caller's stream (here through torch's HIP-graph wrapper) and replayed."""
+    import torch
+    B = 512
+    cfg = common.config("c3", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=14)
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    dev = torch.device("cuda", 0)
+    dd = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in d.items()}
+    out = dict(qdot=torch.zeros((B, 26), dtype=torch.float64, device=dev), status=torch.zeros(B, dtype=torch.int32, device=dev),
+               iters=torch.zeros(B, dtype=torch.int32, device=dev), q_next=torch.zeros((B, 27), dtype=torch.float64, device=dev))
+    step = bt.make_tick_call(dd, out, DT)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        step()                                   # warm-up: workspaces are allocated here, not during capture
+    side.synchronize()
+    ref = {k: v.clone() for k, v in out.items()}
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        step()
+    for v in out.values():
+        v.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for k in out:
+        assert torch.equal(out[k], ref[k]), k
+    dd["q"][:, 19] += 0.01                       # new inputs in the same buffers: the replay follows them
+    g.replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(out["qdot"], ref["qdot"])
+    bt.close()
