@@ -164,7 +164,8 @@ typedef struct WbcQpData {
 } WbcQpData;
 
 typedef struct WbcTickOut {
-  double* qdot;     /* [B][26] xOpt                                                       */
+  double* qdot;     /* [B][26] xOpt; all zeros for an instance whose status is not WBC_QP_OPTIMAL (the reference's xOpt on
+                       its first QP: qpOASES does not write the vector of an unsolved problem, QP_Wrapper.py:50-51) */
   int32_t* status;  /* [B] WBC_QP_*                                                       */
   int32_t* iters;   /* [B] working-set changes (may be NULL)                              */
   double* q_next;   /* [B][27] pin.integrate(q, qdot*dt) (may be NULL)                    */

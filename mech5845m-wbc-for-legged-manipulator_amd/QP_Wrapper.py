@@ -90,7 +90,8 @@ class QP:
     def solveQP(self):
         x = self._solve()
         self.xOpt = np.zeros((self.no_solutions,))
-        self.xOpt[:] = x
+        if self.status == 0:            # qpOASES' getPrimalSolution leaves its argument alone for an unsolved QP (:50-51)
+            self.xOpt[:] = x
         return self.xOpt
 
     def solveQPHotstart(self, A, b, lb, ub, C, Clb, Cub):
@@ -105,5 +106,7 @@ class QP:
         self._A, self._b = A, b
         self._H = self._g = None
         self.nWSR = np.array([100000])
-        self.xOpt[:] = self._solve()
+        x = self._solve()
+        if self.status == 0:            # unsolved: xOpt keeps the previous tick's answer, as in the reference (:71-73)
+            self.xOpt[:] = x
         return self.xOpt

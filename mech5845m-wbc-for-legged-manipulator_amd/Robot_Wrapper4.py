@@ -178,6 +178,7 @@ class RobotModel:
         self.firstQP = True
         self.qp = None
         self.solver_status, self.solver_iters = None, None
+        self.q_vel = None
         self.FL_base_pos = np.copy(self.robot_data.oMf[self.end_effector_index_list_frame[1]].translation)
         self.print_ = False
         self.end_effector_A = self.end_effector_B = self.trunk_A = self.trunk_B = 0
@@ -470,6 +471,14 @@ class RobotModel:
         self._bt.configure(cfg)
         out = self._bt.tick(self._tick_inputs(target_EE, target_trunk), self.dt, want_q_next=True)
         self.solver_status, self.solver_iters = int(out["status"][0]), int(out["iters"][0])
+        if self.solver_status != 0 and getattr(self, "q_vel", None) is not None:
+            # an unsolved QP leaves qpOASES' xOpt at the previous tick's answer (QP_Wrapper.py:71-73): the reference keeps
+            # moving with the stale velocity; the device returns 0, so the stale vector is integrated here
+            q = np.zeros((1, capi.Q_STRIDE))
+            q[0, :self._model.nq] = self.current_joint_config
+            v = np.zeros((1, capi.V_STRIDE))
+            v[0, :self._model.nv] = self.q_vel
+            return np.array(self.q_vel), self._bt.integrate(q, v, self.dt)[0, :self._model.nq]
         return out["qdot"][0, :self._model.nv], out["q_next"][0, :self._model.nq]
 
     def runWBC(self, base_config, target_cartesian_pos_EE=None, target_cartesian_pos_trunk=None):

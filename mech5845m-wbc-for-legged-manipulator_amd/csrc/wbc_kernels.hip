@@ -625,7 +625,9 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   }
 done:
   STAMP(ts, T_INEQ);
-  res.x = x;
+  // a QP that was not solved returns x = 0 (the reference's xOpt on its first QP: qpOASES does not write the primal vector
+  // of an unsolved problem, QP_Wrapper.py:50, 71-73) — and a roll-out holds still instead of integrating a partial iterate
+  res.x = (res.status == WBC_QP_OPTIMAL) ? x : 0.0;
   res.iters = iters;
   return res;
 }

@@ -572,8 +572,21 @@ static double con_value(const QpCons* Q, int c, const double* x) { /* a'x */
 
 #define QN 32 /* max n handled by the oracle QP */
 
+static int qp_solve_body(int n, int p, const double* H, const double* g, const double* C, const double* lb,
+                         const double* ub, const double* Clb, const double* Cub, double* x, int* iters_out);
+/* Contract for a QP that was not solved (iteration cap, infeasible, numerical): x = 0. The reference ignores qpOASES'
+ * return value; qpOASES' getPrimalSolution() does not write its argument unless the QP is solved, so xOpt keeps what it
+ * held — zeros on the first QP (QP_Wrapper.py:50), the previous tick's answer afterwards (QP_Wrapper.py:71-73). The batched
+ * path has no "previous answer" per call: it returns the first-call value, 0 (hold still), and the mirrors keep the stale
+ * vector like the reference. */
 int orc_qp_solve(int n, int p, const double* H, const double* g, const double* C, const double* lb,
                  const double* ub, const double* Clb, const double* Cub, double* x, int* iters_out) {
+  const int st = qp_solve_body(n, p, H, g, C, lb, ub, Clb, Cub, x, iters_out);
+  if (st != WBC_QP_OPTIMAL) for (int i = 0; i < n; ++i) x[i] = 0.0;
+  return st;
+}
+static int qp_solve_body(int n, int p, const double* H, const double* g, const double* C, const double* lb,
+                         const double* ub, const double* Clb, const double* Cub, double* x, int* iters_out) {
   if (n > QN || p > 64) return WBC_QP_NUMERICAL;
   QpCons Q = {n, p, C, lb, ub, Clb, Cub};
   double L[QN][QN], J[QN][QN], R[QN][QN], d[QN], z[QN], r[QN], u[QN + 1], np[QN];

@@ -269,3 +269,24 @@ def test_hip_reproduces_kinematics_and_qp_fixtures():
     assert np.abs(x - zq["x"])[ok].max() < 1e-9
     assert (it == zq["iters"])[ok].all()
     bt.close()
+
+
+def test_qp_class_keeps_the_stale_answer_for_an_unsolved_qp():
+    """qpOASES' getPrimalSolution does not write an unsolved problem's vector (QP_Wrapper.py:50-51, 71-73): zeros on the
+    first QP, the previous answer on a hot start."""
+    from QP_Wrapper import QP
+    rng = np.random.default_rng(0)
+    n, p = 6, 2
+    A = rng.normal(size=(10, n))
+    b = rng.normal(size=10)
+    lb, ub = -np.ones(n), np.ones(n)
+    C = np.zeros((n, p))
+    C[0, 0] = 1.0
+    C[1, 1] = 1.0
+    qp = QP(A, b, lb, ub, C, np.array([-0.5, -0.5]), np.array([0.5, 0.5]), n_of_velocity_dimensions=n)
+    x0 = qp.solveQP().copy()
+    assert qp.status == 0 and np.abs(x0).max() > 0
+    x1 = qp.solveQPHotstart(A, b, lb, ub, C, np.array([2.0, -0.5]), np.array([3.0, 0.5]))   # x0 >= 2 against the bound x0 <= 1
+    assert qp.status == 2 and np.array_equal(x1, x0)
+    bad = QP(A, b, lb, ub, C, np.array([2.0, -0.5]), np.array([3.0, 0.5]), n_of_velocity_dimensions=n)
+    assert not bad.solveQP().any() and bad.status == 2

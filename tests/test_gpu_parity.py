@@ -500,6 +500,28 @@ def test_infeasible_and_degenerate_instances_agree_with_the_oracle(wx200):
         assert (got["status"] == ref["status"]).all(), sim3
         ok = ref["status"] == 0
         assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+        # an unsolved QP returns q̇ = 0 (what the reference's xOpt holds on its first QP, QP_Wrapper.py:50-51): hold still
+        assert (got["qdot"][~ok] == 0).all() and (ref["qdot"][~ok] == 0).all()
+    bt.close()
+
+
+def test_rollouts_are_deterministic_and_survive_unsolvable_ticks(wx200):
+    """Run-to-run bit equality of a long roll-out in which some instances run into unsolvable QPs on the way (they hold
+    still from then on instead of integrating a partial iterate into garbage — found with tools/determinism.py)."""
+    B, K = 8192, 50
+    cfg = common.config("c3", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=3)
+    step = np.zeros((B, 5, 3))
+    step[:, 4, 0] = 1e-4
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    r1 = bt.rollout(d, DT, K, ee_target_step=step)
+    bt.fk(d["q"][:777])                                   # different LDS leftovers in between
+    r2 = bt.rollout(d, DT, K, ee_target_step=step)
+    for k in r1:
+        assert np.array_equal(r1[k], r2[k]), k
+    assert np.isfinite(r1["q"]).all() and np.abs(r1["q"][:, 7:]).max() < 10.0     # nobody left the planet
+    assert (r1["status"] != 0).sum() > 0                                          # the sample does contain unsolvable ticks
     bt.close()
 
 
