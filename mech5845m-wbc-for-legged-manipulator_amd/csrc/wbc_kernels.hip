@@ -234,6 +234,11 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   res.iters = 0;
   res.x = 0.0;
   double g = g_in, lb = lb_in, ub = ub_in, clb = clb_in, cub = cub_in;
+  // a NaN bound would silently drop its constraint (every comparison with it is false): refuse the problem instead
+  if (__ballot((lane < n && (lb != lb || ub != ub)) || (lane < p && (clb != clb || cub != cub)))) {
+    res.status = WBC_QP_NUMERICAL;
+    return res;
+  }
 
   // ---- presolve: variables with lb == ub are fixed (the locked gripper / finger DoF, Robot_Wrapper4.py:627-630).
   // Their rows and columns leave H and C (H_kk = 1, g_k = -value reproduces x_k = value), the value's contribution
@@ -313,7 +318,7 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
 #pragma unroll 1
   for (int j = 0; j < NM; ++j) {
     const double pj = rdl(h[0], j);
-    pmin = fmin(pmin, pj);
+    pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;            // (a NaN pivot must fail the test below; fmin would drop it)
     const double rinv = rsqrt(pj);
     const double l = h[0] * rinv;
     if (lane < NM) S.cl[lane] = l;
@@ -627,6 +632,8 @@ done:
   STAMP(ts, T_INEQ);
   // a QP that was not solved returns x = 0 (the reference's xOpt on its first QP: qpOASES does not write the primal vector
   // of an unsolved problem, QP_Wrapper.py:50, 71-73) — and a roll-out holds still instead of integrating a partial iterate
+  if (res.status == WBC_QP_OPTIMAL && __ballot(lane < n && !(fabs(x) <= 1.7976931348623157e308)))
+    res.status = WBC_QP_NUMERICAL;                       // NaN / Inf reached the answer (non-finite inputs): never "optimal"
   res.x = (res.status == WBC_QP_OPTIMAL) ? x : 0.0;
   res.iters = iters;
   return res;

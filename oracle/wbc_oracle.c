@@ -581,7 +581,13 @@ static int qp_solve_body(int n, int p, const double* H, const double* g, const d
  * vector like the reference. */
 int orc_qp_solve(int n, int p, const double* H, const double* g, const double* C, const double* lb,
                  const double* ub, const double* Clb, const double* Cub, double* x, int* iters_out) {
-  const int st = qp_solve_body(n, p, H, g, C, lb, ub, Clb, Cub, x, iters_out);
+  int st = -1;
+  for (int i = 0; i < n; ++i) if ((lb && lb[i] != lb[i]) || (ub && ub[i] != ub[i])) st = WBC_QP_NUMERICAL;   /* NaN bound: refuse */
+  for (int i = 0; i < p; ++i) if (Clb[i] != Clb[i] || Cub[i] != Cub[i]) st = WBC_QP_NUMERICAL;
+  if (st < 0) st = qp_solve_body(n, p, H, g, C, lb, ub, Clb, Cub, x, iters_out);
+  else if (iters_out) *iters_out = 0;
+  if (st == WBC_QP_OPTIMAL)
+    for (int i = 0; i < n; ++i) if (!(fabs(x[i]) <= 1.7976931348623157e308)) st = WBC_QP_NUMERICAL;   /* NaN / Inf: never "optimal" */
   if (st != WBC_QP_OPTIMAL) for (int i = 0; i < n; ++i) x[i] = 0.0;
   return st;
 }

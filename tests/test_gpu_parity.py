@@ -600,3 +600,39 @@ def test_tick_can_be_captured_into_a_graph(wx200):
     torch.cuda.synchronize()
     assert not torch.equal(out["qdot"], ref["qdot"])
     bt.close()
+
+
+@pytest.mark.timeout(120)
+def test_non_finite_inputs_are_contained(wx200):
+    """NaN / Inf / absurd magnitudes in some instances' inputs: every wave still terminates (all solver loops are capped),
+    the poisoned instances come back flagged with q̇ = 0, and their neighbours are solved as if nothing had happened."""
+    B = 512
+    cfg = common.config("c3", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=33)
+    clean = {k: v.copy() for k, v in d.items()}
+    d["q"][5, 10] = np.nan
+    d["q"][17, 2] = np.inf
+    d["q"][40, 3:7] = 0.0                      # zero quaternion
+    d["ee_target"][63, 4, 1] = np.nan
+    d["ee_target"][64, 4, 0] = 1e200
+    d["trunk_box_center"][100, 0] = -np.inf
+    d["q"][200, 20] = 1e30                     # an angle no range reduction survives
+    poisoned = [5, 17, 40, 63, 64, 100, 200]
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    for sim3 in (1, 0):
+        bt.set_option("sim3_kernel", sim3)
+        bt.set_option("presolve", sim3)
+        ref = bt.tick(clean, DT, want_q_next=True)
+        got = bt.tick(d, DT, want_q_next=True)
+        keep = np.ones(B, dtype=bool)
+        keep[poisoned] = False
+        assert np.array_equal(got["qdot"][keep], ref["qdot"][keep]) and np.array_equal(got["status"][keep], ref["status"][keep])
+        for i in poisoned:
+            assert got["status"][i] != 0 or np.isfinite(got["qdot"][i]).all(), i
+            if got["status"][i] != 0:
+                assert (got["qdot"][i] == 0).all(), i
+        assert (got["status"][[5, 17, 63, 100]] != 0).all()      # NaN / Inf cannot produce an "optimal" answer
+        bt.set_option("sim3_kernel", 1)
+        bt.set_option("presolve", 1)
+    bt.close()
