@@ -405,7 +405,7 @@ static int validate_tick_in(const WbcBatch* b, const WbcTickIn* in, const char* 
 static int run_posture(WbcBatch* b, int B, const double* q, const int32_t* model_id, double* u, double* q_after, void* stream) {
   PostureArgs pa;
   memset(&pa, 0, sizeof pa);
-  pa.models = b->d_models; pa.cfgs = b->d_cfgs; pa.B = B; pa.q = q; pa.model_id = model_id; pa.u = u; pa.q_after = q_after;
+  pa.models = b->d_models; pa.cfgs = b->d_cfgs; pa.B = B; pa.n_models = b->n_models; pa.q = q; pa.model_id = model_id; pa.u = u; pa.q_after = q_after;
   if (int e = launch_posture(pa, B, stream)) return fail(WBC_E_HIP, "posture kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return WBC_OK;
 }
@@ -437,7 +437,7 @@ static int auto_posture(WbcBatch* b, KernelArgs& a, int B, void* stream) {
 
 static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
   memset(&a, 0, sizeof a);
-  a.models = b->d_models; a.cfgs = b->d_cfgs; a.plans = b->d_plans;
+  a.models = b->d_models; a.cfgs = b->d_cfgs; a.plans = b->d_plans; a.n_models = b->n_models;
   a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma; a.presolve = b->presolve; a.sing_tol = b->sing_tol; a.dbg_alias = b->dbg_alias; a.dt = dt;
   a.prof = b->d_prof;
   if (b->n_models > 0) { a.fk_nj = b->models[0]->blob.njoints; a.fk_nf = b->models[0]->blob.nframes; }
@@ -560,7 +560,7 @@ extern "C" int wbc_update_state(WbcBatch* b, int B, const double* q_cur, const d
   HIP_TRY(hipSetDevice(b->device_id));
   UpdateArgs a;
   memset(&a, 0, sizeof a);
-  a.models = b->d_models; a.cfgs = b->d_cfgs; a.B = B;
+  a.models = b->d_models; a.cfgs = b->d_cfgs; a.B = B; a.n_models = b->n_models;
   a.q_cur = q_cur; a.q_next = q_next; a.imu = imu; a.foot_targets = foot_targets; a.model_id = model_id; a.q_new = q_new;
   Stager st{b, mem, (hipStream_t)stream, {}};
   const size_t n = (size_t)B;
@@ -622,7 +622,7 @@ extern "C" int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, 
 
   UpdateArgs u;
   memset(&u, 0, sizeof u);
-  u.models = b->d_models; u.cfgs = b->d_cfgs; u.B = B;
+  u.models = b->d_models; u.cfgs = b->d_cfgs; u.B = B; u.n_models = b->n_models;
   u.q_cur = blk(O_Q); u.q_next = blk(O_QN); u.imu = ro.imu; u.foot_targets = blk(O_EET); u.model_id = a.in.model_id; u.q_new = blk(O_Q);
   u.ee_target = blk(O_EET); u.prev_ee_target = blk(O_EEP);
   u.trunk_target = first.trunk_target ? blk(O_TT) : nullptr; u.prev_trunk_target = first.prev_trunk_target ? blk(O_TP) : nullptr;
@@ -695,7 +695,7 @@ extern "C" int wbc_integrate(WbcBatch* b, int B, const double* q, const double* 
   HIP_TRY(hipSetDevice(b->device_id));
   IntegrateArgs a;
   memset(&a, 0, sizeof a);
-  a.models = b->d_models; a.B = B; a.dt = dt; a.q = q; a.v = v; a.model_id = model_id; a.q_next = q_next;
+  a.models = b->d_models; a.B = B; a.n_models = b->n_models; a.dt = dt; a.q = q; a.v = v; a.model_id = model_id; a.q_next = q_next;
   Stager st{b, mem, (hipStream_t)stream, {}};
   st.in(&a.q, (size_t)B * WBC_Q_STRIDE); st.in(&a.v, (size_t)B * WBC_V_STRIDE); st.in(&a.model_id, (size_t)B);
   st.out(&a.q_next, (size_t)B * WBC_Q_STRIDE);

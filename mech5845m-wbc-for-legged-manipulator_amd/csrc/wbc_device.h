@@ -60,6 +60,7 @@ struct KernelArgs {
   const WbcConfig* cfgs;
   const DevPlan* plans;
   int32_t B, mrows, prows, mcart;   // mcart = Cartesian task rows (excludes the diagonal posture block)
+  int32_t n_models, pad0_;          // model indices read from the caller's buffer are clamped to [0, n_models)
   int32_t post_static;              // every model's DevPlan.post_static (then no posture kernel runs)
   int32_t dbg_alias;                // diagnostic: every wave loads instance 0's inputs (isolates HBM input latency)
   int32_t pad1_;
@@ -84,7 +85,7 @@ struct QpArgs {
 
 struct IntegrateArgs {
   const DevModel* models;
-  int32_t B, pad0;
+  int32_t B, n_models;
   double dt;
   const double *q, *v;
   const int32_t* model_id;
@@ -94,7 +95,7 @@ struct IntegrateArgs {
 struct PostureArgs {
   const DevModel* models;
   const WbcConfig* cfgs;
-  int32_t B, pad0;
+  int32_t B, n_models;
   const double* q;
   const int32_t* model_id;
   double *u, *q_after;
@@ -105,7 +106,7 @@ struct PostureArgs {
 struct UpdateArgs {
   const DevModel* models;
   const WbcConfig* cfgs;
-  int32_t B, pad0;
+  int32_t B, n_models;
   const double *q_cur, *q_next, *imu, *foot_targets;
   const int32_t* model_id;
   double* q_new;

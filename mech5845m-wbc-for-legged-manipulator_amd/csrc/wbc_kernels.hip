@@ -111,6 +111,13 @@ __device__ __forceinline__ double2a lds2(const double* p) { return *reinterpret_
 __device__ __forceinline__ void sts2(double* p, double x, double y) { double2a v; v.x = x; v.y = y; *reinterpret_cast<double2a*>(p) = v; }
 
 __device__ __forceinline__ int li_clamp(int lane) { return lane < NV ? lane : NV - 1; }
+// model index of instance b: wave-uniform (say so, or every table access becomes a vector load) and CLAMPED to the handle's
+// models — a stray value in a caller's device buffer must not turn into an out-of-bounds table read
+__device__ __forceinline__ int model_index(const int32_t* model_id, const int b, const int n_models) {
+  if (!model_id) return 0;
+  const int m = __builtin_amdgcn_readfirstlane(model_id[b]);
+  return m < 0 ? 0 : (m >= n_models ? n_models - 1 : m);
+}
 
 __device__ __forceinline__ void cross3(const double* a, const double* b, double* c) {
   c[0] = a[1] * b[2] - a[2] * b[1];
@@ -1490,7 +1497,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
                     A.in.com_target || A.in.com_target_vel;
   const bool has3 = A.in.ee_ref_rot != nullptr;
   // the model index is wave-uniform: say so, or every M.* / cfg.* access becomes a vector load
-  const int mid = A.in.model_id ? __builtin_amdgcn_readfirstlane(A.in.model_id[b]) : 0;
+  const int mid = model_index(A.in.model_id, b, A.n_models);
   const InRegs cur = load_inputs(A.in, A.dbg_alias ? 0 : b, lane, has2, has3);   // dbg_alias: diagnostic, every wave reads instance 0
   const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);   // L1/L2-resident 3 KB table
   stage_inputs(S, cur, lane, has2, has3);
@@ -1933,7 +1940,7 @@ __global__ void __launch_bounds__(64, 3) wbc_tick_sim3_kernel(const KernelArgs A
   const int b = blockIdx.x;
   if (lane < 48) S.cl[lane] = 0.0;
   const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot;
-  const int mid = A.in.model_id ? __builtin_amdgcn_readfirstlane(A.in.model_id[b]) : 0;
+  const int mid = model_index(A.in.model_id, b, A.n_models);
   const InRegs cur = load_inputs(A.in, A.dbg_alias ? 0 : b, lane, has2, false);
   const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);
   stage_inputs(S, cur, lane, has2, false);
@@ -1961,7 +1968,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_deferred_kernel(const KernelAr
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     S.cl[lane] = 0.0;
-      const int mid = A.in.model_id ? __builtin_amdgcn_readfirstlane(A.in.model_id[b]) : 0;
+      const int mid = model_index(A.in.model_id, b, A.n_models);
     const InRegs cur = load_inputs(A.in, b, lane, has2, has3);
     const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);
     stage_inputs(S, cur, lane, has2, has3);
@@ -2064,7 +2071,7 @@ __global__ void __launch_bounds__(64) wbc_integrate_kernel(const IntegrateArgs A
   for (int b = blockIdx.x; b < A.B; b += gridDim.x) {
     int lane = threadIdx.x;
     asm volatile("" : "+v"(lane));
-    const DevModel& M = A.models[A.model_id ? __builtin_amdgcn_readfirstlane(A.model_id[b]) : 0];
+    const DevModel& M = A.models[model_index(A.model_id, b, A.n_models)];
     const int nv = M.nv, nq = M.nq;
     if (lane < 32) S.in[IN_Q + lane] = (lane < nq) ? A.q[(size_t)b * NQ + lane] : 0.0;
     const double v = (lane < nv) ? A.v[(size_t)b * NV + lane] * A.dt : 0.0;
@@ -2148,7 +2155,7 @@ __global__ void __launch_bounds__(64) wbc_posture_kernel(const PostureArgs A, co
   __shared__ PSmem P;
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
-  const int mid = A.model_id ? __builtin_amdgcn_readfirstlane(A.model_id[b]) : 0;
+  const int mid = model_index(A.model_id, b, A.n_models);
   const DevModel& M = models[mid];
   const WbcConfig& cfg = cfgs[mid];
   const LaneConst lc = load_lane_const(M, cfg, lane);
@@ -2210,7 +2217,7 @@ __global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, cons
   __shared__ USmem U;
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
-  const int mid = A.model_id ? __builtin_amdgcn_readfirstlane(A.model_id[b]) : 0;
+  const int mid = model_index(A.model_id, b, A.n_models);
   const DevModel& M = models[mid];
   const WbcConfig& cfg = cfgs[mid];
   // ---- every global read of the wave is issued here, before the FK (one memory round trip instead of a chain of them)

@@ -636,3 +636,27 @@ def test_non_finite_inputs_are_contained(wx200):
         bt.set_option("sim3_kernel", 1)
         bt.set_option("presolve", 1)
     bt.close()
+
+
+def test_stray_model_indices_are_clamped(wx200, px100):
+    """A model index outside the handle's models in the caller's buffer is clamped, not followed into an out-of-bounds
+    table read (device buffers cannot be validated on the host)."""
+    B = 64
+    models = [wx200, px100]
+    cfgs = [common.config("c3", m) for m in models]
+    d = common.tick_inputs(wx200, cfgs[0], B, seed=8)
+    mid = np.zeros(B, dtype=np.int32)
+    bad = mid.copy()
+    bad[3], bad[9] = -7, 1_000_000
+    want = mid.copy()
+    want[9] = 1
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    a = bt.tick(dict(d, model_id=bad), DT, want_q_next=True)
+    b_ = bt.tick(dict(d, model_id=want), DT, want_q_next=True)
+    for k in a:
+        assert np.array_equal(a[k], b_[k]), k
+    assert np.array_equal(bt.fk(d["q"], bad)["oMf"], bt.fk(d["q"], want)["oMf"])
+    assert np.array_equal(bt.integrate(d["q"], a["qdot"], DT, bad), bt.integrate(d["q"], a["qdot"], DT, want))
+    bt.close()
