@@ -42,6 +42,14 @@ def config(name, model):
     if name == "hybrid_grip_com":  # HYBRID + constraints that DO depend on the arm: the leaked perturbed state shows in C
         return wbc_model.make_config(model, Grip=True, Joint="HYBRID", cCoM=True, cTrunk=True, cFR=True, cFL=True, cRR=True,
                                      cRL=True, cGrip=True, mode="static_reach")
+    if name == "c3_nobounds":   # sim3 switch set without the velocity-damper box: the presolve adds no leg-bound rows
+        return wbc_model.make_config(model, Grip=True, Joint="PREV", cTrunk=True, cFR=True, cFL=True, cRR=True, cRL=True,
+                                     mode="static_reach", use_bounds=False)
+    if name == "c3_two_feet":   # only two stance feet: 26 - 6 = 20 unknowns > 16 -> general path, no presolve
+        return wbc_model.make_config(model, Grip=True, Joint="PREV", cTrunk=True, cFR=True, cRL=True, mode="static_reach")
+    if name == "c3_trunk_task":  # trunk task on top (base-only support: the plan stays enabled, two task blocks)
+        return wbc_model.make_config(model, Grip=True, Trunk=True, Joint="PREV", cTrunk=True, cFR=True, cFL=True, cRR=True,
+                                     cRL=True, mode="static_reach")
     if name == "c3_custom":
         return wbc_model.sim3_config(model, Joint="CUSTOM")
     raise KeyError(name)

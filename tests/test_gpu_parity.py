@@ -229,7 +229,7 @@ def test_tick_custom_posture_and_q_con(wx200):
     bt.close()
 
 
-@pytest.mark.parametrize("cfg_name", ["c3", "c2", "everything", "hybrid_grip_com"])
+@pytest.mark.parametrize("cfg_name", ["c3", "c2", "everything", "hybrid_grip_com", "c3_nobounds", "c3_two_feet", "c3_trunk_task"])
 def test_contact_presolve_and_general_path_agree(wx200, px100, cfg_name):
     """The structural elimination of the stance-foot equalities (default) and the general path (option presolve = 0)
     solve the same QP: both within tolerance of the oracle, same status, on both morphologies (n' = 14 and 13)."""
@@ -237,7 +237,11 @@ def test_contact_presolve_and_general_path_agree(wx200, px100, cfg_name):
     models = [wx200, px100]
     cfgs = [common.config(cfg_name, m) for m in models]
     mid = (np.arange(B) % 2).astype(np.int32)
-    parts = [common.tick_inputs(m, c, B, seed=51 + i, with_rot=(cfg_name == "everything")) for i, (m, c) in enumerate(zip(models, cfgs))]
+    parts = [common.tick_inputs(m, c, B, seed=51 + i, with_rot=(cfg_name in ("everything", "c3_trunk_task")))
+             for i, (m, c) in enumerate(zip(models, cfgs))]
+    if cfg_name == "c3_trunk_task":          # orientation references rule the sim3 kernel out; drop the EE ones, keep the trunk's
+        for prt in parts:
+            prt.pop("ee_ref_rot"), prt.pop("ee_prev_rot")
     d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
     d["model_id"] = mid
     ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
