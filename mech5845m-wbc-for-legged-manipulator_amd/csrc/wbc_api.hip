@@ -227,6 +227,8 @@ static void build_posture_plan(const DevModel& M, const WbcConfig& c, DevPlan* P
 static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan* P) {
   memset(P, 0, sizeof *P);
   build_posture_plan(M, c, P);
+  for (int e = 0; e < WBC_NEE; ++e) { if (c.task_ee[e]) P->task_ee_mask |= 1u << e; if (c.con_ee[e]) P->con_ee_mask |= 1u << e; }
+  P->flags = (c.con_com ? 1u : 0u) | (c.con_trunk ? 2u : 0u) | (c.task_trunk ? 4u : 0u) | (c.use_bounds ? 8u : 0u) | ((uint32_t)(c.task_joint & 7) << 4);
   for (int i = 0; i < 32; ++i) { P->pos[i] = -1; P->lidx[i] = -1; }
   uint32_t legmask = 0;
   int prow = (c.con_com ? 2 : 0) + (c.con_trunk ? 4 : 0), nelim = 0, l = 0;

@@ -45,6 +45,8 @@ struct DevPlan {
   int32_t post_fk2;                  // 1: an active constraint depends on a perturbed joint -> second FK pass needed
   uint32_t post_zero;                // DoF bits
   uint32_t post_pert;                // q-index bits (literal mode only; 0 when the configuration is restored)
+  uint32_t flags;                    // bit 0 con_com, 1 con_trunk, 2 task_trunk, 3 use_bounds, bits 4..6 task_joint
+  uint32_t task_ee_mask, con_ee_mask; // bit e: cfg.task_ee[e] / cfg.con_ee[e] (one scalar instead of five flag loads per loop)
   int32_t rowstart[4];               // first constraint row of eliminated foot f
   int32_t legd[12];                  // DoF index of eliminated leg DoF l (feet in constraint order, DoF ascending)
   int32_t Fd[WBC_PLAN_NR];           // DoF index of reduced variable k (0 beyond n_red)

@@ -1553,6 +1553,11 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
                                              const DevPlan& P, const LaneConst& lc, const InRegs& inr, const int b,
                                              const int lane) {
   const int nv = M.nv, nq = M.nq;
+  // the configuration's switches as ONE word from the plan (each cfg.* flag read where it is tested costs its own scalar load +
+  // full wait): bit 0 con_com, 1 con_trunk, 2 task_trunk, 3 use_bounds, bits 4..6 task_joint
+  const unsigned fl = P.flags;
+  const bool c_con_com = fl & 1u, c_con_trunk = fl & 2u, c_task_trunk = fl & 4u, c_use_bounds = fl & 8u;
+  const int c_task_joint = (fl >> 4) & 7u;
   const double dt = A.dt, inv_dt = 1.0 / A.dt;
   const double* const qv = S.in + IN_Q;
   unsigned long long ts[T_NN];
@@ -1563,7 +1568,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   STAMP(ts, T_START);
   // ---- P1..P3 (updateState, Robot_Wrapper4.py:400-405)
   FkOut fo;
-  fk_pass(S, S.RA, qv, M, lc, cfg.con_com != 0, lane, fo);
+  fk_pass(S, S.RA, qv, M, lc, c_con_com, lane, fo);
   double (&lin)[3] = fo.lin; double (&ang)[3] = fo.ang; double (&com)[3] = fo.com; double (&jc)[3] = fo.jc;
   double (&Rtr)[9] = fo.Rtr; double (&ptr)[3] = fo.ptr;
 
@@ -1602,36 +1607,42 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   }
   const bool stores = my_pos >= 0;
   const int arow = (stores ? my_pos : 0) * mtp;
+  // (the switches come as bit masks from the plan and each block's weights are fetched in one batch: read where they are
+  //  used, every cfg.* value is its own s_load + full wait inside the dependent chain)
 #pragma unroll 1
-  for (int e = 0; e < WBC_NEE; ++e) {
-    if (!cfg.task_ee[e]) continue;
-    const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_EE0 + e] >> lane) & 1u);
+  for (unsigned tm = P.task_ee_mask; tm; tm &= tm - 1) {
+    const int e = __ffs((int)tm) - 1;
+    const unsigned fsup = M.frame_support[WBC_FR_EE0 + e];
+    double w = cfg.ee_w[e], W0 = cfg.ee_W[e][0], W1 = cfg.ee_W[e][1], W2 = cfg.ee_W[e][2], W3 = cfg.ee_W[e][3],
+           W4 = cfg.ee_W[e][4], W5 = cfg.ee_W[e][5], G0 = cfg.ee_gain[e][0], G1 = cfg.ee_gain[e][1], G2 = cfg.ee_gain[e][2];
+    asm volatile("" : "+s"(w), "+s"(W0), "+s"(W1), "+s"(W2), "+s"(W3), "+s"(W4), "+s"(W5), "+s"(G0), "+s"(G1), "+s"(G2));
+    const double Wd[6] = {W0, W1, W2, W3, W4, W5}, Gd[3] = {G0, G1, G2};
+    const bool sup = (lane < nv) && ((fsup >> lane) & 1u);
     const double pfe[3] = {S.pf[3 * e], S.pf[3 * e + 1], S.pf[3 * e + 2]};
     double a[6];
     {  // endEffectorA2 (Robot_Wrapper4.py:474-484): LOCAL_WORLD_ALIGNED: lin + ang x p_f
       double wxp[3];
       cross3(ang, pfe, wxp);
-      const double w = cfg.ee_w[e];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        a[r] = sup ? cfg.ee_W[e][r] * ((lin[r] + wxp[r]) * w) : 0.0;
-        a[3 + r] = sup ? cfg.ee_W[e][3 + r] * (ang[r] * w) : 0.0;
+        a[r] = sup ? Wd[r] * ((lin[r] + wxp[r]) * w) : 0.0;
+        a[3 + r] = sup ? Wd[3 + r] * (ang[r] * w) : 0.0;
       }
     }
     const double* xt = S.in + IN_EET + 3 * e;
     const double* xp = S.in + IN_EEP + 3 * e;
     double vel[6] = {0, 0, 0, 0, 0, 0};   // calcTargetVelEE3 (:1052-1157) with R* == R*_prev (no orientation references here)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) * inv_dt + cfg.ee_gain[e][i] * ((xt[i] - pfe[i]) * inv_dt);
+    for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) * inv_dt + Gd[i] * ((xt[i] - pfe[i]) * inv_dt);
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const double br = vel[r] * cfg.ee_w[e];                  // EndEffectorB2 (:907-910)
+      const double br = vel[r] * w;                            // EndEffectorB2 (:907-910)
       g = fma(-a[r], br, g);
       if (stores) At[arow + row + r] = a[r];
     }
     row += 6;
   }
-  if (cfg.task_trunk) {   // trunkA (Robot_Wrapper4.py:487-490, WORLD), calcTargetVelTrunk2 (:948-1015)
+  if (c_task_trunk) {   // trunkA (Robot_Wrapper4.py:487-490, WORLD), calcTargetVelTrunk2 (:948-1015)
     const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_TRUNK] >> lane) & 1u);
     double a[6];
 #pragma unroll
@@ -1691,19 +1702,18 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   {
     int r0 = 0;
 #pragma unroll 1
-    for (int e = 0; e < WBC_NEE; ++e) {
-      if (!cfg.task_ee[e]) continue;
-      jtj_block_c<6>(S, At, mtp, r0, P.redsup[WBC_FR_EE0 + e], lane);
+    for (unsigned tm = P.task_ee_mask; tm; tm &= tm - 1) {
+      jtj_block_c<6>(S, At, mtp, r0, P.redsup[WBC_FR_EE0 + __ffs((int)tm) - 1], lane);
       r0 += 6;
     }
-    if (cfg.task_trunk) { jtj_block_c<6>(S, At, mtp, r0, P.redsup[WBC_FR_TRUNK], lane); r0 += 6; }
+    if (c_task_trunk) { jtj_block_c<6>(S, At, mtp, r0, P.redsup[WBC_FR_TRUNK], lane); r0 += 6; }
   }
   // posture rows: qpJointA (Robot_Wrapper4.py:1199-1206), qpJointb (:1209-1268); lane = DoF
   const double dpost = (1.0 / nv) * cfg.joint_w;
   {
     double upost = 0.0;
-    if (cfg.task_joint == WBC_JOINT_PREV && lane < nv) upost = qv[lane < 6 ? lane : lane + 1];
-    if (cfg.task_joint >= WBC_JOINT_MANI && lane < nv) {
+    if (c_task_joint == WBC_JOINT_PREV && lane < nv) upost = qv[lane < 6 ? lane : lane + 1];
+    if (c_task_joint >= WBC_JOINT_MANI && lane < nv) {
       if (A.post_static) upost = ((P.post_zero >> lane) & 1u) ? 0.0 : qv[lane < 6 ? lane : lane + 1];   // see DevPlan.post_static
       else upost = inr.pu;
     }
@@ -1717,19 +1727,19 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   if (A.in.q_con) {   // the configuration qpJointb MANI/HYBRID left behind: constraints, bounds, integrate see it
     if (lane < NQ) S.in[IN_Q + lane] = inr.qc;
     WSYNC();
-    fk_pass(S, S.RB, qv, M, lc, cfg.con_com != 0, lane, fo);
+    fk_pass(S, S.RB, qv, M, lc, c_con_com, lane, fo);
     WSYNC();
   } else if (A.post_static && P.post_pert) {   // same leak, structurally-zero gradients (see process_instance)
     if (lane < NQ && ((P.post_pert >> lane) & 1u)) S.in[IN_Q + lane] = (qv[lane] + 0.0002) - (0.0002 * 2);
     WSYNC();
-    if (P.post_fk2) { fk_pass(S, S.RB, qv, M, lc, cfg.con_com != 0, lane, fo); WSYNC(); }
+    if (P.post_fk2) { fk_pass(S, S.RB, qv, M, lc, c_con_com, lane, fo); WSYNC(); }
   }
 
   // ---- original constraint rows (findConstraints order, Robot_Wrapper4.py:764-836) into the scratch image Co = RB [p][26]
   double* const Co = S.RB;
   double clb = 0.0, cub = 0.0;
   int prow = 0;
-  if (cfg.con_com) {
+  if (c_con_com) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       if (lane < NV) Co[(prow + r) * LDJ + lane] = jc[r];
@@ -1739,7 +1749,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     }
     prow += 2;
   }
-  if (cfg.con_trunk) {
+  if (c_con_trunk) {
     const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_TRUNK] >> lane) & 1u);
     double wxp[3];
     cross3(ang, ptr, wxp);
@@ -1764,8 +1774,8 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     prow += 4;
   }
 #pragma unroll 1
-  for (int e = 0; e < WBC_NEE; ++e) {
-    if (!cfg.con_ee[e]) continue;
+  for (unsigned cm_ = P.con_ee_mask; cm_; cm_ &= cm_ - 1) {
+    const int e = __ffs((int)cm_) - 1;
     const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_EE0 + e] >> lane) & 1u);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -1778,7 +1788,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   // ---- velDamperJointConstraints (Robot_Wrapper4.py:572-637), lane = DoF
   double lb = 0.0, ub = 0.0;
   if (lane < nv) {
-    if (!cfg.use_bounds) { lb = -1e30; ub = 1e30; }
+    if (!c_use_bounds) { lb = -1e30; ub = 1e30; }
     else {
       const double qi = qv[lc.dq_idx], lo = lc.d_lo, hi = lc.d_hi, vm = lc.d_vm;
       if (qi <= lo + cfg.damper_qi) {
@@ -1859,7 +1869,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     if (lane == i2) { nclb = bl; ncub = bu; }
     ++i2;
   }
-  if (cfg.use_bounds) {
+  if (c_use_bounds) {
 #pragma unroll
     for (int l = 0; l < 12; ++l) {
       if (l < nl) { if (lane < CSC) Cm[(i2 + l) * CSC + lane] = gcol[l]; }
