@@ -817,8 +817,18 @@ __device__ __forceinline__ void stage_inputs(SM& S, const InRegs& r, const int l
 // ------------------------------------------------------------------------------------------------
 // forward kinematics + Jacobian columns of one configuration (updateState's pinocchio calls, Robot_Wrapper4.py:400-405)
 // ------------------------------------------------------------------------------------------------
+// The handful of model scalars the kinematics read, fetched ONCE per tick by the caller (the sim3 kernel pins them right
+// after the model index is known; read where they are used each costs a scalar load + full wait, twice per tick with the
+// second FK pass).
+struct Hdr { int nq, nv, nj, maxdepth, nframes, trunk_joint; };
+__device__ __forceinline__ Hdr load_hdr(const DevModel& M) {
+  Hdr h;
+  h.nq = M.nq; h.nv = M.nv; h.nj = M.njoints; h.maxdepth = M.maxdepth; h.nframes = M.nframes;
+  h.trunk_joint = M.frame_joint[WBC_FR_TRUNK];
+  return h;
+}
 // P1: pin.forwardKinematics. qv = the configuration (LDS), oMi = [joint][12] (R column-major, then p), lane j = joint j.
-__device__ __forceinline__ void fk_levels(double* const oMi, const double* const qv, const DevModel& M, const LaneConst& lc,
+__device__ __forceinline__ void fk_levels(double* const oMi, const double* const qv, const Hdr& H, const LaneConst& lc,
                                           const int lane) {
   // root free-flyer: R from the quaternion exactly as Eigen's toRotationMatrix, p = xyz
   if (lane == 1) {
@@ -836,7 +846,7 @@ __device__ __forceinline__ void fk_levels(double* const oMi, const double* const
   const double pris = lc.pris ? th : 0.0;
   WSYNC();
 #pragma unroll 1
-  for (int lvl = 2; lvl <= M.maxdepth; ++lvl) {
+  for (int lvl = 2; lvl <= H.maxdepth; ++lvl) {
     if (lc.depth == lvl) {
       const double* Pp = oMi + lc.par_off;
       double Av[3], Bv[3], Cv[3], P[3];
@@ -869,16 +879,16 @@ __device__ __forceinline__ void jac_column(const double* const oMi, const LaneCo
 struct FkOut { double lin[3], ang[3], com[3], jc[3], Rtr[9], ptr[3]; };
 // P1..P3 + frames + CoM. oMi and (oMi + OFF_MC) are scratch in LDS; frame origins go to S.pf.
 template <class SM>
-__device__ __forceinline__ void fk_pass(SM& S, double* const oMi, const double* const qv, const DevModel& M,
+__device__ __forceinline__ void fk_pass(SM& S, double* const oMi, const double* const qv, const Hdr& H,
                                         const LaneConst& lc, const bool need_com, const int lane, FkOut& o,
                                         unsigned long long* ts = nullptr) {
-  const int nv = M.nv, nj = M.njoints;
-  fk_levels(oMi, qv, M, lc, lane);
+  const int nv = H.nv, nj = H.nj;
+  fk_levels(oMi, qv, H, lc, lane);
 #ifdef WBC_PROFILE
   if (ts) STAMP(ts, T_F1);
 #endif
   // ---- P2: frame origins, pin.updateFramePlacements (Robot_Wrapper4.py:405); frames carry no rotation offset
-  if (lane < M.nframes) {
+  if (lane < H.nframes) {
     const double* Pj = oMi + lc.fj_off;
 #pragma unroll
     for (int r = 0; r < 3; ++r) S.pf[3 * lane + r] = Pj[9 + r] + Pj[r] * lc.f0 + Pj[3 + r] * lc.f1 + Pj[6 + r] * lc.f2;
@@ -917,7 +927,7 @@ __device__ __forceinline__ void fk_pass(SM& S, double* const oMi, const double* 
     }
   }
   // trunk frame (imu): rotation of its supporting joint, uniform read
-  const double* Pj = oMi + 12 * M.frame_joint[WBC_FR_TRUNK];
+  const double* Pj = oMi + 12 * H.trunk_joint;
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -1119,7 +1129,8 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
   // ---- P1..P3: forward kinematics, frames, Jacobian columns, CoM (updateState, Robot_Wrapper4.py:400-405, 670)
   const bool need_com = cfg.task_com || cfg.con_com || (MODE == MODE_FK && (A.fk.com || A.fk.Jcom));
   FkOut fo;
-  fk_pass(S, oMi, qv, M, lc, need_com, lane, fo, ts);
+  const Hdr H = load_hdr(M);
+  fk_pass(S, oMi, qv, H, lc, need_com, lane, fo, ts);
   double (&lin)[3] = fo.lin; double (&ang)[3] = fo.ang; double (&com)[3] = fo.com; double (&jc)[3] = fo.jc;
   double (&Rtr)[9] = fo.Rtr; double (&ptr)[3] = fo.ptr;
 
@@ -1331,14 +1342,14 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     // findConstraints, velDamperJointConstraints and integrate see THAT state. oMi scratch = RB (At is dead).
     if (lane < NQ) S.in[IN_Q + lane] = inr.qc;
     WSYNC();
-    fk_pass(S, S.RB, qv, M, lc, cfg.con_com != 0, lane, fo);
+    fk_pass(S, S.RB, qv, H, lc, cfg.con_com != 0, lane, fo);
     WSYNC();
   } else if (A.post_static && P.post_pert) {
     // the same state leak when every finite difference of qpJointb is structurally zero (DevPlan.post_static): each
     // perturbed entry is left at (q + d) - 2 d, and the kinematics are redone only if an active constraint depends on one
     if (lane < NQ && ((P.post_pert >> lane) & 1u)) S.in[IN_Q + lane] = (qv[lane] + 0.0002) - (0.0002 * 2);
     WSYNC();
-    if (P.post_fk2) { fk_pass(S, S.RB, qv, M, lc, cfg.con_com != 0, lane, fo); WSYNC(); }
+    if (P.post_fk2) { fk_pass(S, S.RB, qv, H, lc, cfg.con_com != 0, lane, fo); WSYNC(); }
   }
 
   // ---- P6: constraints in order CoM, Trunk, FR, FL, RR, RL, Grip: findConstraints (Robot_Wrapper4.py:764-836)
@@ -1550,9 +1561,9 @@ __device__ __forceinline__ void jtj_block_c(SmemC& S, const double* At, const in
 }
 
 __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
-                                             const DevPlan& P, const LaneConst& lc, const InRegs& inr, const int b,
-                                             const int lane) {
-  const int nv = M.nv, nq = M.nq;
+                                             const DevPlan& P, const Hdr& H, const LaneConst& lc, const InRegs& inr,
+                                             const int b, const int lane) {
+  const int nv = H.nv, nq = H.nq;
   // the configuration's switches as ONE word from the plan (each cfg.* flag read where it is tested costs its own scalar load +
   // full wait): bit 0 con_com, 1 con_trunk, 2 task_trunk, 3 use_bounds, bits 4..6 task_joint
   const unsigned fl = P.flags;
@@ -1568,7 +1579,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   STAMP(ts, T_START);
   // ---- P1..P3 (updateState, Robot_Wrapper4.py:400-405)
   FkOut fo;
-  fk_pass(S, S.RA, qv, M, lc, c_con_com, lane, fo);
+  fk_pass(S, S.RA, qv, H, lc, c_con_com, lane, fo);
   double (&lin)[3] = fo.lin; double (&ang)[3] = fo.ang; double (&com)[3] = fo.com; double (&jc)[3] = fo.jc;
   double (&Rtr)[9] = fo.Rtr; double (&ptr)[3] = fo.ptr;
 
@@ -1727,12 +1738,12 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   if (A.in.q_con) {   // the configuration qpJointb MANI/HYBRID left behind: constraints, bounds, integrate see it
     if (lane < NQ) S.in[IN_Q + lane] = inr.qc;
     WSYNC();
-    fk_pass(S, S.RB, qv, M, lc, c_con_com, lane, fo);
+    fk_pass(S, S.RB, qv, H, lc, c_con_com, lane, fo);
     WSYNC();
   } else if (A.post_static && P.post_pert) {   // same leak, structurally-zero gradients (see process_instance)
     if (lane < NQ && ((P.post_pert >> lane) & 1u)) S.in[IN_Q + lane] = (qv[lane] + 0.0002) - (0.0002 * 2);
     WSYNC();
-    if (P.post_fk2) { fk_pass(S, S.RB, qv, M, lc, c_con_com, lane, fo); WSYNC(); }
+    if (P.post_fk2) { fk_pass(S, S.RB, qv, H, lc, c_con_com, lane, fo); WSYNC(); }
   }
 
   // ---- original constraint rows (findConstraints order, Robot_Wrapper4.py:764-836) into the scratch image Co = RB [p][26]
@@ -1953,9 +1964,11 @@ __global__ void __launch_bounds__(64, 3) wbc_tick_sim3_kernel(const KernelArgs A
   const int mid = model_index(A.in.model_id, b, A.n_models);
   const InRegs cur = load_inputs(A.in, A.dbg_alias ? 0 : b, lane, has2, false);
   const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);
+  Hdr H = load_hdr(models[mid]);                 // one batch of scalar loads, waited for once
+  asm volatile("" : "+s"(H.nq), "+s"(H.nv), "+s"(H.nj), "+s"(H.maxdepth), "+s"(H.nframes), "+s"(H.trunk_joint));
   stage_inputs(S, cur, lane, has2, false);
   WSYNC();
-  process_sim3(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane);
+  process_sim3(S, A, models[mid], cfgs[mid], plans[mid], H, lc, cur, b, lane);
 }
 
 // Second pass after wbc_tick_sim3_kernel: the instances it deferred (rare: a singular stance-leg block) are redone on the
@@ -2134,7 +2147,7 @@ __device__ __forceinline__ double det6_spd(const double* G) {
 __device__ __forceinline__ double manipulability(PSmem& P, const DevModel& M, const LaneConst& lc, const int joint_id,
                                                  const int lane) {
   const int nv = M.nv;
-  fk_levels(P.oMi, P.q, M, lc, lane);
+  fk_levels(P.oMi, P.q, load_hdr(M), lc, lane);
   double lin[3], ang[3];
   jac_column(P.oMi, lc, lane, nv, lin, ang);
   const double* Pj = P.oMi + 12 * joint_id;
@@ -2253,7 +2266,7 @@ __global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, cons
   if (lane < 32) U.q[lane] = c;
   if (lane < 12) U.ft[lane] = ft;
   WSYNC();
-  fk_levels(U.oMi, U.q, M, lc, lane);
+  fk_levels(U.oMi, U.q, load_hdr(M), lc, lane);
   if (lane < M.nframes) {
     const double* Pj = U.oMi + lc.fj_off;
 #pragma unroll
