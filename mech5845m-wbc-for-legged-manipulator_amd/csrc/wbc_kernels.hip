@@ -1174,20 +1174,26 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     for (int k = 0; k < NV; k += 2) sts2(S.RA + lane * LDJ + k, 0.0, 0.0);
   }
   // pass 1: every lane writes its column of every Cartesian block to At and accumulates g
+  // (the switches come as bit masks from the plan and each block's weights are fetched in one batch: read where they are
+  //  used, every cfg.* value is its own s_load + full wait inside the dependent chain)
 #pragma unroll 1
-  for (int e = 0; e < WBC_NEE; ++e) {
-    if (!cfg.task_ee[e]) continue;
-    const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_EE0 + e] >> lane) & 1u);
+  for (unsigned tm = P.task_ee_mask; tm; tm &= tm - 1) {
+    const int e = __ffs((int)tm) - 1;
+    const unsigned fsup = M.frame_support[WBC_FR_EE0 + e];
+    double w = cfg.ee_w[e], W0 = cfg.ee_W[e][0], W1 = cfg.ee_W[e][1], W2 = cfg.ee_W[e][2], W3 = cfg.ee_W[e][3],
+           W4 = cfg.ee_W[e][4], W5 = cfg.ee_W[e][5], G0 = cfg.ee_gain[e][0], G1 = cfg.ee_gain[e][1], G2 = cfg.ee_gain[e][2];
+    asm volatile("" : "+s"(w), "+s"(W0), "+s"(W1), "+s"(W2), "+s"(W3), "+s"(W4), "+s"(W5), "+s"(G0), "+s"(G1), "+s"(G2));
+    const double Wd[6] = {W0, W1, W2, W3, W4, W5}, Gd[3] = {G0, G1, G2};
+    const bool sup = (lane < nv) && ((fsup >> lane) & 1u);
     const double pfe[3] = {S.pf[3 * e], S.pf[3 * e + 1], S.pf[3 * e + 2]};
     double a[6];
     {  // endEffectorA2 (Robot_Wrapper4.py:474-484): LOCAL_WORLD_ALIGNED: lin + ang x p_f
       double wxp[3];
       cross3(ang, pfe, wxp);
-      const double w = cfg.ee_w[e];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        a[r] = sup ? cfg.ee_W[e][r] * ((lin[r] + wxp[r]) * w) : 0.0;
-        a[3 + r] = sup ? cfg.ee_W[e][3 + r] * (ang[r] * w) : 0.0;
+        a[r] = sup ? Wd[r] * ((lin[r] + wxp[r]) * w) : 0.0;
+        a[3 + r] = sup ? Wd[3 + r] * (ang[r] * w) : 0.0;
       }
     }
     // calcTargetVelEE3 (Robot_Wrapper4.py:1052-1157) — uniform arithmetic on the staged inputs
@@ -1195,7 +1201,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     const double* xp = S.in + IN_EEP + 3 * e;
     double vel[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) * inv_dt + cfg.ee_gain[e][i] * ((xt[i] - pfe[i]) * inv_dt);
+    for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) * inv_dt + Gd[i] * ((xt[i] - pfe[i]) * inv_dt);
     if (A.in.ee_ref_rot) {   // omega = vee(((R* - R*_prev)/dt) R*^T)  (:1125-1128, 1133)
       const double* Rs = S.in + IN_ERR + 9 * e;
       const double* Rp = S.in + IN_EPR + 9 * e;
@@ -1208,7 +1214,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const double br = vel[r] * cfg.ee_w[e];                  // EndEffectorB2 (:907-910)
+      const double br = vel[r] * w;                            // EndEffectorB2 (:907-910)
       g = fma(-a[r], br, g);
       if (lane == 0) S.bt[row + r] = br;
       if (lane < NV) At[lane * mtp + row + r] = a[r];
@@ -1292,9 +1298,8 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     // vector units, block by block over each block's DoF support (skips the structural zeros of the Jacobians)
     int r0 = 0;
 #pragma unroll 1
-    for (int e = 0; e < WBC_NEE; ++e) {
-      if (!cfg.task_ee[e]) continue;
-      jtj_block<6>(S, At, mtp, r0, M.frame_support[WBC_FR_EE0 + e], lane);
+    for (unsigned tm = P.task_ee_mask; tm; tm &= tm - 1) {
+      jtj_block<6>(S, At, mtp, r0, M.frame_support[WBC_FR_EE0 + __ffs((int)tm) - 1], lane);
       r0 += 6;
     }
     if (cfg.task_trunk) { jtj_block<6>(S, At, mtp, r0, M.frame_support[WBC_FR_TRUNK], lane); r0 += 6; }
@@ -1393,8 +1398,8 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     prow += 4;
   }
 #pragma unroll 1
-  for (int e = 0; e < WBC_NEE; ++e) {   // EEConstraint (Robot_Wrapper4.py:757-761): WORLD rows 0..2, 0 <= . <= 0
-    if (!cfg.con_ee[e]) continue;
+  for (unsigned cm_ = P.con_ee_mask; cm_; cm_ &= cm_ - 1) {   // EEConstraint (Robot_Wrapper4.py:757-761): WORLD rows 0..2, 0 <= . <= 0
+    const int e = __ffs((int)cm_) - 1;
     const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_EE0 + e] >> lane) & 1u);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
