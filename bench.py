@@ -35,11 +35,11 @@ ALGO_FLOP_PER_TICK = 5.5e4     # + ~1e4 per working-set change
 
 
 def pmc_traffic_bytes():
-    """HBM bytes per bench step from the committed rocprofv3 PMC passes of this same command (profiles/r01_pmc_summary_v11.txt:
+    """HBM bytes per bench step from the committed rocprofv3 PMC passes of this same command (profiles/r01_pmc_summary_v12.txt:
     FETCH_SIZE and WRITE_SIZE in KiB, separate --pmc runs, tools/gpu_profile.sh), summed over the kernels one step launches
     (the sim3 tick kernel + the deferred pass). 8-byte-per-lane accesses: the gfx950 x2
     FETCH_SIZE correction for 16-byte streams does not apply (uncalibrated width)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_v11.txt")
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_v12.txt")
     try:
         total = 0.0
         for line in open(path):
@@ -55,7 +55,7 @@ def pmc_traffic_bytes():
 def pmc_issue_busy():
     """VALU / LDS busy fractions of the sim3 tick kernel from the same committed PMC passes: SQ_ACTIVE_INST_VALU and
     SQ_LDS_IDX_ACTIVE per CU-cycle (GRBM_GUI_ACTIVE counts the 8 XCDs' cycles; 256 CUs)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_v11.txt")
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_v12.txt")
     try:
         v = {}
         for line in open(path):
@@ -70,7 +70,7 @@ def pmc_issue_busy():
                 "salu_insts_per_tick": v["SQ_INSTS_SALU"] / v["SQ_WAVES"],
                 "lds_bank_conflict_rate": v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"],
                 "lds_bytes_per_instance": 13056, "vgprs": 168, "waves_per_simd": 3,      # tools/kernel_stats.sh (wbc_tick_sim3_kernel)
-                "source": "profiles/r01_pmc_summary_v11.txt"}
+                "source": "profiles/r01_pmc_summary_v12.txt"}
     except Exception:
         return None
 
