@@ -8,11 +8,18 @@ switch set (Grip task + posture; 12 contact equalities, 4 trunk-box rows, 26 vel
 With --gpus N (launched under torch.distributed.run) every rank runs its own 65536-instance shard on its own GPU —
 no data-path collective — and the job value is the sum: scaling "weak".
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R] [--batch B] [--no-cpu-baseline]
 
-Extra objects on the line: "roofline" (algorithmic HBM bytes/tick x ticks / kernel time from HIP events on the launch
-stream, against 8 TB/s) and "cpu_baseline" (the CPU oracle, oracle/wbc_oracle.c, timed on this host's cores on a bounded
-sample of the same inputs — the oracle is only the yardstick/checker here, never the thing measured).
+Timing: after W warm-up steps, R blocks of EXACTLY K steps, each block bracketed by barrier + device synchronise on both
+sides and reduced with MAX over the ranks; `value` / `ms_per_step` come from the MEDIAN block, every block is listed under
+"repeats". Extra objects on the line: "roofline" (algorithmic HBM bytes/tick x ticks / kernel time from HIP events on the
+launch stream against 8 TB/s — reported because the contract asks for it; what bounds this kernel is issue/latency, see
+"issue") and "cpu_baseline" (the CPU oracle, oracle/wbc_oracle.c, timed on this host's cores on a bounded sample of the
+same inputs — the oracle is only the yardstick/checker here, never the thing measured). The run FAILS (exit code 1, line
+still printed) if the q̇ error against the oracle exceeds the tolerance or any solver status differs.
+
+The per-rank body is `run_rank(args, comm, engine)`: `comm` wraps torch.distributed (RCCL on the GPUs; tests/ drive the same
+function over gloo on CPU ranks with an engine whose tick is the oracle), `engine` is the thing that ticks.
 """
 import argparse
 import json
@@ -31,55 +38,271 @@ ALGO_BYTES_PER_TICK = 572
 ACTUAL_BYTES_PER_TICK = 216 + 120 + 120 + 32 + 208 + 4 + 4
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak
-ALGO_FLOP_PER_TICK = 5.5e4     # + ~1e4 per working-set change beyond the equalities
+ALGO_FLOP_PER_TICK = 5.5e4     # dense count of the n = 26 problem (+ ~1e4 per working-set change)
+REDUCED_FLOP_PER_TICK = 1.4e4  # the problem the sim3 kernel actually solves (n' = 14, no equalities): DESIGN.md §4
+PMC_PROFILE = "r01_pmc_summary_v12.txt"   # committed rocprofv3 PMC passes the static roofline.traffic / roofline.issue fields come from
+DT = 0.002
+QDOT_TOL = 1e-5
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per bench step from the committed rocprofv3 PMC passes of this same command (profiles/r01_pmc_summary_v12.txt:
-    FETCH_SIZE and WRITE_SIZE in KiB, separate --pmc runs, tools/gpu_profile.sh), summed over the kernels one step launches
-    (the sim3 tick kernel + the deferred pass). 8-byte-per-lane accesses: the gfx950 x2
-    FETCH_SIZE correction for 16-byte streams does not apply (uncalibrated width)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_v12.txt")
+def _pmc_lines(kernels):
+    path = os.path.join(ROOT, "profiles", os.environ.get("WBC_PMC_PROFILE", PMC_PROFILE))
+    out = {}
     try:
-        total = 0.0
         for line in open(path):
-            if "wbc_tick_sim3_kernel" in line or "wbc_tick_deferred_kernel" in line:
-                for key in ("FETCH_SIZE", "WRITE_SIZE"):
-                    if " %s " % key in line:
-                        total += float(line.split("per_dispatch=")[1])
-        return total * 1024.0 if total else None
+            for kn in kernels:
+                if kn in line:
+                    parts = line.split()
+                    for i, tok in enumerate(parts):
+                        if tok.startswith("per_dispatch="):
+                            out.setdefault(kn, {})[parts[i - 3]] = float(tok.split("=")[1])
     except Exception:
-        return None
+        return {}, path
+    return out, path
 
 
-def pmc_issue_busy():
-    """VALU / LDS busy fractions of the sim3 tick kernel from the same committed PMC passes: SQ_ACTIVE_INST_VALU and
-    SQ_LDS_IDX_ACTIVE per CU-cycle (GRBM_GUI_ACTIVE counts the 8 XCDs' cycles; 256 CUs)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary_v12.txt")
-    try:
-        v = {}
-        for line in open(path):
-            if "wbc_tick_sim3_kernel" in line:
-                for key in ("SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVES",
-                            "SQ_LDS_BANK_CONFLICT"):
-                    if " %s " % key in line:
-                        v[key] = float(line.split("per_dispatch=")[1])
-        cu_cycles = 256.0 * v["GRBM_GUI_ACTIVE"] / 8.0
-        return {"valu_busy": v["SQ_ACTIVE_INST_VALU"] / cu_cycles, "lds_busy": v["SQ_LDS_IDX_ACTIVE"] / cu_cycles,
-                "valu_insts_per_tick": v["SQ_INSTS_VALU"] / v["SQ_WAVES"], "lds_insts_per_tick": v["SQ_INSTS_LDS"] / v["SQ_WAVES"],
-                "salu_insts_per_tick": v["SQ_INSTS_SALU"] / v["SQ_WAVES"],
-                "lds_bank_conflict_rate": v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"],
-                "lds_bytes_per_instance": 13056, "vgprs": 168, "waves_per_simd": 3,      # tools/kernel_stats.sh (wbc_tick_sim3_kernel)
-                "source": "profiles/r01_pmc_summary_v12.txt"}
-    except Exception:
-        return None
+def pmc_static():
+    """roofline.traffic and roofline.issue from the COMMITTED rocprofv3 PMC passes of this same command (separate --pmc runs,
+    tools/gpu_profile.sh): constants of that profile, not measurements of this run — marked "static_from_profile"."""
+    v, path = _pmc_lines(("wbc_tick_sim3_kernel", "wbc_tick_deferred_kernel"))
+    s = v.get("wbc_tick_sim3_kernel")
+    if not s:
+        return None, None
+    traffic = 0.0
+    for kn in v:
+        traffic += v[kn].get("FETCH_SIZE", 0.0) + v[kn].get("WRITE_SIZE", 0.0)       # KiB per dispatch; 8-byte-per-lane accesses:
+    try:                                                                             # the gfx950 x2 correction for 16-byte streams does not apply
+        cu_cycles = 256.0 * s["GRBM_GUI_ACTIVE"] / 8.0
+        issue = {"valu_busy": s["SQ_ACTIVE_INST_VALU"] / cu_cycles, "lds_busy": s["SQ_LDS_IDX_ACTIVE"] / cu_cycles,
+                 "valu_insts_per_tick": s["SQ_INSTS_VALU"] / s["SQ_WAVES"], "lds_insts_per_tick": s["SQ_INSTS_LDS"] / s["SQ_WAVES"],
+                 "salu_insts_per_tick": s["SQ_INSTS_SALU"] / s["SQ_WAVES"],
+                 "lds_bank_conflict_rate": s["SQ_LDS_BANK_CONFLICT"] / s["SQ_LDS_IDX_ACTIVE"],
+                 "static_from_profile": os.path.relpath(path, ROOT)}
+    except KeyError:
+        issue = None
+    return (traffic * 1024.0 if traffic else None), issue
 
 
-def main():
+# ------------------------------------------------------------------------------------------------ communication
+class Comm:
+    """torch.distributed as the benchmark uses it: a barrier and a MAX all-reduce — nothing on the data path."""
+
+    def __init__(self, backend, rank, world, device=None):
+        self.rank, self.world, self.device = rank, world, device
+        self.dist = None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if not dist.is_initialized():
+                kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+                dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max(self, values):
+        """element-wise max over the ranks of a list of floats"""
+        if self.dist is None:
+            return [float(v) for v in values]
+        import torch
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.cpu()]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ the GPU engine
+class GpuEngine:
+    """wbc_tick on one MI355X through the C-ABI (WbcBatch); inputs generated with the product's own FK, resident in HBM."""
+    name = "hip"
+
+    def __init__(self, args, local):
+        import torch
+        import wbc_model
+        from wbc_batch import WbcBatch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+        torch.cuda.set_device(local)
+        self.torch, self.dev, self.args = torch, torch.device("cuda", local), args
+        self.model = wbc_model.load_model("a1_wx200")
+        self.cfg = wbc_model.sim3_config(self.model, Joint=args.posture)
+        self.bt = WbcBatch(self.model, args.batch, device_id=local)
+        self.bt.configure(self.cfg)
+        self.options = {"jtj_mfma": int(bool(args.jtj_mfma)), "presolve": 1, "sim3_kernel": 1, "dbg_alias_inputs": 0}
+        for env, opt in (("WBC_PRESOLVE", "presolve"), ("WBC_SIM3_KERNEL", "sim3_kernel"), ("WBC_DBG_ALIAS", "dbg_alias_inputs")):
+            if os.environ.get(env) not in (None, ""):       # diagnostic A/B switches: they change WHAT is measured, so they are reported
+                self.options[opt] = int(os.environ[env])
+        for k, v in self.options.items():
+            self.bt.set_option(k, v)
+
+    def fk(self, q):
+        return self.bt.fk(q, want=("oMf",))["oMf"]
+
+    def load(self, host_in):
+        t = self.torch
+        B = host_in["q"].shape[0]
+        self.dev_in = {k: t.from_numpy(np.ascontiguousarray(v)).to(self.dev) for k, v in host_in.items()}
+        self.dev_out = dict(qdot=t.zeros((B, 26), dtype=t.float64, device=self.dev), status=t.zeros(B, dtype=t.int32, device=self.dev),
+                            iters=t.zeros(B, dtype=t.int32, device=self.dev))
+        self.step = self.bt.make_tick_call(self.dev_in, self.dev_out, DT)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def timed_block(self, steps):
+        """-> kernel milliseconds of the block from HIP events on the launch stream (the C-ABI launches on torch's current one)"""
+        ev0, ev1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(steps):
+            self.step()
+        ev1.record()
+        return lambda: ev0.elapsed_time(ev1)
+
+    def results(self):
+        return {k: v.cpu().numpy() for k, v in self.dev_out.items()}
+
+    def path(self):
+        return "wbc_tick_sim3_kernel (+ wbc_tick_deferred_kernel)" if self.bt.stat("last_path") == 1 else "wbc_tick_kernel<MODE_TICK>"
+
+    def closed_loop(self, host_in, ticks):
+        t = self.torch
+        B = host_in["q"].shape[0]
+        dev_in = {k: t.from_numpy(np.ascontiguousarray(v)).to(self.dev) for k, v in host_in.items()}
+        step_t = t.zeros((B, 5, 3), dtype=t.float64, device=self.dev)
+        step_t[:, 4, 0] = 1e-4
+        self.bt.rollout(dev_in, DT, 2, ee_target_step=step_t, want_trace=False)
+        self.sync()
+        t1 = time.perf_counter()
+        ro = self.bt.rollout(dev_in, DT, ticks, ee_target_step=step_t, want_trace=False)
+        self.sync()
+        t_roll = time.perf_counter() - t1
+        st = ro["status"].cpu().numpy()
+        return {"value": float(B) * ticks / t_roll, "ms_per_tick": 1e3 * t_roll / ticks,
+                "worst_status_histogram": {name: int((st == code).sum()) for code, name in enumerate(("optimal", "max_iter", "infeasible", "numerical"))},
+                "optimal_frac": float((st == 0).mean()), "iters_per_tick": float(ro["iters"].double().mean().item()) / ticks}
+
+    def close(self):
+        self.bt.close()
+
+
+# ------------------------------------------------------------------------------------------------ the per-rank body
+def run_rank(args, comm, engine, make_inputs):
+    """What every rank does: seed-by-rank inputs -> warm-up -> R bracketed blocks of K steps -> MAX over ranks ->
+    rank 0 assembles the JSON line. Returns (line or None, results dict)."""
+    rank, world = comm.rank, comm.world
+    B, K, R = args.batch, args.steps, max(1, args.repeats)
+    host_in = make_inputs(engine, B, seed=rank, stress=True)
+    engine.host_in = host_in
+    engine.load(host_in)
+
+    def barrier():
+        engine.sync()
+        comm.barrier()
+        engine.sync()
+
+    for _ in range(args.warmup):
+        engine.step()
+    elapsed, kernel_ms = [], []
+    for _ in range(R):
+        barrier()
+        t0 = time.perf_counter()
+        km = engine.timed_block(K)
+        barrier()
+        elapsed.append(time.perf_counter() - t0)
+        kernel_ms.append(km() / K)
+    elapsed = comm.max(elapsed)                     # the job is as slow as its slowest rank, block by block
+    res = engine.results()
+    if rank != 0:
+        return None, res
+    order = np.argsort(elapsed)
+    med = int(order[len(order) // 2])
+    t_med, k_med = elapsed[med], kernel_ms[med]
+    ticks = float(B) * world * K
+    ach = ALGO_BYTES_PER_TICK * B / (k_med * 1e-3) / 1e9
+    traffic, issue = pmc_static()
+    status, iters = res["status"], res["iters"]
+    line = {
+        "metric": "wbc_qp_solves_per_sec", "value": ticks / t_med, "unit": "ticks/s", "n_gpus": world,
+        "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * t_med / K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2] / SURVEY C3: A1+wx200 (nq 27, nv 26), sim3 switch set: Grip task + " + args.posture + " posture, "
+                               "12 contact equalities + 4 trunk-box rows + 26 damper bounds (3 locked), m=32 p=16 n=26",
+                   "batch_per_gpu": B, "global_batch": B * world, "dt": DT, "parallelism": "shard%d (no collective)" % world,
+                   "engine": engine.name, "kernel_path": engine.path(), "options": getattr(engine, "options", {}),
+                   "jtj": "mfma_f64" if getattr(engine, "options", {}).get("jtj_mfma") else "valu_f64"},
+        "repeats": {"n": R, "ms_per_step": [1e3 * e / K for e in elapsed], "kernel_ms_per_step": kernel_ms,
+                    "spread": (max(elapsed) - min(elapsed)) / t_med, "reported": "median block"},
+        "roofline": {"bound": "valu_lds_issue_latency", "contract_bound": "hbm",
+                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC, batch 65536)", "traffic_static_from_profile": "profiles/" + PMC_PROFILE,
+                     "kernel": engine.path(), "kernel_ms": k_med,
+                     "algorithmic_bytes_per_tick": ALGO_BYTES_PER_TICK, "streamed_bytes_per_tick": ACTUAL_BYTES_PER_TICK,
+                     "issue_frac": None if not issue else max(issue["valu_busy"], issue["lds_busy"]),
+                     "fp64_tflops_nominal_n26": ALGO_FLOP_PER_TICK * B / (k_med * 1e-3) / 1e12,
+                     "fp64_frac_nominal_n26": ALGO_FLOP_PER_TICK * B / (k_med * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                     "fp64_frac_solved_problem": REDUCED_FLOP_PER_TICK * B / (k_med * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                     "issue": issue,
+                     "note": "tiny-dense LDS-resident fp64 work: bound by VALU/LDS issue and dependent-chain latency at 3 waves/SIMD; neither HBM "
+                             "nor MFMA is approachable (SURVEY.md §8d). achieved/peak/frac are the HBM figures the contract asks for; "
+                             "issue_frac = max(VALU busy, LDS busy) of the committed PMC profile"},
+        "solver": {"optimal_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
+                   "iters_p95": float(np.percentile(iters, 95)), "iters_max": int(iters.max())},
+    }
+    return line, res
+
+
+def make_inputs(engine, B, seed, stress):
+    import wbc_workload
+
+    class FK:   # inputs are placed on the robot with the engine's own FK
+        def __call__(self, q):
+            return engine.fk(q)
+    return wbc_workload.make_tick_inputs(engine.model, engine.cfg, B, seed=seed, fk=FK(), stress=stress)
+
+
+def cpu_baseline_and_accuracy(line, engine, host_in, res, args):
+    """rank 0, N = 1 only: the oracle on this host's cores on a bounded sample (~10-20 s), and the accuracy gate."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle   # checker / yardstick only
+    model, cfg, B = engine.model, engine.cfg, host_in["q"].shape[0]
+    cores = len(os.sched_getaffinity(0))
+    n = args.cpu_sample or min(B, 16384)
+    sub = {k: v[:n] for k, v in host_in.items()}
+    oracle.tick([model], [cfg], {k: v[:256] for k, v in host_in.items()}, DT, min(256, B), nthreads=cores, want_q_next=False)
+    reps, t_cpu, ref = 0, 0.0, None
+    while t_cpu < 10.0 and reps < 64:
+        t1 = time.perf_counter()
+        ref = oracle.tick([model], [cfg], sub, DT, n, nthreads=cores, want_q_next=False)
+        t_cpu += time.perf_counter() - t1
+        reps += 1
+    n1 = min(2048, B)
+    t1 = time.perf_counter()
+    oracle.tick([model], [cfg], {k: v[:n1] for k, v in host_in.items()}, DT, n1, nthreads=1, want_q_next=False)
+    one = n1 / (time.perf_counter() - t1)
+    ok = (ref["status"] == 0) & (res["status"][:n] == 0)
+    line["cpu_baseline"] = {"value": n * reps / t_cpu, "unit": "ticks/s", "cores": cores, "kind": "port",
+                            "sample": "first %d instances of rank 0's batch x %d repeats (%.1f s), OpenMP over %d threads; "
+                                      "single-thread rate %.0f ticks/s; reference design rate 500 ticks/s (paced, not measured)" % (n, reps, t_cpu, cores, one),
+                            "single_thread": one}
+    err = float(np.abs(ref["qdot"] - res["qdot"][:n])[ok].max()) if ok.any() else float("nan")
+    agree = float((ref["status"] == res["status"][:n]).mean())
+    line["accuracy"] = {"qdot_max_abs_err_vs_cpu": err, "status_agree_frac": agree, "tolerance": QDOT_TOL, "instances": int(n),
+                        "pass": bool(err < QDOT_TOL and agree == 1.0)}
+    return line["accuracy"]["pass"]
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median block is reported")
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances for the CPU baseline (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,145 +310,34 @@ def main():
     ap.add_argument("--rollout-ticks", type=int, default=10, help="closed-loop ticks of the extra wbc_rollout measurement (0 = skip)")
     ap.add_argument("--posture", default="PREV", choices=["PREV", "HYBRID", "MANI"],
                     help="posture mode of the tick (default PREV = the BASELINE workload; HYBRID is what sim3.py:145 sets)")
-    args = ap.parse_args()
-
-    import torch
-    import wbc_model
-    import wbc_workload
-    from wbc_batch import WbcBatch
+    args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    B, DT = args.batch, 0.002
-    model = wbc_model.load_model("a1_wx200")
-    cfg = wbc_model.sim3_config(model, Joint=args.posture)
-    bt = WbcBatch(model, B, device_id=local)
-    bt.configure(cfg)
-    if args.jtj_mfma:
-        bt.set_option("jtj_mfma", 1)
-    if os.environ.get("WBC_PRESOLVE") is not None:        # diagnostic A/B: 0 = general path only (no structural presolve, no sim3 kernel)
-        bt.set_option("presolve", int(os.environ["WBC_PRESOLVE"]))
-    if os.environ.get("WBC_SIM3_KERNEL") is not None:     # diagnostic A/B: 0 = presolve inside the general kernel
-        bt.set_option("sim3_kernel", int(os.environ["WBC_SIM3_KERNEL"]))
-    if os.environ.get("WBC_DBG_ALIAS"):
-        bt.set_option("dbg_alias_inputs", 1)
-
-    class GpuFK:   # inputs are placed on the robot with the product's own FK (never the oracle's)
-        def __call__(self, q):
-            return bt.fk(q, want=("oMf",))["oMf"]
-
-    host_in = wbc_workload.make_tick_inputs(model, cfg, B, seed=rank, fk=GpuFK(), stress=True)
-    dev_in = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in host_in.items()}
-    dev_out = dict(qdot=torch.zeros((B, 26), dtype=torch.float64, device=dev),
-                   status=torch.zeros(B, dtype=torch.int32, device=dev), iters=torch.zeros(B, dtype=torch.int32, device=dev))
-    step = bt.make_tick_call(dev_in, dev_out, DT)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                      # same (current) stream the C-ABI launches on
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # closed loop: K chained ticks on the device = tick + updateState/trunkWorldPos + reference-state advance
-    closed = None
-    if args.rollout_ticks > 0 and world == 1:     # extra leg, single-GPU runs only
-        step_t = torch.zeros((B, 5, 3), dtype=torch.float64, device=dev)
-        step_t[:, 4, 0] = 1e-4
-        bt.rollout(dev_in, DT, 2, ee_target_step=step_t, want_trace=False)
-        barrier()
-        t1 = time.perf_counter()
-        ro = bt.rollout(dev_in, DT, args.rollout_ticks, ee_target_step=step_t, want_trace=False)
-        barrier()
-        t_roll = time.perf_counter() - t1
-        closed = {"value": float(B) * args.rollout_ticks / t_roll, "unit": "closed-loop ticks/s per GPU", "ticks": args.rollout_ticks,
-                  "ms_per_tick": 1e3 * t_roll / args.rollout_ticks, "optimal_frac": float((ro["status"] == 0).double().mean().item()),
-                  "what": "wbc_rollout: wbc_tick + wbc_update_state (FK + trunkWorldPos) + prev-target state advance, targets moving 0.1 mm/tick"}
-
-    status = dev_out["status"].cpu().numpy()
-    iters = dev_out["iters"].cpu().numpy()
-    qdot = dev_out["qdot"].cpu().numpy()
-
+    engine = GpuEngine(args, local)
+    comm = Comm("nccl", rank, world, engine.dev)
+    line, res = run_rank(args, comm, engine, make_inputs)
+    ok = True
     if rank == 0:
-        ticks = float(B) * world * args.steps
-        value = ticks / elapsed
-        ach = ALGO_BYTES_PER_TICK * B / (kernel_ms * 1e-3) / 1e9
-        line = {
-            "metric": "wbc_qp_solves_per_sec", "value": value, "unit": "ticks/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2] / SURVEY C3: A1+wx200 (nq 27, nv 26), sim3 switch set: Grip task + " + args.posture + " posture, "
-                                   "12 contact equalities + 4 trunk-box rows + 26 damper bounds (3 locked), m=32 p=16 n=26",
-                       "batch_per_gpu": B, "global_batch": B * world, "dt": DT, "parallelism": "shard%d (no collective)" % world,
-                       "jtj": "mfma_f64" if args.jtj_mfma else "valu_f64"},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes(), "traffic_unit": "bytes/launch (PMC, batch 65536)", "kernel": "wbc_tick_sim3_kernel (+ wbc_tick_deferred_kernel)", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_tick": ALGO_BYTES_PER_TICK, "streamed_bytes_per_tick": ACTUAL_BYTES_PER_TICK,
-                         "fp64_tflops": ALGO_FLOP_PER_TICK * B / (kernel_ms * 1e-3) / 1e12,
-                         "fp64_frac": ALGO_FLOP_PER_TICK * B / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                         "issue": pmc_issue_busy(),
-                         "note": "tiny-dense LDS-resident fp64 work: VALU- and LDS-issue bound, neither HBM nor MFMA is approachable (SURVEY.md §8d); see profiles/"},
-            "solver": {"optimal_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
-                       "iters_p95": float(np.percentile(iters, 95)), "iters_max": int(iters.max())},
-        }
-        if closed is not None:
-            line["closed_loop"] = closed
+        if args.rollout_ticks > 0 and world == 1:     # closed loop, extra leg of single-GPU runs
+            what = "wbc_rollout: wbc_tick + wbc_update_state (FK + trunkWorldPos) + prev-target state advance, targets moving 0.1 mm/tick"
+            line["closed_loop"] = dict(engine.closed_loop(make_inputs(engine, args.batch, seed=rank, stress=True), args.rollout_ticks),
+                                       unit="closed-loop ticks/s per GPU", ticks=args.rollout_ticks, what=what,
+                                       inputs="C3 stress recipe (25 % of the trunks start at / just outside their box edge: those QPs turn "
+                                              "infeasible within a few ticks and the instance holds still — see worst_status_histogram)")
+            line["closed_loop_unstressed"] = dict(engine.closed_loop(make_inputs(engine, args.batch, seed=rank, stress=False), args.rollout_ticks),
+                                                  unit="closed-loop ticks/s per GPU", ticks=args.rollout_ticks,
+                                                  inputs="same distribution without the stress recipe")
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle   # checker / yardstick only
-            cores = len(os.sched_getaffinity(0))
-            n = args.cpu_sample or min(B, 16384)
-            sub = {k: v[:n] for k, v in host_in.items()}
-            oracle.tick([model], [cfg], {k: v[:256] for k, v in host_in.items()}, DT, 256, nthreads=cores, want_q_next=False)
-            reps, t_cpu, ref = 0, 0.0, None
-            while t_cpu < 10.0 and reps < 64:
-                t1 = time.perf_counter()
-                ref = oracle.tick([model], [cfg], sub, DT, n, nthreads=cores, want_q_next=False)
-                t_cpu += time.perf_counter() - t1
-                reps += 1
-            t1 = time.perf_counter()
-            oracle.tick([model], [cfg], {k: v[:2048] for k, v in host_in.items()}, DT, 2048, nthreads=1, want_q_next=False)
-            one = 2048 / (time.perf_counter() - t1)
-            ok = (ref["status"] == 0) & (status[:n] == 0)
-            line["cpu_baseline"] = {"value": n * reps / t_cpu, "unit": "ticks/s", "cores": cores, "kind": "port",
-                                    "sample": "first %d instances of rank 0's batch x %d repeats (%.1f s), OpenMP over %d threads; "
-                                              "single-thread rate %.0f ticks/s; reference design rate 500 ticks/s (paced, not measured)" % (n, reps, t_cpu, cores, one),
-                                    "single_thread": one}
-            line["accuracy"] = {"qdot_max_abs_err_vs_cpu": float(np.abs(ref["qdot"] - qdot[:n])[ok].max()),
-                                "status_agree_frac": float((ref["status"] == status[:n]).mean()), "tolerance": 1e-5, "instances": int(n)}
+            ok = cpu_baseline_and_accuracy(line, engine, engine.host_in, res, args)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    bt.close()
+    comm.close()
+    engine.close()
+    if not ok:
+        raise SystemExit("bench.py: accuracy gate failed (see \"accuracy\" in the line above)")
 
 
 if __name__ == "__main__":

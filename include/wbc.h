@@ -171,10 +171,11 @@ typedef struct WbcTickOut {
   double* q_next;   /* [B][27] pin.integrate(q, qdot*dt) (may be NULL)                    */
 } WbcTickOut;
 
-/* forward-kinematics outputs of updateState (all optional) */
+/* forward-kinematics outputs of updateState (all optional). In a handle with several models the per-instance strides of
+ * oMi / oMf are the LARGEST model's njoints / nframes; an instance of a smaller model fills its own rows and zeroes the rest. */
 typedef struct WbcFkOut {
-  double* oMi;     /* [B][njoints][12]  R (9, row-major) then p (3); joint 0 = identity       */
-  double* oMf;     /* [B][nframes][12]  controller frames (WbcModelBlob.frame_*)              */
+  double* oMi;     /* [B][max njoints][12]  R (9, row-major) then p (3); joint 0 = identity   */
+  double* oMf;     /* [B][max nframes][12]  controller frames (WbcModelBlob.frame_*)          */
   double* J;       /* [B][6][26] data.J of computeJointJacobians (WORLD)                      */
   double* com;     /* [B][3]     data.com[0]                                                  */
   double* Jcom;    /* [B][3][26] jacobianCenterOfMass                                         */
@@ -267,8 +268,27 @@ typedef struct WbcRollout {
 } WbcRollout;
 int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRollout* r, int mem, void* stream);
 
-/* knobs: 0 = default. "jtj_mfma": use v_mfma_f64_16x16x4_f64 for the J'J contraction in wbc_tick/wbc_assemble. */
+/* Knobs of a handle (none of them changes a result beyond rounding; defaults in brackets):
+ *   "jtj_mfma"         [0] 1: H = A'A of wbc_tick / wbc_assemble on the fp64 matrix cores (v_mfma_f64_16x16x4_f64) instead of
+ *                          the sparse vector-unit contraction. Selects the general tick kernel (the compact sim3 kernel has no
+ *                          matrix-core path), so on the sim3 switch set it costs the structural speed-up.
+ *   "presolve"         [1] structural elimination of the stance-foot contact equalities (Robot_Wrapper4.py:757-761) where no
+ *                          task touches the stance legs; 0: every QP runs at its full size n = nv.
+ *   "sim3_kernel"      [1] batches whose every model has such an elimination plan, <= 16 constraint rows and no orientation
+ *                          references run on the compact wbc_tick_sim3_kernel (+ a second pass of the general kernel over the
+ *                          instances whose leg blocks it could not eliminate); 0: the general kernel does the elimination.
+ *   "presolve_tol_exp" [7] a stance-leg 3 x 3 block K with |det K| <= 10^-value (sum |K_ij|)^3 is treated as singular
+ *                          (0: every block, i.e. the fallback for singular blocks is forced on every instance).
+ *   "grid"                 workgroups of the grid-stride kernels (wbc_qp_solve*, wbc_integrate); default = what fills the chip.
+ *   "dbg_alias_inputs" [0] diagnostic: every instance reads instance 0's inputs (isolates input latency in timings).
+ *   "dbg_stop"         [0] diagnostic: the sim3 kernel stops after stage k (1..7, see wbc_kernels.hip) — outputs are garbage,
+ *                          only the run time means something (tools/ablate_sim3.py). */
 int wbc_batch_set_option(WbcBatch* b, const char* name, int value);
+
+/* Read-only statistics of a handle: "last_path" (kernel the last tick ran on: 0 general, 1 compact sim3 + second pass),
+ * "deferred_last" (instances the last sim3-kernel tick left to the second pass; waits for `stream`),
+ * "sim3_lds_bytes" / "tick_lds_bytes" (LDS per instance of the two tick kernels). */
+int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, int64_t* out);
 
 /* wait for everything queued by this handle on `stream`. */
 int wbc_batch_synchronize(WbcBatch* b, void* stream);

@@ -45,7 +45,10 @@ struct WbcBatch {
   double sing_tol;
   int sim3_kernel;       // 1 (default): batches that qualify run on wbc_tick_sim3_kernel (compact LDS) + a deferred pass
   int32_t* d_status;     // status buffer of our own when the caller passes none (the deferred pass needs one)
-  int dbg_alias;
+  int dbg_alias, dbg_stop;
+  int32_t* d_defer;      // [1 + max_batch]: count + compact list of the instances the sim3 kernel deferred (lazy)
+  int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass)
+  int max_nj, max_nf;    // FK output strides: the largest model's joint / frame counts
   unsigned long long* d_prof;
   double *d_pu, *d_pq;   // qpJointb MANI/HYBRID results: u [max_batch][26], q_after [max_batch][27] (lazy)
   void* d_roll;          // wbc_rollout's mutable controller state for max_batch instances (lazy)
@@ -93,6 +96,8 @@ extern "C" int wbc_model_create(const WbcModelBlob* b, WbcModel** out) {
     // velocity columns of this joint
     const int nvj = (t == WBC_JT_FF) ? 6 : 1;
     if (b->idx_v[j] < 0 || b->idx_v[j] + nvj > b->nv) { delete m; return fail(WBC_E_ARG, "joint %d: idx_v out of range", j); }
+    // idx_q becomes a global write index (q_next) and a shift count in the kernels: 1-DoF joints live in [7, nq)
+    if (t != WBC_JT_FF && (b->idx_q[j] < 7 || b->idx_q[j] >= b->nq)) { delete m; return fail(WBC_E_ARG, "joint %d: idx_q %d outside [7, nq = %d)", j, b->idx_q[j], b->nq); }
     for (int c = 0; c < nvj; ++c) {
       const int k = b->idx_v[j] + c;
       d.col_joint[k] = j; d.col_lin[k] = -1; d.col_ang[k] = -1; d.col_q[k] = b->idx_q[j] + c;
@@ -125,6 +130,7 @@ extern "C" int wbc_model_create(const WbcModelBlob* b, WbcModel** out) {
 extern "C" void wbc_model_destroy(WbcModel* m) { delete m; }
 
 // ---------------------------------------------------------------------------------------------- batch
+extern "C" void wbc_batch_destroy(WbcBatch* b);
 extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int max_batch, int device_id, WbcBatch** out) {
   if (!out || n_models < 0 || n_models > WBC_MAX_MODELS || (n_models > 0 && !models) || max_batch < 1)
     return fail(WBC_E_ARG, "wbc_batch_create: bad arguments (n_models %d, max_batch %d)", n_models, max_batch);
@@ -142,18 +148,27 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
     b->models[i] = models[i];
     dm[i] = models[i]->dev;
+    if (models[i]->blob.njoints > b->max_nj) b->max_nj = models[i]->blob.njoints;
+    if (models[i]->blob.nframes > b->max_nf) b->max_nf = models[i]->blob.nframes;
   }
+  // everything allocated so far is released on any failure below (wbc_batch_destroy frees what is non-null)
+#define HIP_TRY_B(expr)                                                                                              \
+  do {                                                                                                               \
+    hipError_t e_ = (expr);                                                                                          \
+    if (e_ != hipSuccess) { wbc_batch_destroy(b); return fail(WBC_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); }  \
+  } while (0)
   hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  HIP_TRY_B(hipGetDeviceProperties(&prop, device_id));
   const int per_cu = (int)(prop.maxSharedMemoryPerMultiProcessor / (size_t)tick_lds_bytes());
   b->grid = prop.multiProcessorCount * (per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu));
   if (n_models > 0) {   // n_models == 0: a QP-only handle (wbc_qp_solve / wbc_qp_solve_ls)
-    HIP_TRY(hipMalloc((void**)&b->d_models, sizeof(DevModel) * n_models));
-    HIP_TRY(hipMalloc((void**)&b->d_cfgs, sizeof(WbcConfig) * n_models));
-    HIP_TRY(hipMalloc((void**)&b->d_plans, sizeof(DevPlan) * n_models));
-    HIP_TRY(hipMemset(b->d_plans, 0, sizeof(DevPlan) * n_models));
-    HIP_TRY(hipMemcpy(b->d_models, dm.data(), sizeof(DevModel) * n_models, hipMemcpyHostToDevice));
+    HIP_TRY_B(hipMalloc((void**)&b->d_models, sizeof(DevModel) * n_models));
+    HIP_TRY_B(hipMalloc((void**)&b->d_cfgs, sizeof(WbcConfig) * n_models));
+    HIP_TRY_B(hipMalloc((void**)&b->d_plans, sizeof(DevPlan) * n_models));
+    HIP_TRY_B(hipMemset(b->d_plans, 0, sizeof(DevPlan) * n_models));
+    HIP_TRY_B(hipMemcpy(b->d_models, dm.data(), sizeof(DevModel) * n_models, hipMemcpyHostToDevice));
   }
+#undef HIP_TRY_B
   *out = b;
   return WBC_OK;
 }
@@ -170,6 +185,7 @@ extern "C" void wbc_batch_destroy(WbcBatch* b) {
   if (b->d_pq) (void)hipFree(b->d_pq);
   if (b->d_roll) (void)hipFree(b->d_roll);
   if (b->d_status) (void)hipFree(b->d_status);
+  if (b->d_defer) (void)hipFree(b->d_defer);
   delete b;
 }
 
@@ -278,12 +294,8 @@ extern "C" int wbc_batch_configure(WbcBatch* b, int mi, const WbcConfig* cfg) {
   int mcart = 0;
   const int m = rows_task(*cfg, &mcart), p = rows_con(*cfg);
   if (p > WBC_MAX_P) return fail(WBC_E_ARG, "too many constraint rows (%d)", p);
-  for (int j = 0; j < b->n_models; ++j)
-    if (j != mi && b->configured[j]) {
-      int mc2 = 0;
-      if (rows_task(b->cfg_host[j], &mc2) != m || rows_con(b->cfg_host[j]) != p || mc2 != mcart)
-        return fail(WBC_E_ARG, "all models of a batch must share the task/constraint switches");
-    }
+  // (all models of a batch must share the task / constraint switches; that is checked when the batch is USED, so that a
+  //  configured multi-model batch can be moved to another switch set one model at a time — same_switches below)
   HIP_TRY(hipSetDevice(b->device_id));
   b->cfg_host[mi] = *cfg;
   b->configured[mi] = true;
@@ -307,8 +319,27 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!strcmp(name, "presolve_tol_exp")) { double t = 1.0; for (int i = 0; i < value; ++i) t *= 0.1; b->sing_tol = t; return WBC_OK; }
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
   if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
+  if (!strcmp(name, "dbg_stop")) { b->dbg_stop = value; return WBC_OK; }
   if (!strcmp(name, "grid")) { if (value < 1) return fail(WBC_E_ARG, "grid must be >= 1"); b->grid = value; return WBC_OK; }
   return fail(WBC_E_ARG, "unknown option %s", name);
+}
+
+extern "C" int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, int64_t* out) {
+  if (!b || !name || !out) return fail(WBC_E_ARG, "wbc_batch_get_stat: null");
+  HIP_TRY(hipSetDevice(b->device_id));
+  if (!strcmp(name, "last_path")) { *out = b->last_path; return WBC_OK; }
+  if (!strcmp(name, "deferred_last")) {      // waits for `stream`
+    *out = 0;
+    if (!b->d_defer || !b->last_path) return WBC_OK;
+    int32_t c = 0;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(&c, b->d_defer, sizeof c, hipMemcpyDeviceToHost));
+    *out = c;
+    return WBC_OK;
+  }
+  if (!strcmp(name, "sim3_lds_bytes")) { *out = sim3_lds_bytes(); return WBC_OK; }
+  if (!strcmp(name, "tick_lds_bytes")) { *out = tick_lds_bytes(); return WBC_OK; }
+  return fail(WBC_E_ARG, "unknown statistic %s", name);
 }
 
 extern "C" int wbc_batch_synchronize(WbcBatch* b, void* stream) {
@@ -359,13 +390,25 @@ struct Stager {
   }
 };
 
+// the switches that fix the row layout of A, C and which inputs a tick reads: identical for every model of a batch
+static bool same_switches(const WbcConfig& a, const WbcConfig& c) {
+  for (int i = 0; i < WBC_NEE; ++i)
+    if ((a.task_ee[i] != 0) != (c.task_ee[i] != 0) || (a.con_ee[i] != 0) != (c.con_ee[i] != 0)) return false;
+  return (a.task_trunk != 0) == (c.task_trunk != 0) && (a.task_com != 0) == (c.task_com != 0) &&
+         (a.con_com != 0) == (c.con_com != 0) && (a.con_trunk != 0) == (c.con_trunk != 0) &&
+         (a.use_bounds != 0) == (c.use_bounds != 0) && (a.task_joint != 0) == (c.task_joint != 0);
+}
 static int check_batch(WbcBatch* b, int B, const char* who, bool need_cfg, bool need_model = true) {
   if (!b) return fail(WBC_E_ARG, "%s: null batch", who);
   if (need_model && b->n_models < 1) return fail(WBC_E_STATE, "%s: this handle was created without a model", who);
   if (B < 1 || B > b->max_batch) return fail(WBC_E_ARG, "%s: B = %d outside [1, max_batch = %d]", who, B, b->max_batch);
-  if (need_cfg)
+  if (need_cfg) {
     for (int i = 0; i < b->n_models; ++i)
       if (!b->configured[i]) return fail(WBC_E_STATE, "%s: model %d has no configuration (wbc_batch_configure)", who, i);
+    for (int i = 1; i < b->n_models; ++i)
+      if (!same_switches(b->cfg_host[0], b->cfg_host[i]))
+        return fail(WBC_E_STATE, "%s: all models of a batch must share the task/constraint switches (model %d differs from model 0)", who, i);
+  }
   return WBC_OK;
 }
 static int grid_for(const WbcBatch* b, int B) { return B < b->grid ? B : b->grid; }   // persistent kernels (QP, integrate)
@@ -441,8 +484,8 @@ static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
   memset(&a, 0, sizeof a);
   a.models = b->d_models; a.cfgs = b->d_cfgs; a.plans = b->d_plans; a.n_models = b->n_models;
   a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma; a.presolve = b->presolve; a.sing_tol = b->sing_tol; a.dbg_alias = b->dbg_alias; a.dt = dt;
-  a.prof = b->d_prof;
-  if (b->n_models > 0) { a.fk_nj = b->models[0]->blob.njoints; a.fk_nf = b->models[0]->blob.nframes; }
+  a.prof = b->d_prof; a.dbg_stop = b->dbg_stop;
+  a.fk_nj = b->max_nj; a.fk_nf = b->max_nf;
 }
 
 // The fused tick on the best kernel for the batch: wbc_tick_sim3_kernel (compact LDS, reduced QP only) when every
@@ -450,6 +493,7 @@ static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
 // the instances it deferred (singular leg block); otherwise the general kernel alone. `a` holds device pointers.
 static bool sim3_eligible(const WbcBatch* b, const KernelArgs& a) {
   if (!b->sim3_kernel || !b->presolve || b->n_models < 1) return false;
+  if (b->jtj_mfma) return false;       // the compact kernel has no matrix-core contraction: the option selects the general kernel
   if (a.in.ee_ref_rot || a.in.com_target || a.in.com_target_vel) return false;
   if (b->prows > WBC_SIM3_MAXP || b->mcart > 12) return false;
   for (int i = 0; i < b->n_models; ++i) {
@@ -460,13 +504,18 @@ static bool sim3_eligible(const WbcBatch* b, const KernelArgs& a) {
 }
 static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
   if (!sim3_eligible(b, a)) {
+    b->last_path = 0;
     if (int e = launch_tick(a, MODE_TICK, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return WBC_OK;
   }
+  b->last_path = 1;
   if (!a.out.status) {
     if (!b->d_status) HIP_TRY(hipMalloc((void**)&b->d_status, sizeof(int32_t) * (size_t)b->max_batch));
     a.out.status = b->d_status;
   }
+  if (!b->d_defer) HIP_TRY(hipMalloc((void**)&b->d_defer, sizeof(int32_t) * ((size_t)b->max_batch + 1)));
+  a.defer = b->d_defer;
+  HIP_TRY(hipMemsetAsync(b->d_defer, 0, sizeof(int32_t), (hipStream_t)stream));   // (a memset node when the call is captured into a graph)
   if (int e = launch_tick_sim3(a, B, stream)) return fail(WBC_E_HIP, "sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   if (int e = launch_tick_deferred(a, stream)) return fail(WBC_E_HIP, "deferred tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return WBC_OK;
@@ -489,7 +538,7 @@ extern "C" int wbc_fk_jacobians(WbcBatch* b, int B, const double* q, const int32
       if (!b->configured[i]) HIP_TRY(hipMemcpy(b->d_cfgs + i, &z, sizeof z, hipMemcpyHostToDevice));
   }
   a.in.q = q; a.in.model_id = model_id; a.fk = *out;
-  const int nj = b->models[0]->blob.njoints, nf = b->models[0]->blob.nframes;
+  const int nj = b->max_nj, nf = b->max_nf;   // output strides: the largest model of the handle
   Stager st{b, mem, (hipStream_t)stream, {}};
   st.in(&a.in.q, (size_t)B * WBC_Q_STRIDE); st.in(&a.in.model_id, (size_t)B);
   st.out(&a.fk.oMi, (size_t)B * nj * 12); st.out(&a.fk.oMf, (size_t)B * nf * 12);

@@ -65,9 +65,10 @@ struct KernelArgs {
   int32_t n_models, pad0_;          // model indices read from the caller's buffer are clamped to [0, n_models)
   int32_t post_static;              // every model's DevPlan.post_static (then no posture kernel runs)
   int32_t dbg_alias;                // diagnostic: every wave loads instance 0's inputs (isolates HBM input latency)
-  int32_t pad1_;
+  int32_t dbg_stop;                 // diagnostic (ablation timing): the sim3 kernel returns after stage dbg_stop (0 = run the whole tick)
   int32_t jtj_mfma, presolve;  // presolve: structural elimination of the contact equalities (default on)
-  int32_t fk_nj, fk_nf;             // oMi / oMf output strides (sizes of model 0)
+  int32_t fk_nj, fk_nf;             // oMi / oMf output strides = max njoints / nframes over the handle's models
+  int32_t* defer;                   // [1 + max_batch]: count, then the instances wbc_tick_sim3_kernel left to the general path
   unsigned long long* prof;         // WBC_PROFILE builds: per-phase cycle sums [16] (else unused)
   double dt;
   double sing_tol;                  // a stance-leg block with |det K| <= sing_tol (sum|K_ij|)^3 is not eliminated

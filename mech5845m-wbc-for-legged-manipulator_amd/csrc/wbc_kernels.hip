@@ -234,7 +234,7 @@ struct QpResult { double x; int status; int iters; };
 template <int NM, class SM = Smem, int CS = LDJ>
 __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const double lb_in, const double ub_in,
                                             const double clb_in, const double cub_in, const int n, const int p, const int lane,
-                                            unsigned long long* ts) {
+                                            unsigned long long* ts, const int dbg_stop = 0) {
   const int li = lane < NM ? lane : NM - 1;
   QpResult res;
   res.status = WBC_QP_OPTIMAL;
@@ -346,6 +346,7 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   }
   STAMP(ts, T_CHOL);
   if (!(pmin > 0.0)) { res.status = WBC_QP_NUMERICAL; return res; }
+  if (dbg_stop == 6) { res.x = y[0] + h[0]; return res; }      // ablation timing: fused Cholesky / substitution sweep done
 
   // ---- constraint bookkeeping
   const bool has_b = lane < n, has_r = lane < p;
@@ -481,6 +482,7 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   double* const T = S.RA;
   const double* const Cm = S.RC;
   STAMP(ts, T_EQ);
+  if (dbg_stop == 7) { res.x = x; return res; }                // ablation timing: equality phase and x_eq done
 
   // ---- inequality phase
 #pragma unroll 1
@@ -1135,10 +1137,12 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
   double (&Rtr)[9] = fo.Rtr; double (&ptr)[3] = fo.ptr;
 
   if (MODE == MODE_FK) {
-    const int M0nj = A.fk_nj, M0nf = A.fk_nf;   // output strides = model 0's sizes
-    // outputs of updateState: oMi / oMf (row-major R then p), data.J, com, Jcom
+    const int M0nj = A.fk_nj, M0nf = A.fk_nf;   // output strides = the largest model of the handle (mixed batches)
+    // outputs of updateState: oMi / oMf (row-major R then p), data.J, com, Jcom; rows beyond this model's own count are zeroed
+    if (A.fk.oMi && lane >= nj && lane < M0nj) { double* o = A.fk.oMi + ((size_t)b * M0nj + lane) * 12; for (int i = 0; i < 12; ++i) o[i] = 0.0; }
+    if (A.fk.oMf && lane >= M.nframes && lane < M0nf) { double* o = A.fk.oMf + ((size_t)b * M0nf + lane) * 12; for (int i = 0; i < 12; ++i) o[i] = 0.0; }
     if (A.fk.oMi && lane < nj) {
-      double* o = A.fk.oMi + ((size_t)b * M0nj + lane) * 12;   // strides of model 0
+      double* o = A.fk.oMi + ((size_t)b * M0nj + lane) * 12;
       if (lane == 0) { for (int i = 0; i < 12; ++i) o[i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0; }
       else {
         const double* Pj = oMi + 12 * lane;
@@ -1565,6 +1569,13 @@ __device__ __forceinline__ void jtj_block_c(SmemC& S, const double* At, const in
   }
 }
 
+// Ablation timing (option "dbg_stop", diagnostic): the sim3 kernel ends after stage k with a store that keeps the stage's
+// results alive; run time of stage k = T(stop k) - T(stop k - 1). Stages: 1 FK + Jacobian columns, 2 task rows, 3 J'J +
+// posture, 4 constraint rows + damper bounds, 5 presolve (G, g', C', H'), 6 Cholesky / substitutions, 7 equality phase,
+// 0 = the whole tick. One uniform compare per stage in the shipped kernel.
+#define DBG_STOP(k, val) do { if (A.dbg_stop == (k)) { if (lane < NV) A.out.qdot[(size_t)b * NV + lane] = (val); \
+                                                      if (lane == 0) A.out.status[b] = 0; return; } } while (0)
+
 __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
                                              const DevPlan& P, const Hdr& H, const LaneConst& lc, const InRegs& inr,
                                              const int b, const int lane) {
@@ -1589,6 +1600,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   double (&Rtr)[9] = fo.Rtr; double (&ptr)[3] = fo.ptr;
 
   STAMP(ts, T_FK);
+  DBG_STOP(1, lin[0] + ang[1] + ptr[2] + Rtr[4]);
   // ---- the plan's index maps: one batch of scalar loads, per-lane views by select chains
   const int nelim = P.nelim, n_red = P.n_red, nl = 3 * nelim, p_keep = P.p_keep, p = A.prows;
   int legd[12], Fd[NR], rowstart[4];
@@ -1714,6 +1726,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   }
   WSYNC();
   STAMP(ts, T_A1);
+  DBG_STOP(2, g + At[(lane & 15) * mtp]);
   // ---- pass 2: H'[lane][k] = sum_r At[k][r] At[lane][r], block by block over each block's reduced support
   {
     int r0 = 0;
@@ -1740,6 +1753,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   if (lane < NR) S.RA[lane * LDJ + lane] += (lane < n_red) ? dpost * dpost : 1.0;
   WSYNC();   // At is dead: RB may be reused
   STAMP(ts, T_A2);
+  DBG_STOP(3, g + S.RA[(lane & 15) * LDJ + 3]);
   if (A.in.q_con) {   // the configuration qpJointb MANI/HYBRID left behind: constraints, bounds, integrate see it
     if (lane < NQ) S.in[IN_Q + lane] = inr.qc;
     WSYNC();
@@ -1825,6 +1839,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   if (lane < 32) { S.npv[lane] = g; S.xv[lane] = lb; S.yv[lane] = ub; }
   WSYNC();
   STAMP(ts, T_ASM);
+  DBG_STOP(4, g + lb + ub + clb + cub + Co[(lane & 15) * LDJ + 2]);
 
   // ---- G_e = -K_e^-1 B_e, all feet at once (see contact_presolve)
   double* const Gm = S.Gm;
@@ -1852,8 +1867,12 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
       Gm[(3 * f + 2) * GS + c] = live ? id * (a20 * b0 + a21 * b1 + a22 * b2) : 0.0;
     }
   }
-  if (singular) {   // left to the general kernel's second pass
-    if (lane == 0) A.out.status[b] = WBC_QP_DEFERRED;
+  if (singular) {   // left to the general kernel's second pass: appended to the compact list that pass walks
+    if (lane == 0) {
+      A.out.status[b] = WBC_QP_DEFERRED;
+      const int slot = atomicAdd(A.defer, 1);
+      A.defer[1 + slot] = b;
+    }
     WSYNC();
     return;
   }
@@ -1914,7 +1933,8 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   }
   WSYNC();
   STAMP(ts, T_PRE);
-  QpResult res = qp_core<NR, SmemC, CSC>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
+  DBG_STOP(5, g_red + lb_red + ub_red + nclb + ncub + S.RA[(lane & 15) * LDJ + 1] + Cm[(lane & 15) * CSC + 1]);
+  QpResult res = qp_core<NR, SmemC, CSC>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, A.dbg_stop);
   res.iters += nl;
   // ---- x = Z y
   WSYNC();
@@ -1976,27 +1996,29 @@ __global__ void __launch_bounds__(64, 3) wbc_tick_sim3_kernel(const KernelArgs A
   process_sim3(S, A, models[mid], cfgs[mid], plans[mid], H, lc, cur, b, lane);
 }
 
-// Second pass after wbc_tick_sim3_kernel: the instances it deferred (rare: a singular stance-leg block) are redone on the
-// general path. One wave inspects 64 statuses with one coalesced load and walks the flagged ones; a sequential loop is
-// fine here (speed is irrelevant for a handful of instances per batch, and every wave reaches the loop exit).
+// Second pass after wbc_tick_sim3_kernel: the instances it deferred (a stance-leg block it could not eliminate) are redone on
+// the general path. The sim3 kernel appended them to a compact list (A.defer: count, then instance indices, in arrival
+// order); workgroup i takes entries i, i + gridDim.x, ... — with at most gridDim.x deferred instances (the usual handful)
+// every one has a workgroup of its own, and a batch that defers everything is spread over the whole chip instead of being
+// walked 64 instances per wave. Every wave reaches the loop exit (i >= count).
 __global__ void __launch_bounds__(64, 2) wbc_tick_deferred_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                                   const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   __shared__ Smem S;
   const int lane0 = threadIdx.x;
-  const int cand = blockIdx.x * 64 + lane0;
-  unsigned long long todo = __ballot(cand < A.B && A.out.status[cand < A.B ? cand : 0] == WBC_QP_DEFERRED);
-  if (!todo) return;
+  int count = __builtin_amdgcn_readfirstlane(A.defer[0]);
+  if (count > A.B) count = A.B;
+  if ((int)blockIdx.x >= count) return;
   const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
                     A.in.com_target || A.in.com_target_vel;
   const bool has3 = A.in.ee_ref_rot != nullptr;
 #pragma unroll 1
-  while (todo) {
-    const int b = blockIdx.x * 64 + ctz64(todo);
-    todo &= todo - 1;
+  for (int i = blockIdx.x; i < count; i += gridDim.x) {
+    int b = __builtin_amdgcn_readfirstlane(A.defer[1 + i]);
+    b = b < 0 ? 0 : (b >= A.B ? A.B - 1 : b);
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     S.cl[lane] = 0.0;
-      const int mid = model_index(A.in.model_id, b, A.n_models);
+    const int mid = model_index(A.in.model_id, b, A.n_models);
     const InRegs cur = load_inputs(A.in, b, lane, has2, has3);
     const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);
     stage_inputs(S, cur, lane, has2, has3);
@@ -2346,7 +2368,8 @@ int launch_tick_sim3(const KernelArgs& a, int grid, void* stream) {
   return check_launch("tick_sim3");
 }
 int launch_tick_deferred(const KernelArgs& a, void* stream) {
-  hipLaunchKernelGGL(wbc_tick_deferred_kernel, dim3((a.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  const int grid = a.B < 2048 ? a.B : 2048;    // 8 general-path workgroups per CU: one round of the chip
+  hipLaunchKernelGGL(wbc_tick_deferred_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   return check_launch("tick_deferred");
 }
 int sim3_lds_bytes() { return (int)sizeof(SmemC); }

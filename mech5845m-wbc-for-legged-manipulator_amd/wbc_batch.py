@@ -25,27 +25,34 @@ def _mem_of(arrays):
     return capi.MEM_DEVICE if kinds == {"dev"} else capi.MEM_HOST
 
 
-def _prep(a, dtype, keep):
-    """-> (pointer, array kept alive). numpy arrays are made contiguous float64/int32; torch tensors are checked."""
+# doubles (int32 for model_id) per instance of every WbcTickIn field (include/wbc.h)
+TICK_IN_WIDTH = dict(q=NQS, ee_target=15, prev_ee_target=15, trunk_target=3, prev_trunk_target=3, trunk_box_center=4,
+                     ee_ref_rot=45, ee_prev_rot=45, trunk_ref_euler=3, trunk_prev_rot=9, com_target=3, com_target_vel=3,
+                     model_id=1, posture_u=NV, q_con=NQS)
+
+
+def _prep(a, dtype, keep, B=None, width=None, name="array", device_id=None):
+    """-> pointer (the array is kept alive in `keep`). numpy arrays are made contiguous float64/int32; torch tensors are
+    checked. With B / width given the array must hold exactly B x width values with B as its leading dimension: the
+    kernels index raw pointers with those strides, so a wrong shape would read (or write) its neighbours' data."""
     if a is None:
         return None
+    if B is not None:
+        shape = tuple(a.shape)
+        if len(shape) < 1 or shape[0] != B or int(np.prod(shape)) != B * width:
+            raise capi.WbcError("%s: shape %s does not hold %d x %d values (leading dimension = batch)" % (name, shape, B, width))
     if _is_torch(a):
         import torch
         want = torch.float64 if dtype == np.float64 else torch.int32
         if a.dtype != want or not a.is_contiguous():
-            raise capi.WbcError("device tensors must be contiguous %s" % want)
+            raise capi.WbcError("%s: device tensors must be contiguous %s" % (name, want))
+        if a.is_cuda and device_id is not None and a.device.index != device_id:
+            raise capi.WbcError("%s lives on cuda:%s, the handle on cuda:%d" % (name, a.device.index, device_id))
         keep.append(a)
         return a.data_ptr()
     arr = np.ascontiguousarray(a, dtype=dtype)
     keep.append(arr)
     return arr.ctypes.data
-
-
-def _stream(mem):
-    if mem == capi.MEM_DEVICE:
-        import torch
-        return torch.cuda.current_stream().cuda_stream
-    return None
 
 
 class WbcBatch:
@@ -60,8 +67,30 @@ class WbcBatch:
             self._mh.append(h)
         arr = (C.c_void_p * len(self._mh))(*[h.value for h in self._mh])
         self._h = C.c_void_p()
+        self.device_id = int(device_id)
         capi.check(self.lib.wbc_batch_create(arr, len(self._mh), self.max_batch, device_id, C.byref(self._h)), self.lib)
         self.cfgs = [None] * len(self.models)
+        self.max_nj = max(m.njoints for m in self.models)          # FK output strides (include/wbc.h, WbcFkOut)
+        self.max_nf = max(m.blob.nframes for m in self.models)
+
+    def _stream(self, mem):
+        """the handle's device's current torch stream for device buffers, the null stream for host buffers"""
+        if mem == capi.MEM_DEVICE:
+            import torch
+            return torch.cuda.current_stream(self.device_id).cuda_stream
+        return None
+
+    def _p(self, a, dtype, keep, B=None, width=None, name="array"):
+        return _prep(a, dtype, keep, B, width, name, self.device_id)
+
+    def _batch_of(self, q, name="q"):
+        if q is None or len(q.shape) != 2 or q.shape[1] != NQS:
+            raise capi.WbcError("%s must be [B, %d] (padded to the largest model's nq), got %s" % (
+                name, NQS, None if q is None else tuple(q.shape)))
+        B = int(q.shape[0])
+        if B < 1 or B > self.max_batch:
+            raise capi.WbcError("B = %d outside [1, max_batch = %d]" % (B, self.max_batch))
+        return B
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -102,14 +131,30 @@ class WbcBatch:
     def synchronize(self, stream=None):
         capi.check(self.lib.wbc_batch_synchronize(self._h, stream), self.lib)
 
+    def stat(self, name, stream=None):
+        """wbc_batch_get_stat: "last_path", "deferred_last", "sim3_lds_bytes", "tick_lds_bytes"."""
+        v = C.c_int64()
+        capi.check(self.lib.wbc_batch_get_stat(self._h, name.encode(), stream, C.byref(v)), self.lib)
+        return int(v.value)
+
     # ---- helpers
-    def _tick_in(self, inputs, keep):
+    def _tick_in(self, inputs, keep, B):
+        unknown = set(inputs) - set(TICK_IN_WIDTH)
+        if unknown:
+            raise capi.WbcError("unknown tick inputs %s" % sorted(unknown))
         t = capi.WbcTickIn()
         for name, _ in capi.WbcTickIn._fields_:
             a = inputs.get(name)
             if a is not None:
-                setattr(t, name, _prep(a, np.int32 if name == "model_id" else np.float64, keep))
+                setattr(t, name, self._p(a, np.int32 if name == "model_id" else np.float64, keep, B, TICK_IN_WIDTH[name], name))
         return t
+
+    def _outs(self, out, widths, keep, B, struct):
+        for k, v in out.items():
+            if k not in widths:
+                raise capi.WbcError("unknown output %r" % k)
+            setattr(struct, k, self._p(v, np.int32 if k in ("status", "iters") else np.float64, keep, B, widths[k], k))
+        return struct
 
     def _alloc(self, like, shape, dtype=np.float64):
         if like is not None and _is_torch(like):
@@ -119,68 +164,67 @@ class WbcBatch:
 
     # ---- entry points
     def fk(self, q, model_id=None, want=("oMi", "oMf", "J", "com", "Jcom")):
-        """updateState's kinematics: returns dict(oMi [B,nj,12], oMf [B,nf,12], J [B,6,26], com [B,3], Jcom [B,3,26])."""
+        """updateState's kinematics: returns dict(oMi [B,nj,12], oMf [B,nf,12], J [B,6,26], com [B,3], Jcom [B,3,26]);
+        nj / nf are the LARGEST model's joint / frame counts (rows beyond an instance's own model are zero)."""
         keep = []
         mem = _mem_of([q, model_id])
-        B = q.shape[0]
-        nj, nf = self.models[0].njoints, self.models[0].blob.nframes
+        B = self._batch_of(q)
+        nj, nf = self.max_nj, self.max_nf
         shapes = dict(oMi=(B, nj, 12), oMf=(B, nf, 12), J=(B, 6, NV), com=(B, 3), Jcom=(B, 3, NV))
         out = {k: self._alloc(q, shapes[k]) for k in want}
         o = capi.WbcFkOut()
         for k, v in out.items():
-            setattr(o, k, _prep(v, np.float64, keep))
-        capi.check(self.lib.wbc_fk_jacobians(self._h, B, _prep(q, np.float64, keep), _prep(model_id, np.int32, keep), mem,
-                                              C.byref(o), _stream(mem)), self.lib)
+            setattr(o, k, self._p(v, np.float64, keep))
+        capi.check(self.lib.wbc_fk_jacobians(self._h, B, self._p(q, np.float64, keep), self._p(model_id, np.int32, keep, B, 1, "model_id"),
+                                              mem, C.byref(o), self._stream(mem)), self.lib)
         return out
 
     def assemble(self, inputs, dt, want=("A", "b", "H", "g", "C", "Clb", "Cub", "lb", "ub")):
         """qpA/qpb/findConstraints/velDamperJointConstraints + H, g for every instance."""
         keep = []
         mem = _mem_of(list(inputs.values()))
-        q = inputs["q"]
-        B = q.shape[0]
+        q = inputs.get("q")
+        B = self._batch_of(q)
         m, p = self.task_rows, self.constraint_rows
         shapes = dict(A=(B, m, NV), b=(B, m), H=(B, NV, NV), g=(B, NV), C=(B, p, NV), Clb=(B, p), Cub=(B, p), lb=(B, NV), ub=(B, NV))
         out = {k: self._alloc(q, shapes[k]) for k in want}
         o = capi.WbcQpData()
         for k, v in out.items():
-            setattr(o, k, _prep(v, np.float64, keep))
-        tin = self._tick_in(inputs, keep)
-        capi.check(self.lib.wbc_assemble(self._h, B, C.byref(tin), float(dt), mem, C.byref(o), _stream(mem)), self.lib)
+            setattr(o, k, self._p(v, np.float64, keep))
+        tin = self._tick_in(inputs, keep, B)
+        capi.check(self.lib.wbc_assemble(self._h, B, C.byref(tin), float(dt), mem, C.byref(o), self._stream(mem)), self.lib)
         return out
+
+    _TICK_OUT_WIDTH = dict(qdot=NV, status=1, iters=1, q_next=NQS)
 
     def tick(self, inputs, dt, want_q_next=False, out=None):
         """One runWBC tick per instance up to the QP (+ integrate): returns dict(qdot, status, iters[, q_next])."""
         keep = []
-        mem = _mem_of(list(inputs.values()))
-        q = inputs["q"]
-        B = q.shape[0]
+        q = inputs.get("q")
+        B = self._batch_of(q)
         if out is None:
             out = dict(qdot=self._alloc(q, (B, NV)), status=self._alloc(q, (B,), np.int32), iters=self._alloc(q, (B,), np.int32))
             if want_q_next:
                 out["q_next"] = self._alloc(q, (B, NQS))
-        o = capi.WbcTickOut()
-        for k, v in out.items():
-            setattr(o, k, _prep(v, np.int32 if k in ("status", "iters") else np.float64, keep))
-        tin = self._tick_in(inputs, keep)
-        capi.check(self.lib.wbc_tick(self._h, B, C.byref(tin), float(dt), mem, C.byref(o), _stream(mem)), self.lib)
+        mem = _mem_of(list(inputs.values()) + list(out.values()))
+        o = self._outs(out, self._TICK_OUT_WIDTH, keep, B, capi.WbcTickOut())
+        tin = self._tick_in(inputs, keep, B)
+        capi.check(self.lib.wbc_tick(self._h, B, C.byref(tin), float(dt), mem, C.byref(o), self._stream(mem)), self.lib)
         return out
 
     def make_tick_call(self, inputs, out, dt):
-        """Bind device tensors once; the returned closure issues exactly one wbc_tick on the current stream."""
+        """Bind device tensors once; the returned closure issues exactly one wbc_tick on the handle's current stream."""
         keep = []
         if _mem_of(list(inputs.values()) + list(out.values())) != capi.MEM_DEVICE:
             raise capi.WbcError("make_tick_call wants device tensors")
-        B = inputs["q"].shape[0]
-        o = capi.WbcTickOut()
-        for k, v in out.items():
-            setattr(o, k, _prep(v, np.int32 if k in ("status", "iters") else np.float64, keep))
-        tin = self._tick_in(inputs, keep)
-        lib, h, dtv = self.lib, self._h, float(dt)
+        B = self._batch_of(inputs.get("q"))
+        o = self._outs(out, self._TICK_OUT_WIDTH, keep, B, capi.WbcTickOut())
+        tin = self._tick_in(inputs, keep, B)
+        lib, h, dtv, dev = self.lib, self._h, float(dt), self.device_id
         import torch
 
         def call():
-            rc = lib.wbc_tick(h, B, C.byref(tin), dtv, capi.MEM_DEVICE, C.byref(o), torch.cuda.current_stream().cuda_stream)
+            rc = lib.wbc_tick(h, B, C.byref(tin), dtv, capi.MEM_DEVICE, C.byref(o), torch.cuda.current_stream(dev).cuda_stream)
             if rc:
                 capi.check(rc, lib)
         call._keep = keep
@@ -190,29 +234,41 @@ class WbcBatch:
         """Batched QP.solveQP given H, g. H [B,n,n], C_ [B,p,n] (row-major rows), returns (x, status, iters)."""
         keep = []
         mem = _mem_of([H, g, C_, lb, ub, Clb, Cub])
+        if len(H.shape) != 3 or H.shape[1] != H.shape[2]:
+            raise capi.WbcError("H must be [B, n, n], got %s" % (tuple(H.shape),))
         B, n = H.shape[0], H.shape[-1]
+        if C_ is not None and (len(C_.shape) != 3 or C_.shape[2] != n):
+            raise capi.WbcError("C must be [B, p, %d], got %s" % (n, tuple(C_.shape)))
         p = 0 if C_ is None else C_.shape[-2]
         x, st, it = self._alloc(H, (B, n)), self._alloc(H, (B,), np.int32), self._alloc(H, (B,), np.int32)
         f = np.float64
-        capi.check(self.lib.wbc_qp_solve(self._h, B, n, p, _prep(H, f, keep), _prep(g, f, keep), _prep(C_, f, keep),
-                                          _prep(lb, f, keep), _prep(ub, f, keep), _prep(Clb, f, keep), _prep(Cub, f, keep), mem,
-                                          _prep(x, f, keep), _prep(st, np.int32, keep), _prep(it, np.int32, keep), _stream(mem)), self.lib)
+        P = self._p
+        capi.check(self.lib.wbc_qp_solve(self._h, B, n, p, P(H, f, keep), P(g, f, keep, B, n, "g"), P(C_, f, keep, B, p * n, "C"),
+                                          P(lb, f, keep, B, n, "lb"), P(ub, f, keep, B, n, "ub"), P(Clb, f, keep, B, p, "Clb"),
+                                          P(Cub, f, keep, B, p, "Cub"), mem,
+                                          P(x, f, keep), P(st, np.int32, keep), P(it, np.int32, keep), self._stream(mem)), self.lib)
         return x, st, it
 
     def qp_solve_ls(self, A, b, C_=None, lb=None, ub=None, Clb=None, Cub=None, use_mfma=False, want_Hg=False):
         """Batched QP(A, b, ...).solveQP(): H = A'A and g = -A'b are formed on the device (QP_Wrapper.py:17-18)."""
         keep = []
         mem = _mem_of([A, b, C_, lb, ub, Clb, Cub])
+        if len(A.shape) != 3:
+            raise capi.WbcError("A must be [B, m, n], got %s" % (tuple(A.shape),))
         B, m, n = A.shape
+        if C_ is not None and (len(C_.shape) != 3 or C_.shape[2] != n):
+            raise capi.WbcError("C must be [B, p, %d], got %s" % (n, tuple(C_.shape)))
         p = 0 if C_ is None else C_.shape[-2]
         x, st, it = self._alloc(A, (B, n)), self._alloc(A, (B,), np.int32), self._alloc(A, (B,), np.int32)
         Ho = self._alloc(A, (B, n, n)) if want_Hg else None
         go = self._alloc(A, (B, n)) if want_Hg else None
         f = np.float64
-        capi.check(self.lib.wbc_qp_solve_ls(self._h, B, m, n, p, _prep(A, f, keep), _prep(b, f, keep), _prep(C_, f, keep),
-                                             _prep(lb, f, keep), _prep(ub, f, keep), _prep(Clb, f, keep), _prep(Cub, f, keep), mem,
-                                             int(bool(use_mfma)), _prep(x, f, keep), _prep(st, np.int32, keep), _prep(it, np.int32, keep),
-                                             _prep(Ho, f, keep), _prep(go, f, keep), _stream(mem)), self.lib)
+        P = self._p
+        capi.check(self.lib.wbc_qp_solve_ls(self._h, B, m, n, p, P(A, f, keep), P(b, f, keep, B, m, "b"), P(C_, f, keep, B, p * n, "C"),
+                                             P(lb, f, keep, B, n, "lb"), P(ub, f, keep, B, n, "ub"), P(Clb, f, keep, B, p, "Clb"),
+                                             P(Cub, f, keep, B, p, "Cub"), mem,
+                                             int(bool(use_mfma)), P(x, f, keep), P(st, np.int32, keep), P(it, np.int32, keep),
+                                             P(Ho, f, keep), P(go, f, keep), self._stream(mem)), self.lib)
         return (x, st, it, Ho, go) if want_Hg else (x, st, it)
 
     def posture_target(self, q, model_id=None, want_q_after=True):
@@ -220,12 +276,12 @@ class WbcBatch:
         and the configuration the reference's state is left at, q_after [B,27]."""
         keep = []
         mem = _mem_of([q, model_id])
-        B = q.shape[0]
+        B = self._batch_of(q)
         u = self._alloc(q, (B, NV))
         qa = self._alloc(q, (B, NQS)) if want_q_after else None
         f = np.float64
-        capi.check(self.lib.wbc_posture_target(self._h, B, _prep(q, f, keep), _prep(model_id, np.int32, keep), mem,
-                                                _prep(u, f, keep), _prep(qa, f, keep), _stream(mem)), self.lib)
+        capi.check(self.lib.wbc_posture_target(self._h, B, self._p(q, f, keep), self._p(model_id, np.int32, keep, B, 1, "model_id"), mem,
+                                                self._p(u, f, keep), self._p(qa, f, keep), self._stream(mem)), self.lib)
         return (u, qa) if want_q_after else u
 
     def update_state(self, q_cur, q_next, foot_targets, imu=None, model_id=None):
@@ -233,22 +289,23 @@ class WbcBatch:
         foot-anchored base estimator trunkWorldPos (:1297-1327). Returns the new current_joint_config [B,27]."""
         keep = []
         mem = _mem_of([q_cur, q_next, foot_targets, imu, model_id])
-        B = q_cur.shape[0]
+        B = self._batch_of(q_cur, "q_cur")
         qn = self._alloc(q_cur, (B, NQS))
         f = np.float64
-        capi.check(self.lib.wbc_update_state(self._h, B, _prep(q_cur, f, keep), _prep(q_next, f, keep), _prep(imu, f, keep),
-                                              _prep(foot_targets, f, keep), _prep(model_id, np.int32, keep), mem,
-                                              _prep(qn, f, keep), _stream(mem)), self.lib)
+        P = self._p
+        capi.check(self.lib.wbc_update_state(self._h, B, P(q_cur, f, keep), P(q_next, f, keep, B, NQS, "q_next"), P(imu, f, keep, B, 4, "imu"),
+                                              P(foot_targets, f, keep, B, 15, "foot_targets"), P(model_id, np.int32, keep, B, 1, "model_id"), mem,
+                                              P(qn, f, keep), self._stream(mem)), self.lib)
         return qn
 
-    def rollout(self, inputs, dt, ticks, ee_target_step=None, trunk_target_step=None, imu=None, want_trace=True):
+    def rollout(self, inputs, dt, ticks, ee_target_step=None, trunk_target_step=None, imu=None, want_trace=True, warm_start=None):
         """K closed-loop ticks on the device: tick -> update_state -> reference-state side effects ->
         targets advance by their step. Returns dict(q, qdot, ee_target, status, iters[, grip_trace [K,B,3]])."""
         keep = []
         extra = [ee_target_step, trunk_target_step, imu]
         mem = _mem_of(list(inputs.values()) + extra)
-        q = inputs["q"]
-        B = q.shape[0]
+        q = inputs.get("q")
+        B = self._batch_of(q)
         out = dict(q=self._alloc(q, (B, NQS)), qdot=self._alloc(q, (B, NV)), ee_target=self._alloc(q, (B, 5, 3)),
                    status=self._alloc(q, (B,), np.int32), iters=self._alloc(q, (B,), np.int32))
         if want_trace:
@@ -256,22 +313,25 @@ class WbcBatch:
         r = capi.WbcRollout()
         r.ticks = int(ticks)
         f = np.float64
-        r.ee_target_step, r.trunk_target_step, r.imu = _prep(ee_target_step, f, keep), _prep(trunk_target_step, f, keep), _prep(imu, f, keep)
-        r.q_final, r.qdot_last, r.ee_target_final = _prep(out["q"], f, keep), _prep(out["qdot"], f, keep), _prep(out["ee_target"], f, keep)
-        r.status_max, r.iters_sum = _prep(out["status"], np.int32, keep), _prep(out["iters"], np.int32, keep)
+        P = self._p
+        r.ee_target_step, r.trunk_target_step, r.imu = (P(ee_target_step, f, keep, B, 15, "ee_target_step"),
+                                                        P(trunk_target_step, f, keep, B, 3, "trunk_target_step"), P(imu, f, keep, B, 4, "imu"))
+        r.q_final, r.qdot_last, r.ee_target_final = P(out["q"], f, keep), P(out["qdot"], f, keep), P(out["ee_target"], f, keep)
+        r.status_max, r.iters_sum = P(out["status"], np.int32, keep), P(out["iters"], np.int32, keep)
         if want_trace:
-            r.grip_trace = _prep(out["grip_trace"], f, keep)
-        tin = self._tick_in(inputs, keep)
-        capi.check(self.lib.wbc_rollout(self._h, B, C.byref(tin), float(dt), C.byref(r), mem, _stream(mem)), self.lib)
+            r.grip_trace = P(out["grip_trace"], f, keep)
+        tin = self._tick_in(inputs, keep, B)
+        capi.check(self.lib.wbc_rollout(self._h, B, C.byref(tin), float(dt), C.byref(r), mem, self._stream(mem)), self.lib)
         return out
 
     def integrate(self, q, v, dt, model_id=None):
         """pin.integrate(model, q, v * dt) for every instance."""
         keep = []
         mem = _mem_of([q, v, model_id])
-        B = q.shape[0]
+        B = self._batch_of(q)
         qn = self._alloc(q, (B, NQS))
         f = np.float64
-        capi.check(self.lib.wbc_integrate(self._h, B, _prep(q, f, keep), _prep(v, f, keep), _prep(model_id, np.int32, keep),
-                                           float(dt), mem, _prep(qn, f, keep), _stream(mem)), self.lib)
+        P = self._p
+        capi.check(self.lib.wbc_integrate(self._h, B, P(q, f, keep), P(v, f, keep, B, NV, "v"), P(model_id, np.int32, keep, B, 1, "model_id"),
+                                           float(dt), mem, P(qn, f, keep), self._stream(mem)), self.lib)
         return qn

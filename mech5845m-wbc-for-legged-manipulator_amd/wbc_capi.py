@@ -103,6 +103,7 @@ SIGNATURES = {
     "wbc_rollout": (_i, [_vp, _i, C.POINTER(WbcTickIn), _d, C.POINTER(WbcRollout), _i, _vp]),
     "wbc_integrate": (_i, [_vp, _i, _vp, _vp, _vp, _d, _i, _vp, _vp]),
     "wbc_batch_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "wbc_batch_get_stat": (_i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64)]),
     "wbc_batch_synchronize": (_i, [_vp, _vp]),
     "wbc_debug_cycles": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "wbc_last_error": (C.c_char_p, []),

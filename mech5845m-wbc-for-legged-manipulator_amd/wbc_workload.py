@@ -11,7 +11,7 @@ import numpy as np
 
 import wbc_capi as capi
 
-_MOCAP = os.path.join(os.path.dirname(capi.HERE), "tests", "golden", "mocap_wx200_legs.csv")
+_MOCAP = os.path.join(capi.HERE, "data", "mocap_wx200_legs.csv")   # ships with the package: the product never reads tests/
 _mocap_cache = None
 
 

@@ -78,18 +78,19 @@ def constraint_rows(cfg):
 
 
 def fk(models, q, model_id=None, want_com=True):
-    """-> dict(oMi [B][nj][12], oMf [B][nf][12], J [B][6][26], com [B][3], Jcom [B][3][26]) (model 0 shapes)."""
+    """-> dict(oMi [B][nj][12], oMf [B][nf][12], J [B][6][26], com [B][3], Jcom [B][3][26]); nj / nf = the largest
+    model's joint / frame counts (include/wbc.h WbcFkOut), rows beyond an instance's own model are zero."""
     q = _f64(q).reshape(-1, NQS)
     B = q.shape[0]
-    m0 = models[0]
-    out = dict(oMi=np.zeros((B, m0.njoints, 12)), oMf=np.zeros((B, m0.blob.nframes, 12)), J=np.zeros((B, 6, NV)))
+    nj, nf = max(m.njoints for m in models), max(m.blob.nframes for m in models)
+    out = dict(oMi=np.zeros((B, nj, 12)), oMf=np.zeros((B, nf, 12)), J=np.zeros((B, 6, NV)))
     if want_com:
         out.update(com=np.zeros((B, 3)), Jcom=np.zeros((B, 3, NV)))
     o = capi.WbcFkOut()
     for k, v in out.items():
         setattr(o, k, v.ctypes.data)
     mid = None if model_id is None else np.ascontiguousarray(model_id, dtype=np.int32)
-    lib().orc_fk_batch(_models(models), C.c_int(B), _p(q), _p(mid), C.byref(o), C.c_int(1))
+    lib().orc_fk_batch(_models(models), C.c_int(B), _p(q), _p(mid), C.byref(o), C.c_int(1), C.c_int(nj), C.c_int(nf))
     return out
 
 

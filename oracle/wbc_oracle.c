@@ -936,16 +936,18 @@ void orc_qp_batch(int B, int n, int p, const double* H, const double* g, const d
 }
 
 /* FK + Jacobians for a batch (outputs as WbcFkOut). */
+/* nj_stride / nf_stride: joints / frames per instance in o->oMi / o->oMf (the largest model of a mixed batch, include/wbc.h
+ * WbcFkOut); rows beyond an instance's own model are left as the caller initialised them (zeros). */
 void orc_fk_batch(const WbcModelBlob* const* models, int B, const double* q, const int32_t* model_id,
-                  const WbcFkOut* o, int nthreads) {
+                  const WbcFkOut* o, int nthreads, int nj_stride, int nf_stride) {
 #pragma omp parallel for num_threads(nthreads) schedule(static)
   for (int b = 0; b < B; ++b) {
     const WbcModelBlob* m = models[model_id ? model_id[b] : 0];
     double oMi[WBC_MAX_JOINTS * 12], J[6 * NV], com[3], Jcom[3 * NV];
     orc_fk(m, q + (size_t)b * NQS, oMi);
     orc_joint_jacobians(m, oMi, J);
-    if (o->oMi) memcpy(o->oMi + (size_t)b * m->njoints * 12, oMi, sizeof(double) * m->njoints * 12);
-    if (o->oMf) for (int f = 0; f < m->nframes; ++f) orc_frame_placement(m, oMi, f, o->oMf + ((size_t)b * m->nframes + f) * 12);
+    if (o->oMi) memcpy(o->oMi + (size_t)b * nj_stride * 12, oMi, sizeof(double) * m->njoints * 12);
+    if (o->oMf) for (int f = 0; f < m->nframes; ++f) orc_frame_placement(m, oMi, f, o->oMf + ((size_t)b * nf_stride + f) * 12);
     if (o->J) memcpy(o->J + (size_t)b * 6 * NV, J, sizeof J);
     if (o->com || o->Jcom) {
       orc_com(m, oMi, J, com, Jcom);

@@ -118,3 +118,16 @@ def test_linear_trajectory_is_klampt_piecewise_linear():
     tr = _LinearTrajectory([[0, 0, 0], [1, 2, 3], [1, 0, 3]])
     assert tr.eval(0) == [0, 0, 0] and tr.eval(-1) == [0, 0, 0] and tr.eval(5) == [1, 0, 3]
     assert np.allclose(tr.eval(0.25), [0.25, 0.5, 0.75]) and np.allclose(tr.eval(1.5), [1, 1, 3])
+
+
+def test_array_shapes_are_checked_on_the_host():
+    """wbc_batch._prep is the gate in front of every raw pointer: B x width values with B leading, or an error."""
+    import wbc_batch
+    keep = []
+    assert wbc_batch._prep(np.zeros((4, 27)), np.float64, keep, 4, 27, "q")
+    assert wbc_batch._prep(np.zeros((4, 5, 3)), np.float64, keep, 4, 15, "ee_target")
+    assert wbc_batch._prep(None, np.float64, keep, 4, 15, "ee_target") is None
+    for bad in (np.zeros((4, 26)), np.zeros((3, 27)), np.zeros(4 * 27), np.zeros((27, 4))):
+        with pytest.raises(capi.WbcError, match="q: shape"):
+            wbc_batch._prep(bad, np.float64, keep, 4, 27, "q")
+    assert set(wbc_batch.TICK_IN_WIDTH) == {n for n, _ in capi.WbcTickIn._fields_}

@@ -269,31 +269,184 @@ def test_contact_presolve_and_general_path_agree(wx200, px100, cfg_name):
     bt.close()
 
 
+def _leg_block_ratio(a):
+    """min over the four stance feet of |det K| / (sum |K_ij|)^3 per instance, K = the foot's 3 x 3 leg block of its WORLD-frame
+    contact rows (constraint rows 4.. of the sim3 switch set; FR, FL, RR, RL own DoF 9-11, 6-8, 15-17, 12-14)."""
+    r = np.full(a["C"].shape[0], np.inf)
+    for f, d0 in enumerate((9, 6, 15, 12)):
+        K = a["C"][:, 4 + 3 * f:7 + 3 * f, d0:d0 + 3]
+        r = np.minimum(r, np.abs(np.linalg.det(K)) / np.abs(K).sum(axis=(1, 2)) ** 3)
+    return r
+
+
 def test_sim3_kernel_defers_singular_leg_blocks(wx200):
-    """A stance leg whose 3 x 3 WORLD-frame block is singular cannot be eliminated: the compact kernel defers the instance
-    to the general kernel's second pass. Built by brute force: search random poses for the smallest |det K|, then shrink
-    it further along the gradient-free direction of one calf angle; whatever is left must still match the oracle."""
-    import wbc_workload
+    """A stance leg whose 3 x 3 WORLD-frame block is (nearly) singular cannot be eliminated: the compact kernel hands the
+    instance to the general kernel's second pass. The 64 instances of a 4096-instance sample with the smallest
+    |det K| / scale^3 are run at the default threshold (1e-7): whichever of them fall below it must be deferred (count
+    checked against the same test on the oracle's C), and every one must match the oracle."""
     B = 4096
     cfg = common.config("c3", wx200)
     d = common.tick_inputs(wx200, cfg, B, seed=77)
-    # FR leg block of the FR contact rows (constraint rows 4..6, DoF 9..11 in compat order): make it singular by zeroing
-    # the moment arm: put the base so that the FR foot's WORLD-frame columns are parallel -> use the oracle's C to pick
     a = oracle.assemble([wx200], [cfg], d, DT, B)
-    K = a["C"][:, 4:7, 9:12]
-    det = np.abs(np.linalg.det(K))
-    scale = np.abs(K).sum(axis=(1, 2)) ** 3
-    ratio = det / scale
+    ratio = _leg_block_ratio(a)
     idx = np.argsort(ratio)[:64]
     sub = {k: v[idx] for k, v in d.items()}
     ref = oracle.tick([wx200], [cfg], sub, DT, len(idx), nthreads=8)
     bt = WbcBatch(wx200, len(idx))
     bt.configure(cfg)
     got = bt.tick(sub, DT)
+    assert bt.stat("last_path") == 1
+    expect = int((ratio[idx] <= 1e-7).sum())
+    assert abs(bt.stat("deferred_last") - expect) <= 1          # (a ratio within rounding of the threshold may fall either way)
     assert (got["status"] == ref["status"]).all() and (got["status"] >= 0).all()
     ok = ref["status"] == 0
     assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
-    print("smallest |det K| / scale^3 in the sample: %.2e" % ratio[idx[0]])
+    print("smallest |det K| / scale^3 in the sample: %.2e, deferred %d" % (ratio[idx[0]], bt.stat("deferred_last")))
+    bt.close()
+
+
+@pytest.mark.parametrize("tol_exp", [0, 3, 5])
+def test_forced_deferral_matches_the_oracle(wx200, px100, tol_exp):
+    """The second pass under load: option presolve_tol_exp lowers the bar for "singular" so that a known share of the
+    batch (all of it at 0) is deferred by the compact kernel and redone by the general kernel from the compact list.
+    The deferred count is the one predicted from the oracle's constraint rows; q̇, status and q_next match the oracle."""
+    B = 3000                                        # > 2048: the list is longer than the second pass's grid at tol_exp = 0
+    models = [wx200, px100]
+    cfgs = [common.config("c3", m) for m in models]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=83 + i) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
+    ratio = _leg_block_ratio(oracle.assemble(models, cfgs, d, DT, B))
+    tol = 10.0 ** -tol_exp
+    expect = int((ratio <= tol).sum())
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    bt.set_option("presolve_tol_exp", tol_exp)
+    got = bt.tick(d, DT, want_q_next=True)
+    n_def = bt.stat("deferred_last")
+    print("tol 1e-%d: deferred %d of %d (predicted %d)" % (tol_exp, n_def, B, expect))
+    assert n_def > 0 and abs(n_def - expect) <= max(2, expect // 200)
+    if tol_exp == 0:
+        assert n_def == B
+    else:
+        assert n_def < B
+    assert (got["status"] == ref["status"]).all()
+    ok = ref["status"] == 0
+    assert ok.mean() > 0.9
+    assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+    assert np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    bt.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["c2", "everything", "c3"])
+def test_tick_and_assemble_on_the_matrix_cores(wx200, cfg_name):
+    """Option jtj_mfma: H = A'A of wbc_assemble / wbc_tick from v_mfma_f64_16x16x4_f64 (QP_Wrapper.py:17) against the oracle,
+    and the option really selects the kernel that has the matrix-core path (the compact sim3 kernel has none)."""
+    B = 512
+    cfg = common.config(cfg_name, wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=19, with_rot=(cfg_name == "everything"))
+    ref = oracle.tick([wx200], [cfg], d, DT, B, nthreads=8)
+    ar = oracle.assemble([wx200], [cfg], d, DT, B)
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    valu = bt.tick(d, DT)
+    path_default = bt.stat("last_path")
+    bt.set_option("jtj_mfma", 1)
+    a = bt.assemble(d, DT)
+    for k in ("A", "b", "H", "g", "C", "Clb", "Cub", "lb", "ub"):
+        assert relerr(a[k], ar[k]) < 1e-11, (k, relerr(a[k], ar[k]))
+    got = bt.tick(d, DT, want_q_next=True)
+    assert bt.stat("last_path") == 0                                  # general kernel
+    assert path_default == (1 if cfg_name == "c3" else 0)
+    assert (got["status"] == ref["status"]).all()
+    ok = ref["status"] == 0
+    assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+    assert np.abs(got["qdot"] - valu["qdot"])[ok].max() < QDOT_TOL
+    assert np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    bt.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["c3", "everything"])
+def test_corrected_damper_map_on_the_device(wx200, px100, cfg_name):
+    """velDamperJointConstraints with the intended index map (damper_compat=False; the reference's own map is off by one,
+    SURVEY.md C.3): bounds and the tick on the HIP path against the oracle, both morphologies."""
+    B = 512
+    models = [wx200, px100]
+    if cfg_name == "c3":
+        cfgs = [wbc_model.sim3_config(m, damper_compat=False) for m in models]
+    else:
+        cfgs = [wbc_model.make_config(m, Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint="PREV", task_com=True,
+                                      cCoM=True, cTrunk=True, cFR=True, cFL=True, cRR=True, cRL=True, mode="static_reach",
+                                      damper_compat=False) for m in models]
+    assert list(cfgs[0].damper_qidx[:8]) == [0, 1, 2, 3, 4, 5, 7, 8]
+    for i, (m, c) in enumerate(zip(models, cfgs)):
+        d = common.tick_inputs(m, c, B, seed=43 + i)
+        compat = common.config("c3", m) if cfg_name == "c3" else common.config("everything", m)
+        ref, ar = oracle.tick([m], [c], d, DT, B, nthreads=8), oracle.assemble([m], [c], d, DT, B)
+        bt = WbcBatch(m, B)
+        bt.configure(c)
+        a = bt.assemble(d, DT)
+        for k in ("lb", "ub", "C", "Clb", "Cub", "H", "g"):
+            assert relerr(a[k], ar[k]) < 1e-11, (k, relerr(a[k], ar[k]))
+        assert np.abs(ar["lb"] - oracle.assemble([m], [compat], d, DT, B)["lb"]).max() > 1e-3    # the two maps do differ on this batch
+        got = bt.tick(d, DT, want_q_next=True)
+        assert (got["status"] == ref["status"]).all()
+        ok = ref["status"] == 0
+        assert ok.mean() > 0.9 and np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+        bt.close()
+
+
+def test_fk_outputs_of_a_mixed_batch_with_the_small_model_first(wx200, px100):
+    """FK output strides are the LARGEST model's joint / frame counts whatever the order of the models in the handle:
+    with [px100 (21 joints), wx200 (22)] every instance's oMi / oMf rows must be its own (round 1 used model 0's count as
+    the stride, so a wx200 instance wrote its 22nd joint into its neighbour's first row)."""
+    import wbc_workload
+    B = 257
+    models = [px100, wx200]
+    rng = np.random.default_rng(6)
+    mid = (np.arange(B) % 2).astype(np.int32)
+    qs = [wbc_workload.sample_q(m, B, rng) for m in models]
+    q = np.where(mid[:, None] == 0, qs[0], qs[1])
+    ref = oracle.fk(models, q, mid)
+    bt = WbcBatch(models, B)
+    got = bt.fk(q, mid)
+    assert got["oMi"].shape == (B, 22, 12) and ref["oMi"].shape == (B, 22, 12)
+    for k in ("oMi", "oMf", "J", "com", "Jcom"):
+        assert np.abs(got[k] - ref[k]).max() < 1e-12, k
+    assert (got["oMi"][mid == 0, 21] == 0).all() and np.abs(got["oMi"][mid == 1, 21]).max() > 0
+    bt.close()
+
+
+def test_wrong_shapes_and_devices_are_refused_before_any_launch(wx200, px100):
+    """The kernels index raw pointers with fixed per-instance strides: every array's shape is checked at the Python boundary."""
+    import torch
+    B = 16
+    cfg = common.config("c3", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=2)
+    bt = WbcBatch(wx200, 64)
+    bt.configure(cfg)
+    with pytest.raises(capi.WbcError, match=r"q must be \[B, 27\]"):
+        bt.tick(dict(d, q=d["q"][:, :26]), DT)                          # px100's true nq instead of the padded 27
+    with pytest.raises(capi.WbcError, match="ee_target"):
+        bt.tick(dict(d, ee_target=d["ee_target"][:, :4]), DT)
+    with pytest.raises(capi.WbcError, match="trunk_box_center"):
+        bt.tick(dict(d, trunk_box_center=d["trunk_box_center"][: B - 1]), DT)
+    with pytest.raises(capi.WbcError, match="model_id"):
+        bt.tick(dict(d, model_id=np.zeros(B - 3, dtype=np.int32)), DT)
+    with pytest.raises(capi.WbcError, match="qdot"):
+        bt.tick(d, DT, out=dict(qdot=np.zeros((B, 25)), status=np.zeros(B, np.int32)))
+    with pytest.raises(capi.WbcError, match="unknown tick inputs"):
+        bt.tick(dict(d, trunk_taget=d["trunk_target"]), DT)
+    with pytest.raises(capi.WbcError, match="ee_target_step"):
+        bt.rollout(d, DT, 2, ee_target_step=np.zeros((B, 4, 3)))
+    with pytest.raises(capi.WbcError, match="C must be"):
+        bt.qp_solve(np.eye(5)[None], np.zeros((1, 5)), np.zeros((1, 2, 4)), None, None, np.zeros((1, 2)), np.zeros((1, 2)))
+    with pytest.raises(capi.WbcError, match="mixing host and device"):
+        bt.tick(dict(d, q=torch.from_numpy(d["q"]).cuda()), DT)
+    assert bt.tick(d, DT)["status"].shape == (B,)                      # and the well-formed call still works
     bt.close()
 
 
@@ -663,4 +816,73 @@ def test_stray_model_indices_are_clamped(wx200, px100):
         assert np.array_equal(a[k], b_[k]), k
     assert np.array_equal(bt.fk(d["q"], bad)["oMf"], bt.fk(d["q"], want)["oMf"])
     assert np.array_equal(bt.integrate(d["q"], a["qdot"], DT, bad), bt.integrate(d["q"], a["qdot"], DT, want))
+    bt.close()
+
+
+def test_config4_as_eight_shards_on_one_gpu(wx200):
+    """BASELINE configs[3]: B = 524288 = 8 x 65536 shards, one per GPU, no communication. On one GPU: the 8 contiguous
+    wbc_shard.shard_range shards go one after the other through a 65536-instance handle (what each rank of the 8-GPU run does
+    with its own shard); their union must be bit-identical to ONE monolithic 524288-instance call, and match the oracle on a
+    2048-instance subsample."""
+    import wbc_shard
+    N, W = 524288, 8
+    cfg = common.config("c3", wx200)
+    d = common.tick_inputs(wx200, cfg, N, seed=404)
+    union = dict(qdot=np.empty((N, 26)), status=np.empty(N, dtype=np.int32), iters=np.empty(N, dtype=np.int32), q_next=np.empty((N, 27)))
+    bt = WbcBatch(wx200, N // W)
+    bt.configure(cfg)
+    for r in range(W):
+        lo, hi = wbc_shard.shard_range(N, r, W)
+        assert hi - lo == 65536
+        got = bt.tick({k: v[lo:hi] for k, v in d.items()}, DT, want_q_next=True)
+        for k in union:
+            union[k][lo:hi] = got[k]
+    bt.close()
+    big = WbcBatch(wx200, N)
+    big.configure(cfg)
+    mono = big.tick(d, DT, want_q_next=True)
+    big.close()
+    for k in union:
+        assert np.array_equal(union[k], mono[k]), k
+    assert (union["status"] == 0).mean() > 0.98
+    rng = np.random.default_rng(1)
+    idx = rng.choice(N, 2048, replace=False)
+    ref = oracle.tick([wx200], [cfg], {k: v[idx] for k, v in d.items()}, DT, len(idx), nthreads=8)
+    assert (ref["status"] == union["status"][idx]).all()
+    good = ref["status"] == 0
+    assert np.abs(ref["qdot"] - union["qdot"][idx])[good].max() < QDOT_TOL
+    assert np.abs(ref["q_next"] - union["q_next"][idx])[good].max() < 1e-7
+
+
+def test_mixed_morphology_full_size_properties(wx200, px100):
+    """BASELINE configs[4] (mixed wx200 / px100 lanes) at the full single-GPU batch B = 65536: contact rows satisfied, box
+    rows and bounds respected on every instance, padded DoF untouched, oracle parity on a 1024-instance subsample."""
+    B = 65536
+    models = [wx200, px100]
+    cfgs = [common.config("c3", m) for m in models]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=57 + i) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    got = bt.tick(d, DT)
+    assert bt.stat("last_path") == 1
+    a = bt.assemble(d, DT, want=("C", "Clb", "Cub", "lb", "ub"))
+    ok = got["status"] == 0
+    assert ok.mean() > 0.98
+    x = got["qdot"]
+    Cx = np.einsum("bpn,bn->bp", a["C"], x)
+    scale = 1 + np.abs(x).max(axis=1, keepdims=True)
+    assert (np.abs(Cx[:, 4:])[ok] / scale[ok]).max() < 1e-8
+    assert ((a["Clb"] - Cx)[ok] / scale[ok]).max() < 1e-8 and ((Cx - a["Cub"])[ok] / scale[ok]).max() < 1e-8
+    assert ((a["lb"] - x)[ok]).max() < 1e-8 and ((x - a["ub"])[ok]).max() < 1e-8
+    assert (x[mid == 1, 25] == 0).all()
+    rng = np.random.default_rng(5)
+    idx = np.sort(rng.choice(B, 1024, replace=False))
+    ref = oracle.tick(models, cfgs, {k: v[idx] for k, v in d.items()}, DT, len(idx), nthreads=8)
+    assert (ref["status"] == got["status"][idx]).all()
+    good = ref["status"] == 0
+    assert np.abs(ref["qdot"] - x[idx])[good].max() < QDOT_TOL
     bt.close()

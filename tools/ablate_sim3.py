@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Where the sim3 tick kernel's time goes, measured on the SHIPPED build by ablation (option "dbg_stop", include/wbc.h): the
+kernel is cut after stage k and timed; stage k costs T(k) - T(k - 1). No stamps, no atomics, same occupancy and code
+placement as the product (one uniform compare per stage).
+    python3 tools/ablate_sim3.py [B] [closed]     closed: states after a 10-tick roll-out instead of the seeded ones"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mech5845m-wbc-for-legged-manipulator_amd"))
+import numpy as np, torch
+import wbc_model, wbc_workload
+from wbc_batch import WbcBatch
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+model = wbc_model.load_model("a1_wx200")
+cfg = wbc_model.sim3_config(model)
+bt = WbcBatch(model, B)
+bt.configure(cfg)
+d = wbc_workload.make_tick_inputs(model, cfg, B, 0, lambda q: bt.fk(q, want=("oMf",))["oMf"])
+dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d.items()}
+out = dict(qdot=torch.zeros((B, 26), dtype=torch.float64, device="cuda"), status=torch.zeros(B, dtype=torch.int32, device="cuda"),
+           iters=torch.zeros(B, dtype=torch.int32, device="cuda"))
+step = bt.make_tick_call(dev, out, 0.002)
+names = {1: "FK + Jacobian columns", 2: "task rows + targets", 3: "J'J + posture", 4: "constraint rows + damper bounds",
+         5: "presolve (G, g', C', H')", 6: "Cholesky + substitutions", 7: "equality phase + x_eq", 0: "inequality phase + x = Z y + output"}
+res, prev = {}, 0.0
+for k in (1, 2, 3, 4, 5, 6, 7, 0):
+    bt.set_option("dbg_stop", k)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 10)
+    t = float(np.median(ts))
+    res[names[k]] = {"stop": k, "cumulative_ms": t, "stage_ms": t - prev}
+    prev = t
+    print("stop %d  %-40s cumulative %.4f ms  stage %.4f ms" % (k, names[k], t, res[names[k]]["stage_ms"]), flush=True)
+bt.set_option("dbg_stop", 0)
+print(json.dumps({"B": B, "note": "cumulative includes the (small) deferred pass; stage = difference of consecutive cuts", "stages": res}))
+bt.close()

@@ -7,7 +7,7 @@ TAG=${1:-prof}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
+BENCH="python3 bench.py --steps 4 --warmup 1 --repeats 1 --rollout-ticks 0 --no-cpu-baseline ${BENCH_ARGS:-}"
 step() {  # name, timeout, command...
   local name=$1 t=$2; shift 2
   timeout -k 10 "$t" "$@" > "$OUT/$name.log" 2>&1
