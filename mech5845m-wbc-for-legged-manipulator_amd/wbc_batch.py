@@ -70,8 +70,8 @@ class WbcBatch:
         self.device_id = int(device_id)
         capi.check(self.lib.wbc_batch_create(arr, len(self._mh), self.max_batch, device_id, C.byref(self._h)), self.lib)
         self.cfgs = [None] * len(self.models)
-        self.max_nj = max(m.njoints for m in self.models)          # FK output strides (include/wbc.h, WbcFkOut)
-        self.max_nf = max(m.blob.nframes for m in self.models)
+        self.max_nj = max((m.njoints for m in self.models), default=0)          # FK output strides (include/wbc.h, WbcFkOut)
+        self.max_nf = max((m.blob.nframes for m in self.models), default=0)
 
     def _stream(self, mem):
         """the handle's device's current torch stream for device buffers, the null stream for host buffers"""

@@ -626,8 +626,17 @@ def test_api_misuse_is_refused_with_a_message(wx200, px100):
     # two morphologies must share the switches, and a mixed batch needs model_id
     b2 = WbcBatch([wx200, px100], B)
     b2.configure(common.config("c3", wx200), 0)
+    b2.configure(common.config("c2", px100), 1)                     # accepted: a batch may change switch sets model by model ...
     with pytest.raises(capi.WbcError, match="share the task/constraint switches"):
-        b2.configure(common.config("c2", px100), 1)
+        b2.tick(dict(d, model_id=np.zeros(B, dtype=np.int32)), DT)    # ... but it cannot be USED while the models disagree
+    # equal row counts are not enough (round 1 compared only m and p): CoM box + trunk box vs two contact feet, both p = 6
+    six_a = wbc_model.make_config(wx200, Grip=True, Joint="PREV", cCoM=True, cTrunk=True, mode="static_reach")
+    six_b = wbc_model.make_config(px100, Grip=True, Joint="PREV", cFR=True, cFL=True, mode="static_reach")
+    b2.configure(six_a, 0)
+    b2.configure(six_b, 1)
+    with pytest.raises(capi.WbcError, match="share the task/constraint switches"):
+        b2.tick(dict(d, model_id=np.zeros(B, dtype=np.int32)), DT)
+    b2.configure(common.config("c3", wx200), 0)
     b2.configure(common.config("c3", px100), 1)
     with pytest.raises(capi.WbcError, match="model_id is required"):
         b2.tick(d, DT)
