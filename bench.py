@@ -134,7 +134,7 @@ class GpuEngine:
         self.cfg = wbc_model.sim3_config(self.model, Joint=args.posture)
         self.bt = WbcBatch(self.model, args.batch, device_id=local)
         self.bt.configure(self.cfg)
-        self.options = {"jtj_mfma": int(bool(args.jtj_mfma)), "presolve": 1, "sim3_kernel": 1, "dbg_alias_inputs": 0}
+        self.options = {"jtj_mfma": int(args.jtj_mfma), "presolve": 1, "sim3_kernel": 1, "dbg_alias_inputs": 0}
         for env, opt in (("WBC_PRESOLVE", "presolve"), ("WBC_SIM3_KERNEL", "sim3_kernel"), ("WBC_DBG_ALIAS", "dbg_alias_inputs")):
             if os.environ.get(env) not in (None, ""):       # diagnostic A/B switches: they change WHAT is measured, so they are reported
                 self.options[opt] = int(os.environ[env])
@@ -235,7 +235,7 @@ def run_rank(args, comm, engine, make_inputs):
                                "12 contact equalities + 4 trunk-box rows + 26 damper bounds (3 locked), m=32 p=16 n=26",
                    "batch_per_gpu": B, "global_batch": B * world, "dt": DT, "parallelism": "shard%d (no collective)" % world,
                    "engine": engine.name, "kernel_path": engine.path(), "options": getattr(engine, "options", {}),
-                   "jtj": "mfma_f64" if getattr(engine, "options", {}).get("jtj_mfma") else "valu_f64"},
+                   "jtj": "mfma_f64" if getattr(engine, "options", {}).get("jtj_mfma", -1) > 0 else "valu_f64"},
         "repeats": {"n": R, "ms_per_step": [1e3 * e / K for e in elapsed], "kernel_ms_per_step": kernel_ms,
                     "spread": (max(elapsed) - min(elapsed)) / t_med, "reported": "median block"},
         "roofline": {"bound": "valu_lds_issue_latency", "contract_bound": "hbm",
@@ -306,7 +306,7 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances for the CPU baseline (0 = auto, ~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--jtj-mfma", type=int, default=0)
+    ap.add_argument("--jtj-mfma", type=int, default=-1, help="-1 auto (library default), 0 vector units, 1 matrix cores (general kernel)")
     ap.add_argument("--rollout-ticks", type=int, default=10, help="closed-loop ticks of the extra wbc_rollout measurement (0 = skip)")
     ap.add_argument("--posture", default="PREV", choices=["PREV", "HYBRID", "MANI"],
                     help="posture mode of the tick (default PREV = the BASELINE workload; HYBRID is what sim3.py:145 sets)")

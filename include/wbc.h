@@ -46,6 +46,7 @@ extern "C" {
 #define WBC_MAX_P 24       /* constraint rows: CoM 2 + trunk 4 + 5 EE x 3 = 21 max                  */
 #define WBC_MAX_M 96       /* task rows accepted by wbc_qp_solve_ls (A is m x n)                    */
 #define WBC_MAX_MODELS 4   /* morphologies interleaved in one batch (BASELINE config 5)             */
+#define WBC_MFMA_AUTO_ROWS 30 /* "auto" puts H = A'A on the fp64 matrix cores from this many rows of A on    */
 
 /* joint types (pinocchio JointModel*) */
 enum { WBC_JT_UNIVERSE = 0, WBC_JT_FF = 1, WBC_JT_RX = 2, WBC_JT_RY = 3, WBC_JT_RZ = 4,
@@ -219,7 +220,8 @@ int wbc_qp_solve(WbcBatch* b, int B, int n, int p, const double* H, const double
                  double* x, int32_t* status, int32_t* iters, void* stream);
 
 /* replaces QP(A, b, ...) + solveQP(): forms H = A'A, g = -A'b on the device (QP_Wrapper.py:17-18)
- * and solves. A is [B][m][n]. H_out/g_out optional. use_mfma: 1 = fp64 MFMA contraction, 0 = VALU. */
+ * and solves. A is [B][m][n]. H_out/g_out optional. use_mfma: 1 = fp64 MFMA contraction, 0 = VALU, -1 = MFMA from
+ * WBC_MFMA_AUTO_ROWS rows on (measured 1.3x at m = 32, 1.8x at m = 64 and 96 on the whole call). */
 int wbc_qp_solve_ls(WbcBatch* b, int B, int m, int n, int p, const double* A, const double* bvec, const double* C,
                     const double* lb, const double* ub, const double* Clb, const double* Cub, int mem, int use_mfma,
                     double* x, int32_t* status, int32_t* iters, double* H_out, double* g_out, void* stream);
@@ -248,14 +250,20 @@ int wbc_integrate(WbcBatch* b, int B, const double* q, const double* v, const in
 int wbc_update_state(WbcBatch* b, int B, const double* q_cur, const double* q_next, const double* imu,
                      const double* foot_targets, const int32_t* model_id, int mem, double* q_new, void* stream);
 
-/* K closed-loop ticks without leaving the device: per tick wbc_tick -> wbc_update_state -> the
+/* K closed-loop ticks without leaving the device (the 2000 QPs of setInitialState for B robots in one
+ * call with mode = WBC_ROLLOUT_WARMUP, ticks = hold_ticks = 1000): per tick wbc_tick -> wbc_update_state -> the
  * reference-state side effects of qpb() (prev_EE_pos / prev_EE_CoM_rot, calcTargetVelEE3 :1151-1152; prev_trunk_ref /
  * old_ref_trunk_rot_matrix, calcTargetVelTrunk2 :995-996) -> the targets advance by a per-tick step (one linear segment
  * of sim3.py's milestone trajectory, sim3.py:207-228). `in0` is the state and the targets of the first tick (never
  * written); all outputs optional. */
+enum { WBC_ROLLOUT_RUNNING = 0  /* updateState(joint_config, base_config, running=True): IMU quaternion fed back, base xyz
+                                   re-estimated from the stance-foot targets (trunkWorldPos)                            */,
+       WBC_ROLLOUT_WARMUP = 1   /* updateState(new_config, feedback=False, running=False) as inside setInitialState's loop
+                                   (Robot_Wrapper4.py:287-326, 440-447 with initialised == False): the integrated
+                                   configuration becomes the state as it is — free-floating base, no IMU, no estimator   */ };
 typedef struct WbcRollout {
-  int32_t ticks;                    /* K >= 1                                                              */
-  int32_t pad_;
+  int32_t ticks;                    /* K >= 1 ticks during which the targets advance by their steps        */
+  int32_t mode;                     /* WBC_ROLLOUT_*                                                        */
   const double* ee_target_step;     /* [B][5][3] added to ee_target after every tick; NULL => constant     */
   const double* trunk_target_step;  /* [B][3]; NULL => constant                                            */
   const double* imu;                /* [B][4] base quaternion fed back every tick; NULL => the integrated one */
@@ -265,13 +273,19 @@ typedef struct WbcRollout {
   double* grip_trace;               /* [K][B][3] gripper_bar position reached after every tick (sim3.py:340-348's log) */
   int32_t* status_max;              /* [B] worst WBC_QP_* status over the K ticks                          */
   int32_t* iters_sum;               /* [B] working-set changes over the K ticks                            */
+  int32_t hold_ticks;               /* further ticks with the targets held where the K ticks left them (the second, clamped
+                                       segment of setInitialState's trajectories, Robot_Wrapper4.py:275); grip_trace then holds
+                                       ticks + hold_ticks entries                                           */
+  int32_t pad_;
 } WbcRollout;
 int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRollout* r, int mem, void* stream);
 
 /* Knobs of a handle (none of them changes a result beyond rounding; defaults in brackets):
- *   "jtj_mfma"         [0] 1: H = A'A of wbc_tick / wbc_assemble on the fp64 matrix cores (v_mfma_f64_16x16x4_f64) instead of
- *                          the sparse vector-unit contraction. Selects the general tick kernel (the compact sim3 kernel has no
- *                          matrix-core path), so on the sim3 switch set it costs the structural speed-up.
+ *   "jtj_mfma"        [-1] H = A'A of wbc_tick / wbc_assemble (QP_Wrapper.py:17) on the fp64 matrix cores (v_mfma_f64_16x16x4_f64)
+ *                          or as the sparse vector-unit contraction. -1: matrix cores when the Cartesian task stack has
+ *                          >= WBC_MFMA_AUTO_ROWS rows (measured: +9 % ticks/s at 33 and 45 rows, a wash at 6); 0: never;
+ *                          1: always — that also selects the general tick kernel (the compact sim3 kernel has no matrix-core
+ *                          path), so on the sim3 switch set it costs the structural speed-up.
  *   "presolve"         [1] structural elimination of the stance-foot contact equalities (Robot_Wrapper4.py:757-761) where no
  *                          task touches the stance legs; 0: every QP runs at its full size n = nv.
  *   "sim3_kernel"      [1] batches whose every model has such an elimination plan, <= 16 constraint rows and no orientation

@@ -43,7 +43,7 @@ class QP:
         self.nWSR = np.array([100000])
         self.qp = None
         self.status = None
-        self.use_mfma = False
+        self.use_mfma = None     # None: the library decides by the row count of A; True / False force the path
 
     # H, g are attributes in the reference (computed eagerly with numpy); here the device forms them on demand.
     @property

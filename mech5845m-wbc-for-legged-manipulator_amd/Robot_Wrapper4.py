@@ -497,8 +497,11 @@ class RobotModel:
     # ------------------------------------------------------------------ warm-up (reference :196-351)
     def setInitialState(self, iterations_per_segment=1000):
         """Drag the neutral pose to the crouched stance with the bounds-only QP (all six Cartesian tasks + Tikhonov
-        posture), one device tick per step of the straight-line foot/gripper trajectories, then fix the base."""
-        q0 = self._model.neutral()[:self._model.nq]
+        posture) along the straight-line foot / gripper trajectories, then fix the base: the B = 1 call of
+        ``WbcBatch.warm_up`` — the 2 x 1000 QPs run as ONE wbc_rollout (mode WBC_ROLLOUT_WARMUP) on the device. dt is the fixed
+        step_time here (the reference measures wall-clock inside its busy-wait)."""
+        nq = self._model.nq
+        q0 = self._model.neutral()[:nq]
         for i in range(self.n_velocity_dimensions):          # reference :201-208: only the upper clamp has an effect
             if q0[i] > self.robot_model.upperPositionLimit[i]:   # (this is what bends the knees: calf upper limit < 0)
                 q0[i] = self.robot_model.upperPositionLimit[i]
@@ -506,41 +509,24 @@ class RobotModel:
         self._log_previous_state()
         self._capture_default_orientations()
         Trunk_target_pos = np.copy(self.trunk_frame_pos)
-        start = [np.copy(p) for p in self.EE_frame_pos]
-        mult_F = np.diag([1.0, 1.0, 0.9])
-        mult_G = np.diag([1.1, 1.0, 1.5])
-        goal = []
-        for i in range(4):
-            p2 = np.copy(start[i])
-            p2[0] = self.robot_data.oMf[self.hip_waist_joint_index_list_frame[i]].translation[0]
-            goal.append(p2 @ mult_F)
-        g2 = np.copy(start[4])
-        g2[2] = self.robot_data.oMi[self.arm_base_id].translation[2]
-        g2[0] = self.robot_data.oMi[self.FR_hip_joint].translation[0]
-        goal.append(g2 @ mult_G)
-        traj = [_LinearTrajectory([start[i], goal[i]]) for i in range(5)]
         self.setTasks(Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=True)
         saved = (self.const_active_CoM, self.const_active_Trunk, self.const_active_FR_foot, self.const_active_FL_foot,
                  self.const_active_RR_foot, self.const_active_RL_foot, self.const_active_GRIP)
         self.setConstraints()
-        cfg = self._config()
-        step = 1.0 / iterations_per_segment
-        for k in range(2 * iterations_per_segment):          # np.arange(0, len(milestones) = 2, 0.001)
-            t = k * step
-            target = [np.array(tr.eval(t)).reshape(3, 1) for tr in traj]
-            self.FR_target_cartesian_pos, self.FL_target_cartesian_pos = target[0], target[1]
-            self.RR_target_cartesian_pos, self.RL_target_cartesian_pos = target[2], target[3]
-            self._pace()
-            q_vel, q_next = self._solve_tick(cfg, target, Trunk_target_pos)
-            self._advance_reference_state(target, Trunk_target_pos)
-            self.updateState(q_next, feedback=False, running=False)
+        self._bt.configure(self._config())                   # the object's own weights / gains (defaults at construction, :72-125)
+        q = np.zeros((1, capi.Q_STRIDE))
+        q[0, :nq] = q0
+        self.dt = self.step_time
+        out = self._bt.warm_up(q, None, self.step_time, iterations_per_segment, foot_radius=self.foot_radius, configure=False)
         self.setConstraints(*saved)
-        cfgq = np.array(self.current_joint_config, dtype=float)
-        cfgq[3:6] = 0.0                                       # "reset base orientation" (:328-330): x, y, z of the quaternion
-        self.updateState(cfgq, feedback=False)
-        height_offset = -sum(self.EE_frame_pos[i][2] for i in range(4)) / 4
-        cfgq[2] = height_offset + self.foot_radius
-        self.updateState(cfgq, feedback=False)
+        self.solver_status, self.solver_iters = int(out["status"][0]), int(out["iters"][0])
+        # the attribute state the reference's loop leaves behind: targets at their last milestone, reference state advanced
+        goal = out["goal"][0]
+        target = [goal[i].reshape(3, 1) for i in range(5)]
+        self.FR_target_cartesian_pos, self.FL_target_cartesian_pos = target[0], target[1]
+        self.RR_target_cartesian_pos, self.RL_target_cartesian_pos = target[2], target[3]
+        self._advance_reference_state(target, Trunk_target_pos)
+        self.updateState(out["q"][0, :nq].copy(), feedback=False)      # base orientation reset + trunk height fix included (:328-338)
         joints = self.current_joint_config[7:]
         self.FL_leg, self.FR_leg, self.RL_leg, self.RR_leg, self.grip = joints[0:3], joints[3:6], joints[6:9], joints[9:12], joints[12:]
         self.fristQP = False                                  # (sic) reference :347

@@ -143,6 +143,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
   b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
+  b->jtj_mfma = -1;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
@@ -314,12 +315,18 @@ extern "C" int wbc_constraint_rows(const WbcBatch* b) { return b ? b->prows : WB
 
 extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!b || !name) return fail(WBC_E_ARG, "wbc_batch_set_option: null");
-  if (!strcmp(name, "jtj_mfma")) { b->jtj_mfma = value; return WBC_OK; }
+  if (!strcmp(name, "jtj_mfma")) { b->jtj_mfma = value < 0 ? -1 : (value ? 1 : 0); return WBC_OK; }
   if (!strcmp(name, "presolve")) { b->presolve = value; return WBC_OK; }
   if (!strcmp(name, "presolve_tol_exp")) { double t = 1.0; for (int i = 0; i < value; ++i) t *= 0.1; b->sing_tol = t; return WBC_OK; }
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
   if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
-  if (!strcmp(name, "dbg_stop")) { b->dbg_stop = value; return WBC_OK; }
+  if (!strcmp(name, "dbg_stop")) {
+#ifdef WBC_ABLATE
+    b->dbg_stop = value; return WBC_OK;
+#else
+    return value == 0 ? WBC_OK : fail(WBC_E_UNSUPPORTED, "dbg_stop needs the ablation build of the library (make -C csrc ablate; WBC_HIP_LIB=.../libwbc_hip_ablate.so)");
+#endif
+  }
   if (!strcmp(name, "grid")) { if (value < 1) return fail(WBC_E_ARG, "grid must be >= 1"); b->grid = value; return WBC_OK; }
   return fail(WBC_E_ARG, "unknown option %s", name);
 }
@@ -483,7 +490,9 @@ static int auto_posture(WbcBatch* b, KernelArgs& a, int B, void* stream) {
 static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
   memset(&a, 0, sizeof a);
   a.models = b->d_models; a.cfgs = b->d_cfgs; a.plans = b->d_plans; a.n_models = b->n_models;
-  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma; a.presolve = b->presolve; a.sing_tol = b->sing_tol; a.dbg_alias = b->dbg_alias; a.dt = dt;
+  // J'J on the matrix cores: forced (1), off (0) or, by default (-1), for wide Cartesian stacks only — measured on MI355X
+  // (profiles/r02_mfma_evidence.txt): +9 % ticks/s at 33 and 45 Cartesian rows (config 2, "everything"), a wash at 6 (config 3)
+  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma < 0 ? (b->mcart >= WBC_MFMA_AUTO_ROWS) : b->jtj_mfma; a.presolve = b->presolve; a.sing_tol = b->sing_tol; a.dbg_alias = b->dbg_alias; a.dt = dt;
   a.prof = b->d_prof; a.dbg_stop = b->dbg_stop;
   a.fk_nj = b->max_nj; a.fk_nf = b->max_nf;
 }
@@ -493,7 +502,7 @@ static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
 // the instances it deferred (singular leg block); otherwise the general kernel alone. `a` holds device pointers.
 static bool sim3_eligible(const WbcBatch* b, const KernelArgs& a) {
   if (!b->sim3_kernel || !b->presolve || b->n_models < 1) return false;
-  if (b->jtj_mfma) return false;       // the compact kernel has no matrix-core contraction: the option selects the general kernel
+  if (b->jtj_mfma > 0) return false;   // forced: the compact kernel has no matrix-core contraction, the option selects the general kernel
   if (a.in.ee_ref_rot || a.in.com_target || a.in.com_target_vel) return false;
   if (b->prows > WBC_SIM3_MAXP || b->mcart > 12) return false;
   for (int i = 0; i < b->n_models; ++i) {
@@ -630,6 +639,8 @@ extern "C" int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, 
   int rc = check_batch(b, B, "wbc_rollout", true);
   if (rc) return rc;
   if (!r || r->ticks < 1 || !(dt > 0)) return fail(WBC_E_ARG, "wbc_rollout: ticks >= 1 and dt > 0 required");
+  if (r->hold_ticks < 0 || (r->mode != WBC_ROLLOUT_RUNNING && r->mode != WBC_ROLLOUT_WARMUP))
+    return fail(WBC_E_ARG, "wbc_rollout: hold_ticks >= 0 and mode WBC_ROLLOUT_RUNNING / WBC_ROLLOUT_WARMUP required");
   if ((rc = validate_tick_in(b, in0, "wbc_rollout"))) return rc;
   if (!in0->ee_target || !in0->prev_ee_target) return fail(WBC_E_ARG, "wbc_rollout: ee_target / prev_ee_target are required (the base estimator reads the foot targets)");
   HIP_TRY(hipSetDevice(b->device_id));
@@ -651,7 +662,7 @@ extern "C" int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, 
   stage_tick_in(st, a.in, B, b);
   st.in(&ro.ee_target_step, n * 15); st.in(&ro.trunk_target_step, n * 3); st.in(&ro.imu, n * 4);
   st.out(&ro.q_final, n * WBC_Q_STRIDE); st.out(&ro.qdot_last, n * WBC_V_STRIDE); st.out(&ro.ee_target_final, n * 15);
-  st.out(&ro.grip_trace, (size_t)r->ticks * n * 3); st.out(&ro.status_max, n); st.out(&ro.iters_sum, n);
+  st.out(&ro.grip_trace, (size_t)(r->ticks + r->hold_ticks) * n * 3); st.out(&ro.status_max, n); st.out(&ro.iters_sum, n);
   if ((rc = st.stage())) return rc;
   // seed the mutable state from in0
   auto seed = [&](int off, const double* src, size_t k) -> int {
@@ -673,7 +684,7 @@ extern "C" int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, 
 
   UpdateArgs u;
   memset(&u, 0, sizeof u);
-  u.models = b->d_models; u.cfgs = b->d_cfgs; u.B = B; u.n_models = b->n_models;
+  u.models = b->d_models; u.cfgs = b->d_cfgs; u.B = B; u.n_models = b->n_models; u.mode = r->mode;
   u.q_cur = blk(O_Q); u.q_next = blk(O_QN); u.imu = ro.imu; u.foot_targets = blk(O_EET); u.model_id = a.in.model_id; u.q_new = blk(O_Q);
   u.ee_target = blk(O_EET); u.prev_ee_target = blk(O_EEP);
   u.trunk_target = first.trunk_target ? blk(O_TT) : nullptr; u.prev_trunk_target = first.prev_trunk_target ? blk(O_TP) : nullptr;
@@ -682,7 +693,8 @@ extern "C" int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, 
   u.ee_step = ro.ee_target_step; u.trunk_step = ro.trunk_target_step;
   u.status = w_status; u.iters = w_iters; u.status_max = ro.status_max; u.iters_sum = ro.iters_sum;
   const WbcTickIn loop_in = a.in;
-  for (int k = 0; k < r->ticks; ++k) {
+  for (int k = 0; k < r->ticks + r->hold_ticks; ++k) {
+    if (k == r->ticks) { u.ee_step = nullptr; u.trunk_step = nullptr; }   // hold phase: the targets stay where they are
     a.in = loop_in;                       // auto_posture fills posture_u / q_con afresh every tick
     if ((rc = auto_posture(b, a, B, stream))) return rc;
     if ((rc = launch_tick_auto(b, a, B, stream))) return rc;
@@ -731,7 +743,7 @@ extern "C" int wbc_qp_solve_ls(WbcBatch* b, int B, int m, int n, int p, const do
   if (!A || !bvec || m < 1) return fail(WBC_E_ARG, "wbc_qp_solve_ls: A, b and m >= 1 required");
   QpArgs a;
   memset(&a, 0, sizeof a);
-  a.B = B; a.n = n; a.p = p; a.m = m; a.use_mfma = use_mfma;
+  a.B = B; a.n = n; a.p = p; a.m = m; a.use_mfma = use_mfma < 0 ? (m >= WBC_MFMA_AUTO_ROWS) : (use_mfma != 0);
   a.A = A; a.bvec = bvec; a.C = C; a.lb = lb; a.ub = ub; a.Clb = Clb; a.Cub = Cub;
   a.x = x; a.status = status; a.iters = iters; a.H_out = H_out; a.g_out = g_out;
   return qp_common(b, B, a, mem, stream, "wbc_qp_solve_ls");

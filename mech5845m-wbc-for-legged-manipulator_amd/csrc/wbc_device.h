@@ -110,6 +110,7 @@ struct UpdateArgs {
   const DevModel* models;
   const WbcConfig* cfgs;
   int32_t B, n_models;
+  int32_t mode, pad_;                  // WBC_ROLLOUT_RUNNING: IMU fed back + trunkWorldPos; WBC_ROLLOUT_WARMUP: q_new = q_next as it is
   const double *q_cur, *q_next, *imu, *foot_targets;
   const int32_t* model_id;
   double* q_new;

@@ -1569,12 +1569,20 @@ __device__ __forceinline__ void jtj_block_c(SmemC& S, const double* At, const in
   }
 }
 
-// Ablation timing (option "dbg_stop", diagnostic): the sim3 kernel ends after stage k with a store that keeps the stage's
+// Ablation timing (option "dbg_stop", diagnostic build): the sim3 kernel ends after stage k with a store that keeps the stage's
 // results alive; run time of stage k = T(stop k) - T(stop k - 1). Stages: 1 FK + Jacobian columns, 2 task rows, 3 J'J +
 // posture, 4 constraint rows + damper bounds, 5 presolve (G, g', C', H'), 6 Cholesky / substitutions, 7 equality phase,
-// 0 = the whole tick. One uniform compare per stage in the shipped kernel.
+// 0 = the whole tick.
+// Compiled in only with -DWBC_ABLATE (csrc/Makefile target `ablate`): in the shipped kernel the stores that keep a cut stage's
+// results alive cost 24 spilled VGPRs (0.648 -> 0.688 ms per 65536 ticks), so there the macro is empty.
+#ifdef WBC_ABLATE
 #define DBG_STOP(k, val) do { if (A.dbg_stop == (k)) { if (lane < NV) A.out.qdot[(size_t)b * NV + lane] = (val); \
                                                       if (lane == 0) A.out.status[b] = 0; return; } } while (0)
+#define DBG_STOP_ARG A.dbg_stop
+#else
+#define DBG_STOP(k, val) do { } while (0)
+#define DBG_STOP_ARG 0
+#endif
 
 __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
                                              const DevPlan& P, const Hdr& H, const LaneConst& lc, const InRegs& inr,
@@ -1934,7 +1942,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   WSYNC();
   STAMP(ts, T_PRE);
   DBG_STOP(5, g_red + lb_red + ub_red + nclb + ncub + S.RA[(lane & 15) * LDJ + 1] + Cm[(lane & 15) * CSC + 1]);
-  QpResult res = qp_core<NR, SmemC, CSC>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, A.dbg_stop);
+  QpResult res = qp_core<NR, SmemC, CSC>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, DBG_STOP_ARG);
   res.iters += nl;
   // ---- x = Z y
   WSYNC();
@@ -2273,8 +2281,10 @@ __global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, cons
   // ---- every global read of the wave is issued here, before the FK (one memory round trip instead of a chain of them)
   // config = [current base xyz, base_config (IMU quaternion), new joint angles]  (:388-389)
   const int nq = M.nq;
+  const bool warm = A.mode == WBC_ROLLOUT_WARMUP;   // updateState(new_config, feedback=False, running=False): the state is q_next as it is
   double c = 0.0;
-  if (lane < 3) c = A.q_cur[(size_t)b * NQ + lane];
+  if (warm) { if (lane < nq) c = A.q_next[(size_t)b * NQ + lane]; }
+  else if (lane < 3) c = A.q_cur[(size_t)b * NQ + lane];
   else if (lane < 7) c = A.imu ? A.imu[(size_t)b * 4 + (lane - 3)] : A.q_next[(size_t)b * NQ + lane];
   else if (lane < nq) c = A.q_next[(size_t)b * NQ + lane];
   const double ft = (lane < 12) ? A.foot_targets[(size_t)b * 15 + lane] : 0.0;
@@ -2311,6 +2321,7 @@ __global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, cons
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r) base[r] = WPA[r] - (Pt[r] * BPA[0] + Pt[3 + r] * BPA[1] + Pt[6 + r] * BPA[2]);
+  if (warm) { base[0] = U.q[0]; base[1] = U.q[1]; base[2] = U.q[2]; }   // no estimator while warming up (running == False, :414)
   if (lane < NQ) A.q_new[(size_t)b * NQ + lane] = (lane == 0) ? base[0] : (lane == 1) ? base[1] : (lane == 2) ? base[2] : c;
   if (A.grip_trace && lane < 3) {
     // gripper_bar after the base correction: the whole tree translates rigidly with the base

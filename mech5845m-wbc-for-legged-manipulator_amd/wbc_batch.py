@@ -249,8 +249,9 @@ class WbcBatch:
                                           P(x, f, keep), P(st, np.int32, keep), P(it, np.int32, keep), self._stream(mem)), self.lib)
         return x, st, it
 
-    def qp_solve_ls(self, A, b, C_=None, lb=None, ub=None, Clb=None, Cub=None, use_mfma=False, want_Hg=False):
-        """Batched QP(A, b, ...).solveQP(): H = A'A and g = -A'b are formed on the device (QP_Wrapper.py:17-18)."""
+    def qp_solve_ls(self, A, b, C_=None, lb=None, ub=None, Clb=None, Cub=None, use_mfma=None, want_Hg=False):
+        """Batched QP(A, b, ...).solveQP(): H = A'A and g = -A'b are formed on the device (QP_Wrapper.py:17-18);
+        use_mfma: True / False, None = matrix cores from WBC_MFMA_AUTO_ROWS rows of A on."""
         keep = []
         mem = _mem_of([A, b, C_, lb, ub, Clb, Cub])
         if len(A.shape) != 3:
@@ -267,7 +268,7 @@ class WbcBatch:
         capi.check(self.lib.wbc_qp_solve_ls(self._h, B, m, n, p, P(A, f, keep), P(b, f, keep, B, m, "b"), P(C_, f, keep, B, p * n, "C"),
                                              P(lb, f, keep, B, n, "lb"), P(ub, f, keep, B, n, "ub"), P(Clb, f, keep, B, p, "Clb"),
                                              P(Cub, f, keep, B, p, "Cub"), mem,
-                                             int(bool(use_mfma)), P(x, f, keep), P(st, np.int32, keep), P(it, np.int32, keep),
+                                             -1 if use_mfma is None else int(bool(use_mfma)), P(x, f, keep), P(st, np.int32, keep), P(it, np.int32, keep),
                                              P(Ho, f, keep), P(go, f, keep), self._stream(mem)), self.lib)
         return (x, st, it, Ho, go) if want_Hg else (x, st, it)
 
@@ -298,9 +299,13 @@ class WbcBatch:
                                               P(qn, f, keep), self._stream(mem)), self.lib)
         return qn
 
-    def rollout(self, inputs, dt, ticks, ee_target_step=None, trunk_target_step=None, imu=None, want_trace=True, warm_start=None):
+    def rollout(self, inputs, dt, ticks, ee_target_step=None, trunk_target_step=None, imu=None, want_trace=True,
+                mode=capi.ROLLOUT_RUNNING, hold_ticks=0):
         """K closed-loop ticks on the device: tick -> update_state -> reference-state side effects ->
-        targets advance by their step. Returns dict(q, qdot, ee_target, status, iters[, grip_trace [K,B,3]])."""
+        targets advance by their step; then `hold_ticks` more ticks with the targets held. mode: ROLLOUT_RUNNING
+        (updateState(running=True): IMU fed back, base re-estimated from the stance feet) or ROLLOUT_WARMUP
+        (updateState(running=False), the loop of setInitialState). Returns dict(q, qdot, ee_target, status, iters[,
+        grip_trace [K + hold, B, 3]])."""
         keep = []
         extra = [ee_target_step, trunk_target_step, imu]
         mem = _mem_of(list(inputs.values()) + extra)
@@ -309,9 +314,9 @@ class WbcBatch:
         out = dict(q=self._alloc(q, (B, NQS)), qdot=self._alloc(q, (B, NV)), ee_target=self._alloc(q, (B, 5, 3)),
                    status=self._alloc(q, (B,), np.int32), iters=self._alloc(q, (B,), np.int32))
         if want_trace:
-            out["grip_trace"] = self._alloc(q, (int(ticks), B, 3))
+            out["grip_trace"] = self._alloc(q, (int(ticks) + int(hold_ticks), B, 3))
         r = capi.WbcRollout()
-        r.ticks = int(ticks)
+        r.ticks, r.mode, r.hold_ticks = int(ticks), int(mode), int(hold_ticks)
         f = np.float64
         P = self._p
         r.ee_target_step, r.trunk_target_step, r.imu = (P(ee_target_step, f, keep, B, 15, "ee_target_step"),
@@ -335,3 +340,47 @@ class WbcBatch:
         capi.check(self.lib.wbc_integrate(self._h, B, P(q, f, keep), P(v, f, keep, B, NV, "v"), P(model_id, np.int32, keep, B, 1, "model_id"),
                                            float(dt), mem, P(qn, f, keep), self._stream(mem)), self.lib)
         return qn
+
+    # ---- setInitialState for B robots
+    def warm_up(self, q0, model_id=None, dt=0.002, ticks_per_segment=1000, foot_radius=0.0, configure=True):
+        """``RobotModel.setInitialState`` (reference Robot_Wrapper4.py:196-351) for every instance of a batch: from q0 [B,27]
+        (the reference starts from pin.neutral with the joints clamped to their upper limits, :199-208) the six Cartesian
+        tasks + Tikhonov posture drag the feet and the gripper along straight lines to the crouched stance — 2 x
+        ticks_per_segment bounds-only QPs per robot, ONE wbc_rollout call (mode WARMUP) for the whole batch — then the base
+        orientation is reset and the trunk height set from the foot heights (:328-338).
+        configure=True puts the warm-up's own switch set on the handle (setTasks(all True), no constraints, default weights: :272)
+        and leaves it there. Host arrays in, dict(q [B,27], status, iters, start, goal) out."""
+        import wbc_model
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        B = self._batch_of(q0, "q0")
+        mid = None if model_id is None else np.ascontiguousarray(model_id, dtype=np.int32)
+        if configure:
+            for i, m in enumerate(self.models):
+                self.configure(wbc_model.make_config(m, Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=True), i)
+        f = self.fk(q0, mid, want=("oMf",))["oMf"]                        # updateState(q, feedback=False), :211
+        pos, rot = f[:, :, 9:12], f[:, :, 0:9]
+        ee, trunk = pos[:, capi.FR_EE0:capi.FR_EE0 + 5].copy(), pos[:, capi.FR_TRUNK].copy()
+        Rt = rot[:, capi.FR_TRUNK].reshape(B, 3, 3)
+        Ree = rot[:, capi.FR_EE0:capi.FR_EE0 + 5].reshape(B, 5, 3, 3)
+        goal = ee.copy()                                                   # :238-262
+        goal[:, :4, 0] = pos[:, capi.FR_HIP0:capi.FR_HIP0 + 4, 0]          # feet under their hips ...
+        goal[:, :4, 2] *= 0.9                                              # ... and 10 % closer to the trunk (multiplier_F / _R)
+        goal[:, 4, 2] = pos[:, capi.FR_HIP0 + 4, 2]                        # gripper: height of the arm base joint (waist), x of the FR hip,
+        goal[:, 4, 0] = pos[:, capi.FR_HIP0, 0]
+        goal[:, 4, 0] *= 1.1                                               # multiplier_G = diag(1.1, 1, 1.5)
+        goal[:, 4, 2] *= 1.5
+        n = int(ticks_per_segment)
+        d = dict(q=q0, ee_target=ee, prev_ee_target=ee.copy(), trunk_target=trunk, prev_trunk_target=trunk.copy(),
+                 ee_ref_rot=Ree.reshape(B, 5, 9).copy(),                   # R* = from_euler(as_euler(R_EE)) = R_EE (:222-226)
+                 ee_prev_rot=np.einsum("bji,bejk->beik", Rt, Ree).reshape(B, 5, 9),     # prev_EE_CoM_rot = R_trunk' R_EE (:219)
+                 trunk_ref_euler=np.stack([np.arctan2(Rt[:, 2, 1], Rt[:, 2, 2]), -np.arcsin(np.clip(Rt[:, 2, 0], -1, 1)),
+                                           np.arctan2(Rt[:, 1, 0], Rt[:, 0, 0])], axis=1),
+                 trunk_prev_rot=np.zeros((B, 9)))                          # old_ref_trunk_rot_matrix = zeros before initialiseWBC (:150)
+        if mid is not None:
+            d["model_id"] = mid
+        ro = self.rollout(d, dt, n, ee_target_step=(goal - ee) / n, want_trace=False, mode=capi.ROLLOUT_WARMUP, hold_ticks=n)
+        q = ro["q"].copy()
+        q[:, 3:6] = 0.0                                                    # "reset base orientation" (:328-330): x, y, z of the quaternion
+        feet_z = self.fk(q, mid, want=("oMf",))["oMf"][:, capi.FR_EE0:capi.FR_EE0 + 4, 11]
+        q[:, 2] = -feet_z.mean(axis=1) + foot_radius                       # :336-337
+        return dict(q=q, status=ro["status"], iters=ro["iters"], start=ee, goal=goal)

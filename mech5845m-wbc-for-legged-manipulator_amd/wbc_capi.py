@@ -73,10 +73,13 @@ class WbcTickOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("qdot", "status", "iters", "q_next")]
 
 
+ROLLOUT_RUNNING, ROLLOUT_WARMUP = 0, 1
+
+
 class WbcRollout(C.Structure):
-    _fields_ = [("ticks", C.c_int32), ("pad_", C.c_int32)] + [(n, C.c_void_p) for n in (
+    _fields_ = [("ticks", C.c_int32), ("mode", C.c_int32)] + [(n, C.c_void_p) for n in (
         "ee_target_step", "trunk_target_step", "imu", "q_final", "qdot_last", "ee_target_final", "grip_trace",
-        "status_max", "iters_sum")]
+        "status_max", "iters_sum")] + [("hold_ticks", C.c_int32), ("pad_", C.c_int32)]
 
 
 class WbcFkOut(C.Structure):

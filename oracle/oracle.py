@@ -183,9 +183,12 @@ def update_state(models, q_cur, q_next, foot_targets, imu=None, model_id=None):
     return out
 
 
-def rollout(models, cfgs, tick_in_kw, dt, B, ticks, ee_target_step=None, trunk_target_step=None, imu=None, nthreads=1):
+def rollout(models, cfgs, tick_in_kw, dt, B, ticks, ee_target_step=None, trunk_target_step=None, imu=None, nthreads=1,
+            running=True, ee_target_at=None):
     """K closed-loop ticks on the CPU: tick -> update_state -> the reference-state side effects of qpb()
     (calcTargetVelEE3 :1151-1152, calcTargetVelTrunk2 :995-996) -> targets advance by their per-tick step.
+    running=False: updateState(new_config, feedback=False, running=False) as in setInitialState's loop (:326, :440-447) — the
+    integrated configuration is the new state. ee_target_at(k): the EE targets of tick k (instead of the accumulated steps).
     Returns dict(q, qdot, status (max over ticks), iters (sum), ee_target, prev_ee_target, grip_trace [K,B,3])."""
     d = {k: np.array(v, copy=True) for k, v in tick_in_kw.items()}
     mid = d.get("model_id")
@@ -194,10 +197,12 @@ def rollout(models, cfgs, tick_in_kw, dt, B, ticks, ee_target_step=None, trunk_t
     trace = np.zeros((ticks, B, 3))
     out = None
     for k in range(ticks):
+        if ee_target_at is not None:
+            d["ee_target"] = np.asarray(ee_target_at(k), dtype=np.float64).reshape(d["ee_target"].shape)
         out = tick(models, cfgs, d, dt, B, nthreads=nthreads, want_q_next=True)
         status = np.maximum(status, out["status"])
         iters += out["iters"]
-        d["q"] = update_state(models, d["q"], out["q_next"], d["ee_target"], imu, mid)
+        d["q"] = update_state(models, d["q"], out["q_next"], d["ee_target"], imu, mid) if running else out["q_next"]
         trace[k] = fk(models, d["q"], mid, want_com=False)["oMf"][:, capi.FR_EE0 + 4, 9:]
         for i, c in enumerate(cfgs):
             sel = slice(None) if mid is None else (mid == i)
@@ -216,6 +221,56 @@ def rollout(models, cfgs, tick_in_kw, dt, B, ticks, ee_target_step=None, trunk_t
             d["trunk_target"] = d["trunk_target"] + np.asarray(trunk_target_step).reshape(d["trunk_target"].shape)
     return dict(q=d["q"], qdot=out["qdot"], status=status, iters=iters, ee_target=d["ee_target"],
                 prev_ee_target=d["prev_ee_target"], grip_trace=trace)
+
+
+def warmup(models, q0, dt=0.002, ticks_per_segment=1000, foot_radius=0.0, model_id=None, nthreads=1):
+    """RobotModel.setInitialState (Robot_Wrapper4.py:196-351) restated on the oracle's tick / fk, for B robots:
+    updateState(q0) (:211) -> previous / default states (:214-226) -> start = current EE positions, goal milestones (:238-262:
+    feet under their hips at 0.9 of the height, gripper at (1.1 x FR-hip x, y, 1.5 x arm-base z)) -> setTasks(all True), no
+    constraints, default weights (:272) -> for i in np.arange(0, 2, 1 / ticks_per_segment): targets = klampt piecewise-linear
+    eval(i) (clamped at the last milestone), bounds-only QP, q = pin.integrate(q, qdot dt), updateState(running=False)
+    (:278-326) -> quaternion x, y, z = 0 (:328-330) -> z = -mean(foot z) + foot_radius (:336-337).
+    Returns dict(q [B,27], status, iters, start, goal)."""
+    import wbc_model
+    q0 = _f64(q0).reshape(-1, NQS)
+    B = q0.shape[0]
+    mid = None if model_id is None else np.ascontiguousarray(model_id, dtype=np.int32)
+    cfgs = [wbc_model.make_config(m, Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=True) for m in models]
+    f = fk(models, q0, mid, want_com=False)["oMf"]
+    pos, rot = f[:, :, 9:12], f[:, :, 0:9]
+    ee, trunk = pos[:, capi.FR_EE0:capi.FR_EE0 + 5].copy(), pos[:, capi.FR_TRUNK].copy()
+    Rt = rot[:, capi.FR_TRUNK].reshape(B, 3, 3)
+    Ree = rot[:, capi.FR_EE0:capi.FR_EE0 + 5].reshape(B, 5, 3, 3)
+    goal = ee.copy()
+    for i in range(4):
+        p2 = ee[:, i].copy()
+        p2[:, 0] = pos[:, capi.FR_HIP0 + i, 0]
+        goal[:, i] = p2 @ np.diag([1.0, 1.0, 0.9])
+    g2 = ee[:, 4].copy()
+    g2[:, 2] = pos[:, capi.FR_HIP0 + 4, 2]                 # oMi[arm_base_id] (the waist joint)
+    g2[:, 0] = pos[:, capi.FR_HIP0, 0]                     # oMi[FR_hip_joint]
+    goal[:, 4] = g2 @ np.diag([1.1, 1.0, 1.5])
+    from scipy.spatial.transform import Rotation as R
+    d = dict(q=q0, ee_target=ee, prev_ee_target=ee.copy(), trunk_target=trunk, prev_trunk_target=trunk.copy(),
+             ee_ref_rot=R.from_euler("xyz", R.from_matrix(Ree.reshape(-1, 3, 3)).as_euler("xyz")).as_matrix().reshape(B, 5, 9),
+             ee_prev_rot=np.einsum("bji,bejk->beik", Rt, Ree).reshape(B, 5, 9),
+             trunk_ref_euler=R.from_matrix(Rt).as_euler("xyz").reshape(B, 3), trunk_prev_rot=np.zeros((B, 9)))
+    if mid is not None:
+        d["model_id"] = mid
+    n = int(ticks_per_segment)
+    grid = np.arange(0, 2, 1.0 / n)
+
+    def ee_at(k):                                          # klampt Trajectory(milestones=[start, goal]).eval(i)
+        i = grid[k]
+        if i >= 1.0:
+            return goal
+        return (1.0 - i) * ee + i * goal
+    ro = rollout(models, cfgs, d, dt, B, len(grid), nthreads=nthreads, running=False, ee_target_at=ee_at)
+    q = ro["q"].copy()
+    q[:, 3:6] = 0.0
+    feet_z = fk(models, q, mid, want_com=False)["oMf"][:, capi.FR_EE0:capi.FR_EE0 + 4, 11]
+    q[:, 2] = -feet_z.mean(axis=1) + foot_radius
+    return dict(q=q, status=ro["status"], iters=ro["iters"], start=ee, goal=goal)
 
 
 def integrate(models, q, v, dt, model_id=None):

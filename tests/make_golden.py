@@ -119,7 +119,39 @@ def make_qp_cases():
     print("qp_cases", dict(zip(names, st.tolist())), it.tolist())
 
 
+def warmup_q0(models, mid, seed):
+    """start configurations for the warm-up: the reference's own (pin.neutral with every entry above its upper limit clamped,
+    Robot_Wrapper4.py:199-208 — that bends the knees: the calf's upper limit is negative) for instance 0 of each model,
+    perturbed arm / leg angles for the others."""
+    rng = np.random.default_rng(seed)
+    q0 = np.zeros((len(mid), 27))
+    for b, i in enumerate(mid):
+        m = models[i]
+        q = m.neutral()
+        for k in range(m.nv):
+            if q[k] > m.q_hi[k]:
+                q[k] = m.q_hi[k]
+        if b >= len(models):
+            q[7:m.nq - 3] += rng.normal(0, 0.05, m.nq - 10)
+        q0[b] = q
+    return q0
+
+
+def make_warmup():
+    """setInitialState: start configurations and the oracle's warmed-up state, both morphologies."""
+    models = list(common.models())
+    mid = np.array([0, 1, 0, 1, 0, 1], dtype=np.int32)
+    q0 = warmup_q0(models, mid, 13)
+    out = oracle.warmup(models, q0, DT, 1000, foot_radius=0.02, model_id=mid, nthreads=4)
+    np.savez_compressed(os.path.join(HERE, "golden", "warmup_mixed.npz"), q0=q0, model_id=mid, foot_radius=0.02, ticks_per_segment=1000,
+                        **{"out_" + k: v for k, v in out.items()})
+    print("warmup_mixed status", out["status"].tolist(), "iters", out["iters"].tolist())
+
+
 if __name__ == "__main__":
+    make_warmup()
+    if len(sys.argv) > 1 and sys.argv[1] == "warmup":
+        sys.exit(0)
     make_kinematics()
     make_qp_cases()
     make("tick_c3_hybrid", "c3_hybrid", 8, 7)

@@ -113,6 +113,26 @@ def test_robot_model_warm_up_reaches_the_crouched_stance(robot):
     assert rm.EE_frame_pos[4][2] - q[2] > 0.15
 
 
+def test_robot_model_warm_up_is_the_oracles_warm_up():
+    """RobotModel.setInitialState is the B = 1 call of the batched device warm-up: the state a fresh object ends up in is the
+    oracle's restatement of Robot_Wrapper4.py:196-351 from the same clamped neutral pose (not just a plausible stance)."""
+    from Robot_Wrapper4 import RobotModel
+    r = wbc_model.A1_ROLES
+    rm = RobotModel("/any/where/a1_wx200.urdf", "/unused/meshes", r["EE_frame_names"], r["EE_joint_names"], r["G_base"],
+                    r["imu"], "FR_hip_joint", r["hip_waist_joint_names"], foot_offset=True)
+    wx = rm._model
+    q0 = wx.neutral()
+    for i in range(wx.nv):
+        if q0[i] > wx.q_hi[i]:
+            q0[i] = wx.q_hi[i]
+    ref = oracle.warmup([wx], q0[None], 0.002, 1000, foot_radius=0.02, nthreads=4)
+    assert ref["status"][0] == 0 and rm.solver_status == 0
+    assert np.abs(rm.current_joint_config - ref["q"][0]).max() < 1e-6
+    assert np.abs(np.array(rm.FL_leg) - ref["q"][0, 7:10]).max() < 1e-6
+    # the reference state the loop leaves behind: targets at their last milestones
+    assert np.abs(np.array(rm.FR_target_cartesian_pos).reshape(3) - ref["goal"][0, 0]).max() < 1e-12
+
+
 def test_robot_model_tick_matches_oracle(robot):
     """sim3's call sequence (sim3.py:145-148, 197, 269, 314) on the mirror; every quantity re-derived by the oracle."""
     rm = robot

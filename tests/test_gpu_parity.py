@@ -895,3 +895,55 @@ def test_mixed_morphology_full_size_properties(wx200, px100):
     good = ref["status"] == 0
     assert np.abs(ref["qdot"] - x[idx])[good].max() < QDOT_TOL
     bt.close()
+
+
+def test_batched_warm_up_matches_the_oracle(wx200, px100):
+    """setInitialState (Robot_Wrapper4.py:196-351) for a mixed batch in ONE wbc_rollout call
+    (mode WBC_ROLLOUT_WARMUP, 1000 moving + 1000 held ticks = 2000 bounds-only QPs per robot) against oracle.warmup and
+    against the committed fixture. State tolerance as in test_rollout_parity (targets accumulate by steps on the device,
+    the oracle evaluates the reference's piecewise-linear interpolation: ~1e-13 apart per tick)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "warmup_mixed.npz"))
+    models = [wx200, px100]
+    q0, mid, fr = z["q0"], z["model_id"], float(z["foot_radius"])
+    B = q0.shape[0]
+    bt = WbcBatch(models, B)
+    got = bt.warm_up(q0, mid, DT, int(z["ticks_per_segment"]), foot_radius=fr)
+    assert (got["status"] == z["out_status"]).all() and (got["status"] == 0).all()
+    assert np.abs(got["q"] - z["out_q"]).max() < 1e-6
+    assert np.abs(got["goal"] - z["out_goal"]).max() < 1e-12 and np.abs(got["start"] - z["out_start"]).max() < 1e-12
+    # a short warm-up straight against the oracle (fresh, not from the fixture)
+    ref = oracle.warmup(models, q0, DT, 50, foot_radius=fr, model_id=mid, nthreads=8)
+    short = bt.warm_up(q0, mid, DT, 50, foot_radius=fr)
+    assert (short["status"] == ref["status"]).all()
+    assert np.abs(short["q"] - ref["q"]).max() < 1e-6
+    assert abs(int(short["iters"].sum()) - int(ref["iters"].sum())) <= 4 * B
+    bt.close()
+
+
+def test_rollout_warmup_mode_is_tick_plus_integrate(wx200):
+    """WBC_ROLLOUT_WARMUP = updateState(new_config, feedback=False, running=False): the integrated configuration is the next
+    state, bit for bit what chaining wbc_tick (+ q_next) from the host gives; hold_ticks keeps the targets in place."""
+    B, K, Hd = 32, 3, 2
+    cfg = common.config("full", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=47, with_rot=True)
+    step = np.zeros((B, 5, 3))
+    step[:, :, 2] = -1e-4
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    got = bt.rollout(d, DT, K, ee_target_step=step, mode=capi.ROLLOUT_WARMUP, hold_ticks=Hd)
+    assert got["grip_trace"].shape == (K + Hd, B, 3)
+    s = {k: v.copy() for k, v in d.items()}
+    for k in range(K + Hd):
+        o = bt.tick(s, DT, want_q_next=True)
+        s["q"] = o["q_next"]
+        s["prev_ee_target"] = s["ee_target"].copy()
+        s["ee_prev_rot"] = s["ee_ref_rot"].copy()
+        s["prev_trunk_target"] = s["trunk_target"].copy()
+        from scipy.spatial.transform import Rotation as R
+        s["trunk_prev_rot"] = R.from_euler("xyz", s["trunk_ref_euler"]).as_matrix().reshape(B, 9)
+        if k < K:
+            s["ee_target"] = s["ee_target"] + step
+    assert np.abs(got["q"] - s["q"]).max() < 1e-12 and (got["ee_target"] == s["ee_target"]).all()
+    assert np.abs(got["ee_target"] - (d["ee_target"] + K * step)).max() < 1e-15
+    bt.close()

@@ -99,3 +99,33 @@ def test_rollout_follows_a_moving_target(wx, monkeypatch):
     # along the segment's direction
     travel = (out["grip_trace"][-1] - start) @ (step[0, 4] / np.linalg.norm(step[0, 4]))
     assert (travel > 0.3 * np.linalg.norm((K - 1) * step[0, 4])).all(), travel
+
+
+def test_warmup_reaches_the_crouched_stance_and_matches_its_fixture():
+    """oracle.warmup = setInitialState (Robot_Wrapper4.py:196-351) for B robots: from the clamped neutral pose the feet end
+    under their hips at 0.9 of their height and the gripper at its milestone (the straight-line trajectories are followed),
+    the base quaternion's x, y, z are reset, the trunk height is -mean(foot z) + foot radius; and the committed fixture
+    (tests/golden/warmup_mixed.npz, written by make_golden.py) is reproduced."""
+    import os
+    import make_golden
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "warmup_mixed.npz"))
+    models = list(common.models())
+    mid = z["model_id"]
+    assert np.array_equal(make_golden.warmup_q0(models, mid, 13), z["q0"])
+    sel = [0, 1, 2]                                  # the reference's own start pose of both robots + one perturbed
+    out = oracle.warmup(models, z["q0"][sel], DT, 1000, foot_radius=float(z["foot_radius"]), model_id=mid[sel], nthreads=4)
+    assert (out["status"] == 0).all()
+    assert np.abs(out["q"] - z["out_q"][sel]).max() < 1e-9
+    q = out["q"]
+    assert (q[:, 3:6] == 0).all() and (q[:, 6] > 0.99).all()
+    f = oracle.fk(models, q, mid[sel], want_com=False)["oMf"]
+    feet, hips = f[:, capi.FR_EE0:capi.FR_EE0 + 4, 9:], f[:, capi.FR_HIP0:capi.FR_HIP0 + 4, 9:]
+    assert np.abs(feet[:2, :, 2] - 0.02).max() < 2e-3                    # from the symmetric start pose the feet stand level on z = foot radius
+    # (:336-337 SETS z to -mean(foot z) + radius, where foot z still contains the base height the warm-up drifted to (~0.2 mm):
+    #  the mean foot height ends that much above the radius — the reference's arithmetic, reproduced)
+    assert np.abs(feet[:, :, 2].mean(axis=1) - 0.02).max() < 1e-3
+    assert np.abs(feet[:2, :, 0] - hips[:2, :, 0]).max() < 5e-3          # under their hips
+    assert (q[:, 9] < -1.2).all() and (q[:, 8] > 0.5).all()              # knees bent: the crouch
+    assert 0.25 < q[0, 2] < 0.33
+    # milestones as the reference builds them (:238-262)
+    assert np.allclose(out["goal"][:, :4, 2], 0.9 * out["start"][:, :4, 2]) and np.allclose(out["goal"][:, 4, 1], out["start"][:, 4, 1])

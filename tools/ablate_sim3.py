@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Where the sim3 tick kernel's time goes, measured on the SHIPPED build by ablation (option "dbg_stop", include/wbc.h): the
-kernel is cut after stage k and timed; stage k costs T(k) - T(k - 1). No stamps, no atomics, same occupancy and code
-placement as the product (one uniform compare per stage).
+"""Where the sim3 tick kernel's time goes, by ablation (option "dbg_stop" of the -DWBC_ABLATE build, include/wbc.h): the
+kernel is cut after stage k and timed; stage k costs T(k) - T(k - 1). No stamps, no atomics, same occupancy as the product;
+the cut points cost this build 24 spilled VGPRs (its whole tick is ~6 % slower than the shipped kernel's): read shares.
     python3 tools/ablate_sim3.py [B] [closed]     closed: states after a 10-tick roll-out instead of the seeded ones"""
-import json, os, sys
+import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "mech5845m-wbc-for-legged-manipulator_amd"))
+PKG = os.path.join(ROOT, "mech5845m-wbc-for-legged-manipulator_amd")
+sys.path.insert(0, PKG)
+subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "csrc"), "ablate"])      # the -DWBC_ABLATE build of the library
+os.environ["WBC_HIP_LIB"] = os.path.join(PKG, "csrc", "build", "libwbc_hip_ablate.so")
 import numpy as np, torch
 import wbc_model, wbc_workload
 from wbc_batch import WbcBatch
