@@ -54,7 +54,7 @@ def build_robot(robot, posture):
     return rm
 
 
-def replay(rm, batch=1, segments=3, ticks=500, offsets=None, want_trace=True, robot="a1_wx200"):
+def replay(rm, batch=1, segments=3, ticks=500, offsets=None, want_trace=True, robot="a1_wx200", sim3_kernel=1):
     """Walk the first `segments` segments of the milestone trajectory for `batch` instances; returns
     dict(time, target [K,3], real [K,3], status [batch], iters [batch], q [batch,27], seconds)."""
     from wbc_batch import WbcBatch
@@ -62,6 +62,7 @@ def replay(rm, batch=1, segments=3, ticks=500, offsets=None, want_trace=True, ro
     cfg = rm._config()
     bt = WbcBatch(model, batch)
     bt.configure(cfg)
+    bt.set_option("sim3_kernel", int(sim3_kernel))      # 0: the kernel RobotModel.runWBC's ticks run on (it passes orientation references)
     start = np.asarray(rm.prev_EE_pos[4], dtype=float).reshape(3)            # sim3.py:203: the trajectory starts where the gripper is
     pts = [start] + [np.array(m, dtype=float) for m in MILESTONES[robot]]
     EE_target = [np.asarray(rm.prev_EE_pos[i], dtype=float).reshape(3, 1) for i in range(5)]
