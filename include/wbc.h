@@ -146,6 +146,11 @@ typedef struct WbcTickIn {
                                                 WBC_JOINT_CUSTOM; for MANI/HYBRID NULL => computed by the library (wbc_posture_target) */
   const double* q_con;             /* [B][27]   configuration seen by findConstraints, velDamperJointConstraints and integrate when it
                                                 differs from q (the state qpJointb MANI/HYBRID leaves behind); NULL => q          */
+  const uint64_t* working_set;     /* [B][2]    warm start = what solveQPHotstart keeps between ticks (QP_Wrapper.py:55-73, the qpOASES
+                                                object's working set): WbcTickOut.working_set of the previous tick. Word 0: velocity
+                                                bounds (bit d: DoF d at its lower bound, bit 32 + d: at its upper bound); word 1:
+                                                constraint rows in findConstraints' order (bit i: row i at Clb, bit 32 + i: at Cub).
+                                                Any bit pattern is safe (wrong guesses are dropped again); NULL or zeros => cold start */
 } WbcTickIn;
 
 #define WBC_Q_STRIDE 27   /* doubles per instance in q / q_next (nq of the largest model)           */
@@ -170,6 +175,8 @@ typedef struct WbcTickOut {
   int32_t* status;  /* [B] WBC_QP_*                                                       */
   int32_t* iters;   /* [B] working-set changes (may be NULL)                              */
   double* q_next;   /* [B][27] pin.integrate(q, qdot*dt) (may be NULL)                    */
+  uint64_t* working_set; /* [B][2] the inequality constraints active at the solution, format of WbcTickIn.working_set (may be
+                            NULL; may alias the input); zeros for an instance whose QP was not solved */
 } WbcTickOut;
 
 /* forward-kinematics outputs of updateState (all optional). In a handle with several models the per-instance strides of
@@ -293,6 +300,9 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          instances whose leg blocks it could not eliminate); 0: the general kernel does the elimination.
  *   "presolve_tol_exp" [7] a stance-leg 3 x 3 block K with |det K| <= 10^-value (sum |K_ij|)^3 is treated as singular
  *                          (0: every block, i.e. the fallback for singular blocks is forced on every instance).
+ *   "warm_start"       [1] wbc_rollout carries every instance's final working set into its next tick (the hot start the
+ *                          reference gets from QP.solveQPHotstart, Robot_Wrapper4.py:1389-1394); 0: every tick starts cold.
+ *                          (wbc_tick is warm exactly when WbcTickIn.working_set is passed.)
  *   "grid"                 workgroups of the grid-stride kernels (wbc_qp_solve*, wbc_integrate); default = what fills the chip.
  *   "dbg_alias_inputs" [0] diagnostic: every instance reads instance 0's inputs (isolates input latency in timings).
  *   "dbg_stop"         [0] diagnostic: the sim3 kernel stops after stage k (1..7, see wbc_kernels.hip) — outputs are garbage,

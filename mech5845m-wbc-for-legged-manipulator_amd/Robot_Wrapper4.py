@@ -176,6 +176,8 @@ class RobotModel:
         self.prev_EE_CoM_rot = [0, 0, 0, 0, 0]
         self.EE_A_list, self.EE_b_list = [0] * 5, [0] * 5
         self.firstQP = True
+        self.hotstart = True               # runWBC's QPs after the first are warm-started, as the reference's are (:1389-1394)
+        self._working_set = None
         self.qp = None
         self.solver_status, self.solver_iters = None, None
         self.q_vel = None
@@ -469,7 +471,11 @@ class RobotModel:
 
     def _solve_tick(self, cfg, target_EE, target_trunk):
         self._bt.configure(cfg)
-        out = self._bt.tick(self._tick_inputs(target_EE, target_trunk), self.dt, want_q_next=True)
+        inp = self._tick_inputs(target_EE, target_trunk)
+        if self.hotstart and not self.firstQP and self._working_set is not None:
+            inp["working_set"] = self._working_set        # solveQPHotstart (reference :1392-1394): the previous tick's working set seeds this one
+        out = self._bt.tick(inp, self.dt, want_q_next=True, want_working_set=True)
+        self._working_set = out["working_set"]
         self.solver_status, self.solver_iters = int(out["status"][0]), int(out["iters"][0])
         if self.solver_status != 0 and getattr(self, "q_vel", None) is not None:
             # an unsolved QP leaves qpOASES' xOpt at the previous tick's answer (QP_Wrapper.py:71-73): the reference keeps

@@ -46,6 +46,7 @@ struct WbcBatch {
   int sim3_kernel;       // 1 (default): batches that qualify run on wbc_tick_sim3_kernel (compact LDS) + a deferred pass
   int32_t* d_status;     // status buffer of our own when the caller passes none (the deferred pass needs one)
   int dbg_alias, dbg_stop;
+  int warm_start;        // 1 (default): wbc_rollout carries each instance's working set from tick to tick
   int32_t* d_defer;      // [1 + max_batch]: count + compact list of the instances the sim3 kernel deferred (lazy)
   int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass)
   int max_nj, max_nf;    // FK output strides: the largest model's joint / frame counts
@@ -143,7 +144,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
   b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
-  b->jtj_mfma = -1;
+  b->jtj_mfma = -1; b->warm_start = 1;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
@@ -320,6 +321,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!strcmp(name, "presolve_tol_exp")) { double t = 1.0; for (int i = 0; i < value; ++i) t *= 0.1; b->sing_tol = t; return WBC_OK; }
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
   if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
+  if (!strcmp(name, "warm_start")) { b->warm_start = value != 0; return WBC_OK; }
   if (!strcmp(name, "dbg_stop")) {
 #ifdef WBC_ABLATE
     b->dbg_stop = value; return WBC_OK;
@@ -432,6 +434,7 @@ static void stage_tick_in(Stager& st, WbcTickIn& in, int B, const WbcBatch* b) {
   st.in(&in.com_target, n * 3); st.in(&in.com_target_vel, n * 3);
   st.in(&in.model_id, n);
   st.in(&in.posture_u, n * WBC_V_STRIDE); st.in(&in.q_con, n * WBC_Q_STRIDE);
+  st.in(&in.working_set, n * 2);
   (void)b;
 }
 
@@ -590,7 +593,9 @@ extern "C" int wbc_tick(WbcBatch* b, int B, const WbcTickIn* in, double dt, int 
   stage_tick_in(st, a.in, B, b);
   const size_t n = (size_t)B;
   st.out(&a.out.qdot, n * WBC_V_STRIDE); st.out(&a.out.status, n); st.out(&a.out.iters, n); st.out(&a.out.q_next, n * WBC_Q_STRIDE);
+  st.out(&a.out.working_set, n * 2);
   if ((rc = st.stage())) return rc;
+  a.ws_in = (const unsigned long long*)a.in.working_set; a.ws_out = (unsigned long long*)a.out.working_set;
   if ((rc = auto_posture(b, a, B, stream))) return rc;
   if ((rc = launch_tick_auto(b, a, B, stream))) return rc;
   return st.finish();
@@ -648,11 +653,12 @@ extern "C" int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, 
   const size_t n = (size_t)B, NB = (size_t)b->max_batch;
   // workspace layout (doubles per instance), then two int32 per instance
   enum { O_Q = 0, O_QN = 27, O_QD = 54, O_EET = 80, O_EEP = 95, O_TT = 110, O_TP = 113, O_EPR = 116, O_TPR = 161, O_END = 170 };
-  if (!b->d_roll) HIP_TRY(hipMalloc(&b->d_roll, NB * (O_END * sizeof(double) + 2 * sizeof(int32_t))));
+  if (!b->d_roll) HIP_TRY(hipMalloc(&b->d_roll, NB * (O_END * sizeof(double) + 2 * sizeof(int32_t) + 2 * sizeof(unsigned long long))));
   double* W = (double*)b->d_roll;
   auto blk = [&](int off) { return W + NB * (size_t)off; };
   int32_t* w_status = (int32_t*)(W + NB * O_END);
   int32_t* w_iters = w_status + NB;
+  unsigned long long* w_ws = (unsigned long long*)(w_iters + NB);     // [NB][2] working sets carried from tick to tick (8-byte aligned)
 
   KernelArgs a;
   fill_args(a, b, B, dt);
@@ -672,6 +678,11 @@ extern "C" int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, 
   if ((rc = seed(O_Q, a.in.q, 27)) || (rc = seed(O_EET, a.in.ee_target, 15)) || (rc = seed(O_EEP, a.in.prev_ee_target, 15)) ||
       (rc = seed(O_TT, a.in.trunk_target, 3)) || (rc = seed(O_TP, a.in.prev_trunk_target, 3)) ||
       (rc = seed(O_EPR, a.in.ee_prev_rot, 45)) || (rc = seed(O_TPR, a.in.trunk_prev_rot, 9))) return rc;
+  if (b->warm_start) {   // first tick: the caller's working set if there is one, else cold
+    if (a.in.working_set) HIP_TRY(hipMemcpyAsync(w_ws, a.in.working_set, n * 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    else HIP_TRY(hipMemsetAsync(w_ws, 0, n * 2 * sizeof(unsigned long long), s));
+    a.ws_in = w_ws; a.ws_out = w_ws;
+  }
   if (ro.status_max) HIP_TRY(hipMemsetAsync(ro.status_max, 0, n * sizeof(int32_t), s));
   if (ro.iters_sum) HIP_TRY(hipMemsetAsync(ro.iters_sum, 0, n * sizeof(int32_t), s));
   const WbcTickIn first = a.in;

@@ -69,6 +69,11 @@ struct KernelArgs {
   int32_t jtj_mfma, presolve;  // presolve: structural elimination of the contact equalities (default on)
   int32_t fk_nj, fk_nf;             // oMi / oMf output strides = max njoints / nframes over the handle's models
   int32_t* defer;                   // [1 + max_batch]: count, then the instances wbc_tick_sim3_kernel left to the general path
+  // warm start: the final working set of the previous tick, [B][2] words in FULL-problem indexing whatever
+  // kernel wrote them: word 0 = velocity bounds (bit d: DoF d at its lower bound, bit 32 + d: at its upper bound), word 1 =
+  // constraint rows of findConstraints' order (bit i / 32 + i). Either may be null (cold start / nothing carried); they may alias.
+  const unsigned long long* ws_in;
+  unsigned long long* ws_out;
   unsigned long long* prof;         // WBC_PROFILE builds: per-phase cycle sums [16] (else unused)
   double dt;
   double sing_tol;                  // a stance-leg block with |det K| <= sing_tol (sum|K_ij|)^3 is not eliminated

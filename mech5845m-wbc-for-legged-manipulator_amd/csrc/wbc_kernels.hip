@@ -227,19 +227,31 @@ __device__ __forceinline__ void integrate_ff(const SM& S, const int lane, double
 // Householder QR of J'N_e that only updates J; x_eq = J1 y1 - J2 J2'g; then dual active-set iterations for the
 // inequalities with T = R^-1 kept (in RA) only for the inequality slots.
 // ------------------------------------------------------------------------------------------------
-struct QpResult { double x; int status; int iters; };
+struct QpResult { double x; int status; int iters; int ws_b, ws_r; };   // ws_b / ws_r: final working set, lane = bound / row: 0 inactive, 1 at its lower, 2 at its upper side
+
+// `keep the lowest k set bits of m` (wave-uniform)
+__device__ __forceinline__ unsigned long long low_bits(unsigned long long m, int k) {
+  while (__popcll(m) > k) m &= ~(1ull << (63 - __clzll((long long)m)));
+  return m;
+}
 
 // NM = compiled problem-size cap (even, n <= NM <= 26): register-array sizes and loop trip counts; SM = LDS layout
 // (Smem or the compact SmemC); CS = row stride of the constraint matrix S.RC
-template <int NM, class SM = Smem, int CS = LDJ>
+// WARM: compiled with the warm start (the analogue of qpOASES' hotstart, QP_Wrapper.py:55-73): ws_b_in / ws_r_in
+// carry the previous tick's final working set in the same per-lane code as QpResult.ws_b / ws_r (algebra: tests/gi_variant.py
+// solve_v3). The seeds go through the register-resident Householder QR of the equality block — an order of magnitude cheaper
+// per constraint than a dual iteration — but stay droppable (their columns of T = R22^-1 are built along the way); seeds whose
+// multiplier comes out negative are removed by the restoration steps in front of the dual iterations.
+template <int NM, class SM = Smem, int CS = LDJ, bool WARM = false>
 __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const double lb_in, const double ub_in,
                                             const double clb_in, const double cub_in, const int n, const int p, const int lane,
-                                            unsigned long long* ts, const int dbg_stop = 0) {
+                                            unsigned long long* ts, const int dbg_stop = 0, const int ws_b_in = 0, const int ws_r_in = 0) {
   const int li = lane < NM ? lane : NM - 1;
   QpResult res;
   res.status = WBC_QP_OPTIMAL;
   res.iters = 0;
   res.x = 0.0;
+  res.ws_b = res.ws_r = 0;
   double g = g_in, lb = lb_in, ub = ub_in, clb = clb_in, cub = cub_in;
   // a NaN bound would silently drop its constraint (every comparison with it is false): refuse the problem instead
   if (__ballot((lane < n && (lb != lb || ub != ub)) || (lane < p && (clb != clb || cub != cub)))) {
@@ -355,6 +367,18 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   const unsigned long long eqm_b = __ballot(eq_b), eqm_r = __ballot(eq_r);
   const int nbe = __popcll(eqm_b), ne = nbe + __popcll(eqm_r);
   if (ne > NM) { res.status = WBC_QP_NUMERICAL; return res; }   // more equalities than unknowns
+  // warm start: the carried working set's inequalities (a bound presolved above as fixed is infinite by now and drops out)
+  unsigned long long sdm_b = 0, sdm_r = 0;
+  int nseed = 0;
+  if (WARM) {
+    sdm_b = __ballot(has_b && !eq_b && ((ws_b_in == 1 && lb > -QP_INF) || (ws_b_in == 2 && ub < QP_INF)));
+    sdm_r = __ballot(has_r && !eq_r && ((ws_r_in == 1 && clb > -QP_INF) || (ws_r_in == 2 && cub < QP_INF)));
+    const int cap = ((n < NM) ? n : NM) - ne;               // columns the equality QR still has room for
+    sdm_b = low_bits(sdm_b, cap);
+    sdm_r = low_bits(sdm_r, cap - __popcll(sdm_b));
+    nseed = __popcll(sdm_b) + __popcll(sdm_r);
+  }
+  const int ntot = ne + nseed;
 
   // lanes < 26: y = row `lane` of J0.  jf2 = |J0|_F^2
   double sq = 0.0;
@@ -374,19 +398,29 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   STAMP(ts, T_INV);
   WSYNC();
 
-  // ---- gather row `lane` of B (one register per equality, processing order: bounds by index, then rows) and L^-1 g
+  // ---- gather row `lane` of B (one register per equality / seed, processing order: equality bounds by index, equality rows,
+  // then the seeded bounds and rows, each with the sign of its side) and L^-1 g
   double bq[NM], bg;
   {
-    unsigned long long mb = eqm_b, mr = eqm_r;
+    unsigned long long mb = eqm_b, mr = eqm_r, sb = sdm_b, sr = sdm_r;
 #pragma unroll
     for (int e = 0; e < NM; ++e) {
       double v = 0.0;
-      if (e < ne) {                                      // uniform
+      if (e < ntot) {                                    // uniform
         const double* col;
-        double be, n2;
+        double be, n2, sg = 1.0;
         if (mb) { const int c = ctz64(mb); mb &= mb - 1; col = S.RB + c * LDJ; be = rdl(lb, c); n2 = 1.0; }
-        else { const int c = ctz64(mr); mr &= mr - 1; col = S.RA + c * LDJ; be = rdl(clb, c); n2 = rdl(cn2, c); }
-        v = col[li];
+        else if (mr) { const int c = ctz64(mr); mr &= mr - 1; col = S.RA + c * LDJ; be = rdl(clb, c); n2 = rdl(cn2, c); }
+        else if (WARM && sb) {
+          const int c = ctz64(sb); sb &= sb - 1; col = S.RB + c * LDJ; n2 = 1.0;
+          const bool up = rdli(ws_b_in, c) == 2;
+          sg = up ? -1.0 : 1.0; be = up ? -rdl(ub, c) : rdl(lb, c);
+        } else {
+          const int c = ctz64(sr); sr &= sr - 1; col = S.RA + c * LDJ; n2 = rdl(cn2, c);
+          const bool up = rdli(ws_r_in, c) == 2;
+          sg = up ? -1.0 : 1.0; be = up ? -rdl(cub, c) : rdl(clb, c);
+        }
+        v = sg * col[li];
         if (lane == 0) { S.dinv[e] = be; S.lv[e] = n2; }   // (dinv / lv are free after the substitution)
       }
       bq[e] = (lane < n) ? v : 0.0;
@@ -394,21 +428,34 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
     bg = (lane < n) ? S.RA[p * LDJ + li] : 0.0;
   }
   WSYNC();
+  // T = 0 in RA (the B columns are in registers now); the seeds' columns of T are written during the QR below
+  for (int k = lane; k < NM * LDJ; k += 64) S.RA[k] = 0.0;
 
   bool act_b = eq_b, act_r = eq_r;        // bound `lane` / row `lane` in the working set (equalities stay in)
+  int side_b = 0, side_r = 0;             // side (0 lower, 1 upper) at which bound / row `lane` is active
   double u = 0.0;                         // multiplier of working-set slot `lane` (inequality slots only)
   int a_code = 0;                         // slot `lane`: constraint id | side << 8
   int q = 0, iters = nfix;
   const int max_iter = 10 * (n + p) + 20;
+  double* const T = S.RA;
 
   // ---- equality block: Householder QR of B = J0'N_e with ROTATING columns (bq[0] is always the current column);
   // every reflector is applied at once to the remaining columns, to L^-1 g and to row `lane` of J0 (all in registers).
   // y1 solves R'y1 = b_e incrementally. Nothing but the reflector vector goes through LDS.
   double y1 = 0.0;                        // lane k < q: y1_k
-  const bool any_be = __ballot((eq_b && lb != 0.0) || (eq_r && clb != 0.0)) != 0;
+  const bool any_be = nseed > 0 || __ballot((eq_b && lb != 0.0) || (eq_r && clb != 0.0)) != 0;
+  int qe = -1;                            // first inequality slot (= number of equalities taken); fixed when the first seed comes up
+  unsigned long long sb2 = sdm_b, sr2 = sdm_r;
 #pragma unroll 1
-  for (int e = 0; e < ne; ++e) {
+  for (int e = 0; e < ntot; ++e) {
     ++iters;
+    const bool seed = WARM && e >= ne;    // uniform
+    int scode = 0;
+    if (seed) {
+      if (qe < 0) qe = q;
+      if (sb2) { const int c = ctz64(sb2); sb2 &= sb2 - 1; scode = c | ((rdli(ws_b_in, c) == 2) ? 256 : 0); }
+      else { const int c = ctz64(sr2); sr2 &= sr2 - 1; scode = (n + c) | ((rdli(ws_r_in, c) == 2) ? 256 : 0); }
+    }
     const double d = bq[0];
     const double zn = wsum(lane >= q ? d * d : 0.0);
     const double dy = any_be ? wsum(lane < q ? d * y1 : 0.0) : 0.0;   // y1 stays 0 when every right-hand side is 0
@@ -423,14 +470,28 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
       beta = (vv > 0.0) ? 2.0 / vv : 0.0;
       const double yq = (b_e - dy) / delta;
       if (lane == q) y1 = yq;
+      if (seed) {
+        // the seed stays droppable: column q of T = R22^-1 is (-T r / delta, 1 / delta) with r = the column's entries on the
+        // inequality slots [qe, q) — the same append the dual method's add step makes
+        if (lane < 32) S.yv[lane] = (lane >= qe && lane < q) ? d : 0.0;
+        WSYNC();
+        double acc = 0.0;
+#pragma unroll 1
+        for (int j = qe; j < q; ++j) acc = fma(T[li * LDJ + j], S.yv[j], acc);
+        const double idel = 1.0 / delta;
+        if (lane >= qe && lane < q) T[lane * LDJ + q] = -acc * idel;
+        if (lane == q) { T[lane * LDJ + q] = idel; a_code = scode; }
+        const int sc = scode & 255, sd = scode >> 8;
+        if (sc >= n) { if (lane == sc - n) { act_r = true; side_r = sd; } } else { if (lane == sc) { act_b = true; side_b = sd; } }
+      }
       ++q;
-    } else if (!(fabs(dy - b_e) <= 1e-9 * fmax(1.0, fabs(b_e)))) {   // dependent and inconsistent
+    } else if (!seed && !(fabs(dy - b_e) <= 1e-9 * fmax(1.0, fabs(b_e)))) {   // dependent and inconsistent (a dependent seed is just not taken)
       res.status = WBC_QP_INFEASIBLE; res.iters = iters; return res;
     }
     if (lane < 32) S.dv[lane] = v;
     WSYNC();
     // remaining columns (rotated down by one) and L^-1 g
-    const int left = ne - 1 - e;          // columns still to come
+    const int left = ntot - 1 - e;        // columns still to come
 #pragma unroll
     for (int r = 1; r < NM; ++r) {
       if (((r - 1) & 3) == 0 && r > left) break;      // uniform: whole groups of four past the last column are skipped
@@ -462,15 +523,17 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
     }
     WSYNC();
   }
-  const int qe = q;
+  if (qe < 0) qe = q;
   // ---- x_eq = J1 y1 - J2 (J2' g):  bg now holds J'g
-  if (lane < 32) S.dv[lane] = (lane < qe) ? y1 : ((lane < n) ? -bg : 0.0);
-  // J = J0 Q -> RB for the inequality phase; T = 0 in RA
+  if (lane < 32) S.dv[lane] = (lane < q) ? y1 : ((lane < n) ? -bg : 0.0);
+  // J = J0 Q -> RB for the inequality phase
   if (lane < NM) {
 #pragma unroll
     for (int k = 0; k < NM; k += 2) sts2(S.RB + lane * LDJ + k, y[k], y[k + 1]);
   }
-  for (int k = lane; k < NM * LDJ; k += 64) S.RA[k] = 0.0;
+  if (WARM && q > qe) {   // multipliers of the seeded slots: u = T (y1 + J'g) over [qe, q)
+    if (lane < 32) S.yv[lane] = (lane >= qe && lane < q) ? y1 + bg : 0.0;
+  }
   WSYNC();
   double x = 0.0, x2s = 0.0;
 #pragma unroll
@@ -478,43 +541,65 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   LDS_THEN_VALU(NM / 2, NM);
   x += x2s;
   if (lane >= n) x = 0.0;
+  if (WARM && q > qe) {
+    double acc = 0.0;
+#pragma unroll 1
+    for (int j = qe; j < q; ++j) acc = fma(T[li * LDJ + j], S.yv[j], acc);
+    if (lane >= qe && lane < q) u = acc;
+    WSYNC();
+  }
   double* const J = S.RB;
-  double* const T = S.RA;
   const double* const Cm = S.RC;
   STAMP(ts, T_EQ);
   if (dbg_stop == 7) { res.x = x; return res; }                // ablation timing: equality phase and x_eq done
 
-  // ---- inequality phase
+  // ---- inequality phase. With seeds taken, RESTORATION first: while a seeded slot's multiplier is negative, the most
+  // negative one is dropped and the iterate moved to the minimiser on the remaining set (the add step of the dual method read
+  // backwards: x <- x - u_l z, u <- u + u_l r with z, r of the dropped constraint on the new factors); what is left is an S-pair
+  // (x minimises on the working set, u >= 0) and the dual iterations start from it.
+  bool restoring = WARM && q > qe;
 #pragma unroll 1
   for (;;) {
-    // most violated inactive inequality
-    if (lane < 32) S.xv[lane] = x;
-    WSYNC();
-    double best = 0.0; int code = -1;
-    if (has_b && !act_b && !eq_b) {
-      if (lb > -QP_INF) { const double s = x - lb; if (s < -1e-9 * fmax(1.0, fabs(lb)) && s < best) { best = s; code = lane; } }
-      if (ub < QP_INF) { const double s = ub - x; if (s < -1e-9 * fmax(1.0, fabs(ub)) && s < best) { best = s; code = lane | 256; } }
-    }
-    if (p > 0) {
-      double v = 0.0, vb = 0.0;
+    int wc;
+    double s_ip = 0.0, u_l = 0.0;
+    int drop_l = -1;
+    if (WARM && restoring) {
+      const bool slot = lane >= qe && lane < q;
+      const double um = wmin((lane < 32 && slot) ? u : 0.0);
+      if (!(um < 0.0)) { restoring = false; continue; }
+      drop_l = ctz64(__ballot(slot && u == um));
+      u_l = um;
+      wc = rdli(a_code, drop_l);
+    } else {
+      // most violated inactive inequality
+      if (lane < 32) S.xv[lane] = x;
+      WSYNC();
+      double best = 0.0; int code = -1;
+      if (has_b && !act_b && !eq_b) {
+        if (lb > -QP_INF) { const double s = x - lb; if (s < -1e-9 * fmax(1.0, fabs(lb)) && s < best) { best = s; code = lane; } }
+        if (ub < QP_INF) { const double s = ub - x; if (s < -1e-9 * fmax(1.0, fabs(ub)) && s < best) { best = s; code = lane | 256; } }
+      }
+      if (p > 0) {
+        double v = 0.0, vb = 0.0;
 #pragma unroll
-      for (int k = 0; k < NM; k += 2) {
-        const double2a c2 = lds2(Cm + (has_r ? lane : 0) * CS + k); const double2a x2 = lds2(S.xv + k);
-        v = fma(c2.x, x2.x, v); vb = fma(c2.y, x2.y, vb);
+        for (int k = 0; k < NM; k += 2) {
+          const double2a c2 = lds2(Cm + (has_r ? lane : 0) * CS + k); const double2a x2 = lds2(S.xv + k);
+          v = fma(c2.x, x2.x, v); vb = fma(c2.y, x2.y, vb);
+        }
+        LDS_THEN_VALU(NM, NM);
+        v += vb;
+        if (has_r && !act_r && !eq_r) {
+          if (clb > -QP_INF) { const double s = v - clb; if (s < -1e-9 * fmax(1.0, fabs(clb)) && s < best) { best = s; code = n + lane; } }
+          if (cub < QP_INF) { const double s = cub - v; if (s < -1e-9 * fmax(1.0, fabs(cub)) && s < best) { best = s; code = (n + lane) | 256; } }
+        }
       }
-      LDS_THEN_VALU(NM, NM);
-      v += vb;
-      if (has_r && !act_r && !eq_r) {
-        if (clb > -QP_INF) { const double s = v - clb; if (s < -1e-9 * fmax(1.0, fabs(clb)) && s < best) { best = s; code = n + lane; } }
-        if (cub < QP_INF) { const double s = cub - v; if (s < -1e-9 * fmax(1.0, fabs(cub)) && s < best) { best = s; code = (n + lane) | 256; } }
-      }
+      const double worst = wmin(lane < 32 ? best : 0.0);
+      if (!(worst < 0.0)) break;                          // primal feasible -> optimal
+      const int wl = ctz64(__ballot(lane < 32 && best == worst));
+      wc = rdli(code, wl);
+      s_ip = worst;
     }
-    const double worst = wmin(lane < 32 ? best : 0.0);
-    if (!(worst < 0.0)) break;                          // primal feasible -> optimal
-    const int wl = ctz64(__ballot(lane < 32 && best == worst));
-    const int wc = rdli(code, wl);
     const int ip = wc & 255, ip_side = (wc >> 8) & 1;
-    double s_ip = worst;
     const double b_ip = (ip < n) ? rdl(ip_side ? -ub : lb, ip) : rdl(ip_side ? -cub : clb, ip - n);
     const double sgn = ip_side ? -1.0 : 1.0;
     const bool is_row = ip >= n;
@@ -525,6 +610,46 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
 #pragma unroll 1
     for (;;) {
       if (++iters > max_iter) { res.status = WBC_QP_MAX_ITER; goto done; }
+      if (drop_l >= 0) {
+        // ---- drop slot l: Givens sequence read off the removed row of T, applied to columns of T and J
+        const int l = drop_l;
+        drop_l = -1;
+        const int lc = rdli(a_code, l) & 255;
+        if (lc >= n) { if (lane == lc - n) act_r = false; } else { if (lane == lc) act_b = false; }
+        if (lane < 32) { S.yv[lane] = u; S.lv[lane] = (double)a_code; }     // shift slots l+1.. down by one (rare path)
+        WSYNC();
+        if (lane >= l && lane < q - 1) { u = S.yv[lane + 1]; a_code = (int)S.lv[lane + 1]; }
+        if (lane == q - 1) { u = 0.0; a_code = 0; }
+        const int srow = (li >= l) ? ((li + 1 < NM) ? li + 1 : li) : li;   // old row feeding new row `lane`
+        double tx = T[srow * LDJ + l];
+        double jx = J[li * LDJ + l];
+        double hrun = T[l * LDJ + l];
+#pragma unroll 1
+        for (int k = l; k < q - 1; ++k) {
+          const double tb = T[l * LDJ + k + 1];
+          const double nrm2 = fma(hrun, hrun, tb * tb);
+          double c_ = 1.0, s_ = 0.0, rho = 0.0;
+          if (nrm2 > 0.0) { const double ri = rsqrt(nrm2); c_ = tb * ri; s_ = -hrun * ri; rho = nrm2 * ri; }
+          hrun = rho;
+          const double ty = T[srow * LDJ + k + 1];
+          const double jy = J[li * LDJ + k + 1];
+          WSYNC();
+          if (lane >= qe && lane < q - 1) T[lane * LDJ + k] = fma(c_, tx, s_ * ty);
+          if (lane < n) J[lane * LDJ + k] = fma(c_, jx, s_ * jy);
+          tx = fma(-s_, tx, c_ * ty);
+          jx = fma(-s_, jx, c_ * jy);
+        }
+        WSYNC();
+        if (lane < q) T[lane * LDJ + q - 1] = 0.0;      // dropped last column, and the vacated last row
+        if (lane < q) T[(q - 1) * LDJ + lane] = 0.0;
+        if (lane < n) J[lane * LDJ + q - 1] = jx;
+        --q;
+        WSYNC();
+        if (!(WARM && restoring)) {
+          const double v = is_row ? wsum(lane < n ? Cm[rr * CS + li] * x : 0.0) : rdl(x, ip);
+          s_ip = sgn * v - b_ip;
+        }
+      }
       double d = 0.0;
       if (is_row) {
         double d2 = 0.0;
@@ -564,6 +689,11 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
       }
       if (lane < qe || lane >= q) r = 0.0;
       if (lane >= n) z = 0.0;
+      if (WARM && restoring) {             // the dropped seed's multiplier u_l < 0 is taken back: minimiser on the reduced set
+        x = fma(-u_l, z, x);
+        u = fma(u_l, r, u);
+        break;
+      }
       const bool have_step = zn > 100.0 * n * EPS2 * jf2 * np2;
       const bool cand = (lane >= qe) && (lane < q) && (r > 0.0);
       const double ratio = cand ? u / r : INFINITY;
@@ -594,47 +724,12 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
         const double idel = 1.0 / delta;
         if (lane >= qe && lane < q) T[lane * LDJ + q] = -r * idel;
         if (lane == q) { T[lane * LDJ + q] = idel; u = u_ip; a_code = wc; }
-        if (is_row) { if (lane == rr) act_r = true; } else { if (lane == ip) act_b = true; }
+        if (is_row) { if (lane == rr) { act_r = true; side_r = ip_side; } } else { if (lane == ip) { act_b = true; side_b = ip_side; } }
         ++q;
         WSYNC();
         break;
       }
-      // ---- drop slot l: Givens sequence read off the removed row of T, applied to columns of T and J
-      {
-        const int lc = rdli(a_code, l) & 255;
-        if (lc >= n) { if (lane == lc - n) act_r = false; } else { if (lane == lc) act_b = false; }
-        if (lane < 32) { S.yv[lane] = u; S.lv[lane] = (double)a_code; }     // shift slots l+1.. down by one (rare path)
-        WSYNC();
-        if (lane >= l && lane < q - 1) { u = S.yv[lane + 1]; a_code = (int)S.lv[lane + 1]; }
-        if (lane == q - 1) { u = 0.0; a_code = 0; }
-        const int srow = (li >= l) ? ((li + 1 < NM) ? li + 1 : li) : li;   // old row feeding new row `lane`
-        double tx = T[srow * LDJ + l];
-        double jx = J[li * LDJ + l];
-        double hrun = T[l * LDJ + l];
-#pragma unroll 1
-        for (int k = l; k < q - 1; ++k) {
-          const double tb = T[l * LDJ + k + 1];
-          const double nrm2 = fma(hrun, hrun, tb * tb);
-          double c_ = 1.0, s_ = 0.0, rho = 0.0;
-          if (nrm2 > 0.0) { const double ri = rsqrt(nrm2); c_ = tb * ri; s_ = -hrun * ri; rho = nrm2 * ri; }
-          hrun = rho;
-          const double ty = T[srow * LDJ + k + 1];
-          const double jy = J[li * LDJ + k + 1];
-          WSYNC();
-          if (lane >= qe && lane < q - 1) T[lane * LDJ + k] = fma(c_, tx, s_ * ty);
-          if (lane < n) J[lane * LDJ + k] = fma(c_, jx, s_ * jy);
-          tx = fma(-s_, tx, c_ * ty);
-          jx = fma(-s_, jx, c_ * jy);
-        }
-        WSYNC();
-        if (lane < q) T[lane * LDJ + q - 1] = 0.0;      // dropped last column, and the vacated last row
-        if (lane < q) T[(q - 1) * LDJ + lane] = 0.0;
-        if (lane < n) J[lane * LDJ + q - 1] = jx;
-        --q;
-        WSYNC();
-        const double v = is_row ? wsum(lane < n ? Cm[rr * CS + li] * x : 0.0) : rdl(x, ip);
-        s_ip = sgn * v - b_ip;
-      }
+      drop_l = l;                         // blocking slot: dropped at the top of the next pass, then the step is retried
     }
   }
 done:
@@ -645,6 +740,10 @@ done:
     res.status = WBC_QP_NUMERICAL;                       // NaN / Inf reached the answer (non-finite inputs): never "optimal"
   res.x = (res.status == WBC_QP_OPTIMAL) ? x : 0.0;
   res.iters = iters;
+  if (WARM && res.status == WBC_QP_OPTIMAL) {            // the working set the next tick is seeded with (an unsolved QP carries nothing)
+    res.ws_b = (act_b && !eq_b) ? 1 + side_b : 0;
+    res.ws_r = (act_r && !eq_r) ? 1 + side_r : 0;
+  }
   return res;
 }
 
@@ -1452,8 +1551,18 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
 #ifdef WBC_PROFILE
   ts[T_PRE] = 0;
 #endif
-  if (!contact_presolve(S, A, M, cfg, P, dpost, g, lb, ub, clb, cub, lane, ts, res))
-    res = qp_core<NV>(S, g, lb, ub, clb, cub, nv, A.prows, lane, ts);
+  if (!contact_presolve(S, A, M, cfg, P, dpost, g, lb, ub, clb, cub, lane, ts, res)) {
+    // warm start in the problem's own indexing: lane d <-> bound of DoF d, lane i <-> constraint row i
+    const unsigned long long w0 = A.ws_in ? A.ws_in[2 * (size_t)b] : 0ull, w1 = A.ws_in ? A.ws_in[2 * (size_t)b + 1] : 0ull;
+    const int sb = (lane < 32) ? (int)(((w0 >> lane) & 1ull) | (((w0 >> (32 + lane)) & 1ull) << 1)) : 0;
+    const int sr = (lane < 32) ? (int)(((w1 >> lane) & 1ull) | (((w1 >> (32 + lane)) & 1ull) << 1)) : 0;
+    res = qp_core<NV, Smem, LDJ, true>(S, g, lb, ub, clb, cub, nv, A.prows, lane, ts, 0, sb == 3 ? 0 : sb, sr == 3 ? 0 : sr);
+  }
+  if (A.ws_out) {   // (the in-kernel presolve path runs cold and carries nothing: res.ws_* = 0 there)
+    const unsigned long long o0 = (__ballot(res.ws_b == 1) & 0xFFFFFFFFull) | (__ballot(res.ws_b == 2) << 32);
+    const unsigned long long o1 = (__ballot(res.ws_r == 1) & 0xFFFFFFFFull) | (__ballot(res.ws_r == 2) << 32);
+    if (lane == 0) { A.ws_out[2 * (size_t)b] = o0; A.ws_out[2 * (size_t)b + 1] = o1; }
+  }
   if (A.out.qdot && lane < NV) A.out.qdot[(size_t)b * NV + lane] = (lane < nv) ? res.x : 0.0;
   if (lane == 0) {
     if (A.out.status) A.out.status[b] = res.status;
@@ -1586,7 +1695,7 @@ __device__ __forceinline__ void jtj_block_c(SmemC& S, const double* At, const in
 
 __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
                                              const DevPlan& P, const Hdr& H, const LaneConst& lc, const InRegs& inr,
-                                             const int b, const int lane) {
+                                             const int b, const int lane, const unsigned long long ws0, const unsigned long long ws1) {
   const int nv = H.nv, nq = H.nq;
   // the configuration's switches as ONE word from the plan (each cfg.* flag read where it is tested costs its own scalar load +
   // full wait): bit 0 con_com, 1 con_trunk, 2 task_trunk, 3 use_bounds, bits 4..6 task_joint
@@ -1898,7 +2007,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   // ---- C' = C Z for the rows that stay, then the eliminated legs' bounds as rows G_l
   double* const Cm = S.RC;
   double nclb = 0.0, ncub = 0.0;
-  int i2 = 0;
+  int i2 = 0, my_orig = -1;            // my_orig: original index of the kept row that becomes reduced row `lane`
 #pragma unroll 1
   for (int i = 0; i < p; ++i) {
     if ((elimrows >> i) & 1u) continue;
@@ -1909,7 +2018,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     }
     if (lane < CSC) Cm[i2 * CSC + lane] = v;
     const double bl = rdl(clb, i), bu = rdl(cub, i);
-    if (lane == i2) { nclb = bl; ncub = bu; }
+    if (lane == i2) { nclb = bl; ncub = bu; my_orig = i; }
     ++i2;
   }
   if (c_use_bounds) {
@@ -1942,12 +2051,28 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   WSYNC();
   STAMP(ts, T_PRE);
   DBG_STOP(5, g_red + lb_red + ub_red + nclb + ncub + S.RA[(lane & 15) * LDJ + 1] + Cm[(lane & 15) * CSC + 1]);
-  QpResult res = qp_core<NR, SmemC, CSC>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, DBG_STOP_ARG);
+  // warm start: the carried working set (full-problem indexing, KernelArgs.ws_in) seen from the reduced problem — reduced
+  // variable k is DoF Fd[k]; reduced row r is kept row my_orig or, from p_keep on, the velocity bound of an eliminated leg DoF
+  int sd_b = 0, sd_r = 0;
+  if (lane < n_red) sd_b = (int)(((ws0 >> fj) & 1ull) | (((ws0 >> (32 + fj)) & 1ull) << 1));
+  if (my_orig >= 0) sd_r = (int)(((ws1 >> my_orig) & 1ull) | (((ws1 >> (32 + my_orig)) & 1ull) << 1));
+  else if (c_use_bounds && lane >= p_keep && lane < p_keep + nl) sd_r = (int)(((ws0 >> my_legd) & 1ull) | (((ws0 >> (32 + my_legd)) & 1ull) << 1));
+  QpResult res = qp_core<NR, SmemC, CSC, true>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, DBG_STOP_ARG,
+                                               sd_b == 3 ? 0 : sd_b, sd_r == 3 ? 0 : sd_r);
   res.iters += nl;
   // ---- x = Z y
   WSYNC();
-  if (lane < 32) S.xv[lane] = (lane < n_red) ? res.x : 0.0;
+  if (lane < 32) { S.xv[lane] = (lane < n_red) ? res.x : 0.0; S.lv[lane] = (double)res.ws_b; S.dinv[lane] = (double)res.ws_r; }
   WSYNC();
+  if (A.ws_out) {   // the final working set back in full-problem indexing: lane d = DoF d, lane i = original constraint row i
+    int cb = 0, cr = 0;
+    if (my_pos >= 0) cb = (int)S.lv[my_pos];
+    else if (my_l >= 0 && c_use_bounds) cb = (int)S.dinv[(p_keep + my_l) & 31];
+    if (lane < p && !((elimrows >> lane) & 1u)) cr = (int)S.dinv[__popc(~elimrows & ((1u << lane) - 1u)) & 31];
+    const unsigned long long o0 = (__ballot(cb == 1) & 0xFFFFFFFFull) | (__ballot(cb == 2) << 32);
+    const unsigned long long o1 = (__ballot(cr == 1) & 0xFFFFFFFFull) | (__ballot(cr == 2) << 32);
+    if (lane == 0) { A.ws_out[2 * (size_t)b] = o0; A.ws_out[2 * (size_t)b + 1] = o1; }
+  }
   double x = 0.0;
   if (my_pos >= 0) x = S.xv[my_pos];
   else if (my_l >= 0) {
@@ -1999,9 +2124,11 @@ __global__ void __launch_bounds__(64, 3) wbc_tick_sim3_kernel(const KernelArgs A
   const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);
   Hdr H = load_hdr(models[mid]);                 // one batch of scalar loads, waited for once
   asm volatile("" : "+s"(H.nq), "+s"(H.nv), "+s"(H.nj), "+s"(H.maxdepth), "+s"(H.nframes), "+s"(H.trunk_joint));
+  // the carried working set (warm start): two uniform words, fetched with the other inputs
+  const unsigned long long ws0 = A.ws_in ? A.ws_in[2 * (size_t)b] : 0ull, ws1 = A.ws_in ? A.ws_in[2 * (size_t)b + 1] : 0ull;
   stage_inputs(S, cur, lane, has2, false);
   WSYNC();
-  process_sim3(S, A, models[mid], cfgs[mid], plans[mid], H, lc, cur, b, lane);
+  process_sim3(S, A, models[mid], cfgs[mid], plans[mid], H, lc, cur, b, lane, ws0, ws1);
 }
 
 // Second pass after wbc_tick_sim3_kernel: the instances it deferred (a stance-leg block it could not eliminate) are redone on

@@ -28,7 +28,12 @@ def _mem_of(arrays):
 # doubles (int32 for model_id) per instance of every WbcTickIn field (include/wbc.h)
 TICK_IN_WIDTH = dict(q=NQS, ee_target=15, prev_ee_target=15, trunk_target=3, prev_trunk_target=3, trunk_box_center=4,
                      ee_ref_rot=45, ee_prev_rot=45, trunk_ref_euler=3, trunk_prev_rot=9, com_target=3, com_target_vel=3,
-                     model_id=1, posture_u=NV, q_con=NQS)
+                     model_id=1, posture_u=NV, q_con=NQS, working_set=2)
+_INT32_FIELDS, _INT64_FIELDS = ("model_id", "status", "iters"), ("working_set",)
+
+
+def _dtype_of(name):
+    return np.int32 if name in _INT32_FIELDS else (np.int64 if name in _INT64_FIELDS else np.float64)
 
 
 def _prep(a, dtype, keep, B=None, width=None, name="array", device_id=None):
@@ -43,7 +48,7 @@ def _prep(a, dtype, keep, B=None, width=None, name="array", device_id=None):
             raise capi.WbcError("%s: shape %s does not hold %d x %d values (leading dimension = batch)" % (name, shape, B, width))
     if _is_torch(a):
         import torch
-        want = torch.float64 if dtype == np.float64 else torch.int32
+        want = {np.float64: torch.float64, np.int32: torch.int32, np.int64: torch.int64}[dtype]
         if a.dtype != want or not a.is_contiguous():
             raise capi.WbcError("%s: device tensors must be contiguous %s" % (name, want))
         if a.is_cuda and device_id is not None and a.device.index != device_id:
@@ -113,6 +118,7 @@ class WbcBatch:
 
     def set_option(self, name, value):
         capi.check(self.lib.wbc_batch_set_option(self._h, name.encode(), int(value)), self.lib)
+        self._options = dict(getattr(self, "_options", {}), **{name: int(value)})
 
     @property
     def task_rows(self):
@@ -146,20 +152,20 @@ class WbcBatch:
         for name, _ in capi.WbcTickIn._fields_:
             a = inputs.get(name)
             if a is not None:
-                setattr(t, name, self._p(a, np.int32 if name == "model_id" else np.float64, keep, B, TICK_IN_WIDTH[name], name))
+                setattr(t, name, self._p(a, _dtype_of(name), keep, B, TICK_IN_WIDTH[name], name))
         return t
 
     def _outs(self, out, widths, keep, B, struct):
         for k, v in out.items():
             if k not in widths:
                 raise capi.WbcError("unknown output %r" % k)
-            setattr(struct, k, self._p(v, np.int32 if k in ("status", "iters") else np.float64, keep, B, widths[k], k))
+            setattr(struct, k, self._p(v, _dtype_of(k), keep, B, widths[k], k))
         return struct
 
     def _alloc(self, like, shape, dtype=np.float64):
         if like is not None and _is_torch(like):
             import torch
-            return torch.empty(shape, dtype=torch.float64 if dtype == np.float64 else torch.int32, device=like.device)
+            return torch.empty(shape, dtype={np.float64: torch.float64, np.int32: torch.int32, np.int64: torch.int64}[dtype], device=like.device)
         return np.empty(shape, dtype=dtype)
 
     # ---- entry points
@@ -195,10 +201,11 @@ class WbcBatch:
         capi.check(self.lib.wbc_assemble(self._h, B, C.byref(tin), float(dt), mem, C.byref(o), self._stream(mem)), self.lib)
         return out
 
-    _TICK_OUT_WIDTH = dict(qdot=NV, status=1, iters=1, q_next=NQS)
+    _TICK_OUT_WIDTH = dict(qdot=NV, status=1, iters=1, q_next=NQS, working_set=2)
 
-    def tick(self, inputs, dt, want_q_next=False, out=None):
-        """One runWBC tick per instance up to the QP (+ integrate): returns dict(qdot, status, iters[, q_next])."""
+    def tick(self, inputs, dt, want_q_next=False, out=None, want_working_set=False):
+        """One runWBC tick per instance up to the QP (+ integrate): returns dict(qdot, status, iters[, q_next][, working_set]).
+        inputs["working_set"] (int64 [B,2], the previous tick's out["working_set"]) warm-starts the QP (include/wbc.h)."""
         keep = []
         q = inputs.get("q")
         B = self._batch_of(q)
@@ -206,6 +213,8 @@ class WbcBatch:
             out = dict(qdot=self._alloc(q, (B, NV)), status=self._alloc(q, (B,), np.int32), iters=self._alloc(q, (B,), np.int32))
             if want_q_next:
                 out["q_next"] = self._alloc(q, (B, NQS))
+            if want_working_set:
+                out["working_set"] = self._alloc(q, (B, 2), np.int64)
         mem = _mem_of(list(inputs.values()) + list(out.values()))
         o = self._outs(out, self._TICK_OUT_WIDTH, keep, B, capi.WbcTickOut())
         tin = self._tick_in(inputs, keep, B)
@@ -378,7 +387,12 @@ class WbcBatch:
                  trunk_prev_rot=np.zeros((B, 9)))                          # old_ref_trunk_rot_matrix = zeros before initialiseWBC (:150)
         if mid is not None:
             d["model_id"] = mid
-        ro = self.rollout(d, dt, n, ee_target_step=(goal - ee) / n, want_trace=False, mode=capi.ROLLOUT_WARMUP, hold_ticks=n)
+        warm = getattr(self, "_options", {}).get("warm_start", 1)
+        self.set_option("warm_start", 0)                                   # the reference builds a fresh QP object every iteration (:320): cold
+        try:
+            ro = self.rollout(d, dt, n, ee_target_step=(goal - ee) / n, want_trace=False, mode=capi.ROLLOUT_WARMUP, hold_ticks=n)
+        finally:
+            self.set_option("warm_start", warm)
         q = ro["q"].copy()
         q[:, 3:6] = 0.0                                                    # "reset base orientation" (:328-330): x, y, z of the quaternion
         feet_z = self.fk(q, mid, want=("oMf",))["oMf"][:, capi.FR_EE0:capi.FR_EE0 + 4, 11]

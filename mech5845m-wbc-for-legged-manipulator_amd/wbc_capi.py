@@ -62,7 +62,7 @@ class WbcTickIn(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "q", "ee_target", "prev_ee_target", "trunk_target", "prev_trunk_target", "trunk_box_center",
         "ee_ref_rot", "ee_prev_rot", "trunk_ref_euler", "trunk_prev_rot", "com_target", "com_target_vel", "model_id",
-        "posture_u", "q_con")]
+        "posture_u", "q_con", "working_set")]
 
 
 class WbcQpData(C.Structure):
@@ -70,7 +70,7 @@ class WbcQpData(C.Structure):
 
 
 class WbcTickOut(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("qdot", "status", "iters", "q_next")]
+    _fields_ = [(n, C.c_void_p) for n in ("qdot", "status", "iters", "q_next", "working_set")]
 
 
 ROLLOUT_RUNNING, ROLLOUT_WARMUP = 0, 1

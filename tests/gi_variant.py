@@ -296,3 +296,194 @@ def solve_v2(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, max_iter=None):
             T[qe:qe + m_, qe:qe + m_] = np.triu(Tt[:, :m_])
             q -= 1
             s_ip = (-1.0 if side else 1.0) * value(ip, x) - b_ip
+
+
+def solve_v3(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, seeds=(), max_iter=None):
+    """Kernel v3 algebra = solve_v2 + WARM START (the hot-start analogue of QP_Wrapper.py:55-73):
+    `seeds` = [(constraint, side)] carried over from the previous tick's final working set.
+      1. the seeds go through the same Householder QR as the equalities (cheap, register resident on the wavefront), each one
+         appending its column (-T r / delta, 1 / delta) to T = R22^-1 so that they stay droppable; dependent seeds are skipped;
+      2. x = J1 y1 - J2 J2'g, multipliers of the seeded slots u = T (y1 + J'g)[qe:q];
+      3. RESTORATION: while a seeded multiplier is negative, drop the most negative slot l (Givens, as in the dual method)
+         and move to the minimiser on the reduced set: with d, z, r of the dropped constraint taken on the NEW factors,
+         x <- x - u_l z, u <- u + u_l r (the add step of the dual method read backwards). What is left is an S-pair
+         (x minimises on W, u >= 0) — the dual iterations carry on from there.
+    Returns (x, status, iters, final working set [(constraint, side)])."""
+    n = len(g)
+    p = 0 if C is None else C.shape[0]
+    ncon = n + p
+
+    def lo(c):
+        return (lb[c] if lb is not None else -1e30) if c < n else Clb[c - n]
+
+    def hi(c):
+        return (ub[c] if ub is not None else 1e30) if c < n else Cub[c - n]
+
+    def is_eq(c):
+        return lo(c) == hi(c) and abs(lo(c)) < INF
+
+    def normal(c, side):
+        sgn = -1.0 if side else 1.0
+        if c < n:
+            e = np.zeros(n)
+            e[c] = sgn
+            return e
+        return sgn * C[c - n]
+
+    def value(c, x):
+        return x[c] if c < n else C[c - n] @ x
+
+    try:
+        L = np.linalg.cholesky(H)
+    except np.linalg.LinAlgError:
+        return np.zeros(n), 3, 0, []
+    J = np.linalg.inv(L).T.copy()
+    jf2 = (J * J).sum()
+    iters = 0
+    max_iter = max_iter or 10 * (n + p) + 20
+    q = 0
+    y1 = np.zeros(n)
+    active = np.zeros(ncon, bool)
+    T = np.zeros((n, n))
+    act = []                                    # inequality slots: (constraint, side)
+    todo = [(c, 0, True) for c in range(ncon) if is_eq(c)]
+    qe = None
+    for c, side in seeds:
+        if 0 <= c < ncon and not is_eq(c) and ((side == 0 and lo(c) > -INF) or (side == 1 and hi(c) < INF)) and \
+                not any(t[0] == c for t in todo):
+            todo.append((c, side, False))
+    todo = todo[:n]
+    for c, side, eq in todo:
+        if not eq and qe is None:
+            qe = q
+        iters += 1
+        npv = normal(c, side)
+        b_e = lo(c) if side == 0 else -hi(c)
+        d = J.T @ npv
+        zn = d[q:] @ d[q:]
+        dy = d[:q] @ y1[:q]
+        if not zn > 100.0 * n * EPS2 * jf2 * (npv @ npv):
+            if not eq or abs(dy - b_e) <= 1e-9 * max(1.0, abs(b_e)):
+                continue                         # a dependent seed is simply not taken
+            return np.zeros(n), 2, iters, []
+        dq = d[q]
+        delta = -np.sqrt(zn) if dq >= 0 else np.sqrt(zn)
+        v = d[q:].copy()
+        v[0] -= delta
+        vv = 2.0 * (zn - delta * dq)
+        if vv > 0:
+            w = J[:, q:] @ v
+            J[:, q:] -= np.outer(w, (2.0 / vv) * v)
+        y1[q] = (b_e - dy) / delta
+        if not eq:
+            T[qe:q, q] = -(T[qe:q, qe:q] @ d[qe:q]) / delta
+            T[q, q] = 1.0 / delta
+            act.append((c, side))
+        active[c] = True
+        q += 1
+    if qe is None:
+        qe = q
+    dg = J.T @ g
+    x = J @ np.concatenate([y1[:q], -dg[q:]])
+    u = np.zeros(n + 1)
+    u[:q - qe] = T[qe:q, qe:q] @ (y1[qe:q] + dg[qe:q])
+
+    def drop(l):
+        nonlocal q
+        la = qe + l
+        trow = T[la, la:q].copy()
+        active[act[l][0]] = False
+        del act[l]
+        u[l:q - qe - 1] = u[l + 1:q - qe].copy()
+        u[q - qe - 1] = 0.0
+        Tt = np.delete(T[qe:q, qe:q], l, axis=0)
+        h = trow[0]
+        for k in range(la, q - 1):
+            a_, b_ = h, trow[k - la + 1]
+            rho = np.hypot(a_, b_)
+            c_, s_ = (b_ / rho, -a_ / rho) if rho > 0 else (1.0, 0.0)
+            h = rho
+            kk = k - qe
+            ck, ck1 = Tt[:, kk].copy(), Tt[:, kk + 1].copy()
+            Tt[:, kk], Tt[:, kk + 1] = c_ * ck + s_ * ck1, -s_ * ck + c_ * ck1
+            jk, jk1 = J[:, k].copy(), J[:, k + 1].copy()
+            J[:, k], J[:, k + 1] = c_ * jk + s_ * jk1, -s_ * jk + c_ * jk1
+        T[qe:, qe:] = 0
+        m_ = q - qe - 1
+        T[qe:qe + m_, qe:qe + m_] = np.triu(Tt[:, :m_])
+        q -= 1
+
+    # ---- restoration of dual feasibility
+    while q > qe and u[:q - qe].min() < 0.0:
+        iters += 1
+        if iters > max_iter:
+            return x, 1, iters, list(act)
+        l = int(np.argmin(u[:q - qe]))
+        ul = u[l]
+        c, side = act[l]
+        drop(l)
+        d = J.T @ normal(c, side)
+        z = J[:, q:] @ d[q:]
+        r = T[qe:q, qe:q] @ d[qe:q]
+        x = x - ul * z
+        u[:q - qe] += ul * r
+    # ---- dual iterations (solve_v2's inequality phase)
+    while True:
+        worst, ip = 0.0, -1
+        for c in range(ncon):
+            if active[c] or is_eq(c):
+                continue
+            vv_ = value(c, x)
+            if lo(c) > -INF:
+                s = vv_ - lo(c)
+                if s < -1e-9 * max(1.0, abs(lo(c))) and s < worst:
+                    worst, ip, side, b_ip = s, c, 0, lo(c)
+            if hi(c) < INF:
+                s = hi(c) - vv_
+                if s < -1e-9 * max(1.0, abs(hi(c))) and s < worst:
+                    worst, ip, side, b_ip = s, c, 1, -hi(c)
+        if ip < 0:
+            return x, 0, iters, list(act)
+        s_ip = worst
+        npv = normal(ip, side)
+        np2 = npv @ npv
+        u_ip = 0.0
+        while True:
+            iters += 1
+            if iters > max_iter:
+                return x, 1, iters, list(act)
+            d = J.T @ npv
+            zn = d[q:] @ d[q:]
+            z = J[:, q:] @ d[q:]
+            r = T[qe:q, qe:q] @ d[qe:q]
+            have_step = zn > 100.0 * n * EPS2 * jf2 * np2
+            t1, l = np.inf, -1
+            for k in range(q - qe):
+                if r[k] > 0 and u[k] / r[k] < t1:
+                    t1, l = u[k] / r[k], k
+            t2 = -s_ip / zn if have_step else np.inf
+            t = min(t1, t2)
+            if not np.isfinite(t):
+                return x, 2, iters, list(act)
+            if have_step:
+                x = x + t * z
+            u[:q - qe] -= t * r
+            u_ip += t
+            if have_step and t == t2:
+                dq = d[q]
+                delta = -np.sqrt(zn) if dq >= 0 else np.sqrt(zn)
+                v = d[q:].copy()
+                v[0] -= delta
+                vv = 2.0 * (zn - delta * dq)
+                if vv > 0:
+                    w = z - delta * J[:, q]
+                    J[:, q:] -= np.outer(w, (2.0 / vv) * v)
+                T[qe:q, q] = -r / delta
+                T[q, q] = 1.0 / delta
+                u[q - qe] = u_ip
+                act.append((ip, side))
+                active[ip] = True
+                q += 1
+                break
+            drop(l)
+            s_ip = (-1.0 if side else 1.0) * value(ip, x) - b_ip

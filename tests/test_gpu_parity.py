@@ -529,19 +529,24 @@ def test_rollout_parity(wx200, cfg_name, K, with_imu):
     bt = WbcBatch(wx200, B)
     bt.configure(cfg)
     before = {k: v.copy() for k, v in d.items()}
-    got = bt.rollout(d, DT, K, ee_target_step=step, trunk_target_step=tstep, imu=imu)
-    assert all((d[k] == before[k]).all() for k in d)            # in0 is only read
     ok = ref["status"] == 0
     assert ok.mean() > 0.8
-    assert (got["status"] == ref["status"]).all()
-    # one tick agrees to ~1e-6 in qdot (cond(H) ~ 3e9); K ticks of dt = 2 ms integrate that into ~1e-8 of state
-    assert np.abs(got["q"] - ref["q"])[ok].max() < 1e-6
-    assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < 10 * QDOT_TOL
-    assert np.abs(got["ee_target"] - ref["ee_target"]).max() < 1e-15
-    assert np.abs(got["grip_trace"] - ref["grip_trace"])[:, ok].max() < 1e-6
-    assert (got["iters"][ok] - ref["iters"][ok]).__abs__().max() <= 2 * K
-    if imu is not None:
-        assert (got["q"][:, 3:7] == imu).all()
+    res = {}
+    for warm in (1, 0):      # default: every tick seeded with the previous tick's working set (f2); 0: cold, like the oracle's ticks
+        bt.set_option("warm_start", warm)
+        got = res[warm] = bt.rollout(d, DT, K, ee_target_step=step, trunk_target_step=tstep, imu=imu)
+        assert all((d[k] == before[k]).all() for k in d)            # in0 is only read
+        assert (got["status"] == ref["status"]).all(), warm
+        # one tick agrees to ~1e-6 in qdot (cond(H) ~ 3e9); K ticks of dt = 2 ms integrate that into ~1e-8 of state
+        assert np.abs(got["q"] - ref["q"])[ok].max() < 1e-6, warm
+        assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < 10 * QDOT_TOL, warm
+        assert np.abs(got["ee_target"] - ref["ee_target"]).max() < 1e-15
+        assert np.abs(got["grip_trace"] - ref["grip_trace"])[:, ok].max() < 1e-6, warm
+        if imu is not None:
+            assert (got["q"][:, 3:7] == imu).all()
+    assert (res[0]["iters"][ok] - ref["iters"][ok]).__abs__().max() <= 2 * K       # cold: the oracle's working-set changes
+    print("%s: working-set changes per tick: cold %.2f, warm-started %.2f (oracle %.2f)" % (
+        cfg_name, res[0]["iters"][ok].mean() / K, res[1]["iters"][ok].mean() / K, ref["iters"][ok].mean() / K))
     bt.close()
 
 
@@ -557,11 +562,22 @@ def test_rollout_equals_tick_plus_update_state(wx200):
     got = bt.rollout(d, DT, K, ee_target_step=step)
     s = {k: v.copy() for k, v in d.items()}
     for _ in range(K):
+        o = bt.tick(s, DT, want_q_next=True, want_working_set=True)
+        s["q"] = bt.update_state(s["q"], o["q_next"], s["ee_target"])
+        s["prev_ee_target"][:, 4] = s["ee_target"][:, 4]
+        s["ee_target"] = s["ee_target"] + step
+        s["working_set"] = o["working_set"]               # the roll-out hot-starts every tick from the previous one's working set
+    assert (got["q"] == s["q"]).all() and (got["qdot"] == o["qdot"]).all() and (got["ee_target"] == s["ee_target"]).all()
+    bt.set_option("warm_start", 0)                         # ... unless told not to: then it is the chain of cold ticks
+    cold = bt.rollout(d, DT, K, ee_target_step=step)
+    s = {k: v.copy() for k, v in d.items()}
+    for _ in range(K):
         o = bt.tick(s, DT, want_q_next=True)
         s["q"] = bt.update_state(s["q"], o["q_next"], s["ee_target"])
         s["prev_ee_target"][:, 4] = s["ee_target"][:, 4]
         s["ee_target"] = s["ee_target"] + step
-    assert (got["q"] == s["q"]).all() and (got["qdot"] == o["qdot"]).all() and (got["ee_target"] == s["ee_target"]).all()
+    assert (cold["q"] == s["q"]).all() and (cold["qdot"] == o["qdot"]).all()
+    assert np.abs(cold["q"] - got["q"]).max() < 1e-7       # same minimiser either way
     bt.close()
 
 
@@ -933,6 +949,7 @@ def test_rollout_warmup_mode_is_tick_plus_integrate(wx200):
     step[:, :, 2] = -1e-4
     bt = WbcBatch(wx200, B)
     bt.configure(cfg)
+    bt.set_option("warm_start", 0)
     got = bt.rollout(d, DT, K, ee_target_step=step, mode=capi.ROLLOUT_WARMUP, hold_ticks=Hd)
     assert got["grip_trace"].shape == (K + Hd, B, 3)
     s = {k: v.copy() for k, v in d.items()}
@@ -948,4 +965,64 @@ def test_rollout_warmup_mode_is_tick_plus_integrate(wx200):
             s["ee_target"] = s["ee_target"] + step
     assert np.abs(got["q"] - s["q"]).max() < 1e-12 and (got["ee_target"] == s["ee_target"]).all()
     assert np.abs(got["ee_target"] - (d["ee_target"] + K * step)).max() < 1e-15
+    bt.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["c3", "everything", "c2"])
+def test_warm_started_tick_reaches_the_cold_optimum(wx200, px100, cfg_name):
+    """SURVEY.md §8 f2 (QP_Wrapper.py:55-73, Robot_Wrapper4.py:1389-1394): a tick seeded with a working set — the previous
+    tick's, its own, another kernel's, or garbage — returns the cold tick's q̇ and status (H > 0: one minimiser), and a good
+    seed costs fewer working-set changes than the cold dual iterations."""
+    B = 2048
+    models = [wx200, px100]
+    cfgs = [common.config(cfg_name, m) for m in models]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=91 + i, with_rot=(cfg_name == "everything")) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
+    ok = ref["status"] == 0
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    # "previous tick": the same robots a moment earlier (targets 0.3 mm back)
+    prev = dict(d)
+    prev["ee_target"] = d["ee_target"] - 3e-4
+    p0 = bt.tick(prev, DT, want_working_set=True)
+    cold = bt.tick(d, DT, want_working_set=True)
+    assert (cold["status"] == ref["status"]).all()
+    assert (cold["working_set"][~ok] == 0).all()                          # an unsolved QP carries nothing
+    nact = np.array([bin(int(w) & (2 ** 64 - 1)).count("1") for w in cold["working_set"].ravel()]).reshape(B, 2).sum(axis=1)
+    rng = np.random.default_rng(3)
+    junk = rng.integers(-2 ** 62, 2 ** 62, (B, 2), dtype=np.int64)
+    opposite = np.stack([((w & 0xFFFFFFFF) << 32) | ((w >> 32) & 0xFFFFFFFF) for w in cold["working_set"].T], axis=1)
+    runs = {"previous tick": p0["working_set"], "own": cold["working_set"], "garbage": junk, "opposite sides": opposite}
+    its = {"cold": cold["iters"][ok].mean()}
+    for name, ws in runs.items():
+        got = bt.tick(dict(d, working_set=ws), DT, want_working_set=True)
+        assert (got["status"] == ref["status"]).all(), name
+        assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL, name
+        assert np.abs(got["qdot"] - cold["qdot"])[ok].max() < QDOT_TOL, name
+        its[name] = got["iters"][ok].mean()
+        if name == "own":
+            assert (got["working_set"][ok] == cold["working_set"][ok]).mean() > 0.98
+    # the working set means the same constraints on every kernel path: general-path sets seed the compact kernel and back
+    if cfg_name == "c3":
+        assert bt.stat("last_path") == 1
+        bt.set_option("sim3_kernel", 0)
+        bt.set_option("presolve", 0)
+        gen = bt.tick(dict(d, working_set=cold["working_set"]), DT, want_working_set=True)
+        assert np.abs(gen["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL and (gen["status"] == ref["status"]).all()
+        gen_cold = bt.tick(d, DT, want_working_set=True)
+        assert gen["iters"][ok].mean() <= gen_cold["iters"][ok].mean() + 1e-9
+        bt.set_option("sim3_kernel", 1)
+        bt.set_option("presolve", 1)
+        back = bt.tick(dict(d, working_set=gen_cold["working_set"]), DT)
+        assert np.abs(back["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+        its["general-path set into the compact kernel"] = back["iters"][ok].mean()
+        same = (gen_cold["working_set"][ok] == cold["working_set"][ok]).all(axis=1).mean()
+        assert same > 0.95, same                                           # both paths name the active constraints alike
+    print(cfg_name, "active inequalities per instance %.2f; working-set changes per tick:" % nact[ok].mean(),
+          ", ".join("%s %.2f" % kv for kv in its.items()))
+    assert its["own"] <= its["cold"] + 1e-9 and its["previous tick"] <= its["cold"] + 0.25
     bt.close()

@@ -174,3 +174,49 @@ def test_oracle_solution_is_the_exact_optimum_on_benchmark_ticks():
         H, g, C = a["H"][b], a["g"][b], a["C"][b]
         x = common.exact_optimum(H, g, C, a["lb"][b], a["ub"][b], a["Clb"][b], a["Cub"][b], t["qdot"][b])
         assert np.abs(t["qdot"][b] - x).max() < 2e-6, np.abs(t["qdot"][b] - x).max()
+
+
+def test_warm_started_variant_reaches_the_same_optimum():
+    """tests/gi_variant.py solve_v3 (the warm start the kernels run): seeded with (a) the cold solve's own
+    final working set, (b) that of a perturbed problem (the previous tick), (c) garbage, it returns the cold optimum; (a) needs no
+    dual iteration at all, and wrong seeds are removed by the restoration step, never kept."""
+    rng = np.random.default_rng(77)
+    n, p = 14, 10
+    cold_it, warm_it, warm_prev_it = 0, 0, 0
+    for trial in range(60):
+        A = rng.normal(size=(n + 4, n))
+        H = A.T @ A + 1e-3 * np.eye(n)
+        g = rng.normal(size=n) * 4
+        C = rng.normal(size=(p, n))
+        lb, ub = -rng.uniform(0.02, 0.5, n), rng.uniform(0.02, 0.5, n)
+        lb[-1] = ub[-1] = 0.0                                     # a locked variable
+        cl, cu = -rng.uniform(0.02, 0.5, p), rng.uniform(0.02, 0.5, p)
+        cl[0] = cu[0] = 0.05                                      # an equality row
+        xr, sr, _ = oracle.qp_solve(H[None], g[None], C[None], lb[None], ub[None], cl[None], cu[None])
+        xr, sr = xr[0], int(sr[0])
+        x0, s0, it0, ws0 = gi_variant.solve_v3(H, g, C, lb, ub, cl, cu)
+        assert s0 == sr
+        if sr != 0:
+            continue
+        assert np.abs(x0 - xr).max() < 1e-9
+        cold_it += it0
+        # (a) its own working set: everything is seeded, nothing left to do
+        x1, s1, it1, ws1 = gi_variant.solve_v3(H, g, C, lb, ub, cl, cu, seeds=ws0)
+        assert s1 == 0 and np.abs(x1 - xr).max() < 1e-9 and sorted(ws1) == sorted(ws0)
+        assert it1 == 2 + len(ws0)                               # the two equalities + one step per seed
+        warm_it += it1
+        # (b) the working set of the "previous tick" (g moved a little)
+        xp, sp, itp, wsp = gi_variant.solve_v3(H, g + rng.normal(size=n) * 0.15, C, lb, ub, cl, cu)
+        if sp == 0:
+            x2, s2, it2, _ = gi_variant.solve_v3(H, g, C, lb, ub, cl, cu, seeds=wsp)
+            assert s2 == 0 and np.abs(x2 - xr).max() < 1e-9
+            warm_prev_it += it2 - it0
+        # (c) garbage: random constraints on random sides, duplicates, equalities, out-of-range ids
+        junk = [(int(rng.integers(-2, n + p + 2)), int(rng.integers(0, 2))) for _ in range(rng.integers(1, 12))]
+        x3, s3, _, _ = gi_variant.solve_v3(H, g, C, lb, ub, cl, cu, seeds=junk)
+        assert s3 == 0 and np.abs(x3 - xr).max() < 1e-8, (trial, junk)
+        # (d) the opposite sides of the true working set: every seed must be thrown out again
+        x4, s4, _, ws4 = gi_variant.solve_v3(H, g, C, lb, ub, cl, cu, seeds=[(c, 1 - s) for c, s in ws0])
+        assert s4 == 0 and np.abs(x4 - xr).max() < 1e-8 and sorted(ws4) == sorted(ws0)
+    assert cold_it > 0 and warm_it <= cold_it
+    print("working-set changes: cold %d, seeded with the own set %d, with the previous tick's set %+d vs cold" % (cold_it, warm_it, warm_prev_it))
