@@ -150,7 +150,9 @@ typedef struct WbcTickIn {
                                                 object's working set): WbcTickOut.working_set of the previous tick. Word 0: velocity
                                                 bounds (bit d: DoF d at its lower bound, bit 32 + d: at its upper bound); word 1:
                                                 constraint rows in findConstraints' order (bit i: row i at Clb, bit 32 + i: at Cub).
-                                                Any bit pattern is safe (wrong guesses are dropped again); NULL or zeros => cold start */
+                                                Any bit pattern is accepted: a seed is used only if the equalities-only minimiser
+                                                violates it or comes close to it, and wrong seeds are dropped again (restoration
+                                                + refresh, wbc_kernels.hip qp_core); NULL or zeros => cold start */
 } WbcTickIn;
 
 #define WBC_Q_STRIDE 27   /* doubles per instance in q / q_next (nq of the largest model)           */

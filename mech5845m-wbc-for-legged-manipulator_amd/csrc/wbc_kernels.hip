@@ -445,23 +445,55 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   double y1 = 0.0;                        // lane k < q: y1_k
   const bool any_be = nseed > 0 || __ballot((eq_b && lb != 0.0) || (eq_r && clb != 0.0)) != 0;
   int qe = -1;                            // first inequality slot (= number of equalities taken); fixed when the first seed comes up
-  unsigned long long sb2 = sdm_b, sr2 = sdm_r;
+  unsigned long long sb2 = sdm_b, sr2 = sdm_r, okm_b = 0, okm_r = 0;
 #pragma unroll 1
   for (int e = 0; e < ntot; ++e) {
-    ++iters;
     const bool seed = WARM && e >= ne;    // uniform
     int scode = 0;
+    bool take = true;
     if (seed) {
-      if (qe < 0) qe = q;
-      if (sb2) { const int c = ctz64(sb2); sb2 &= sb2 - 1; scode = c | ((rdli(ws_b_in, c) == 2) ? 256 : 0); }
-      else { const int c = ctz64(sr2); sr2 &= sr2 - 1; scode = (n + c) | ((rdli(ws_r_in, c) == 2) ? 256 : 0); }
-    }
+      if (qe < 0) {
+        qe = q;
+        // Which seeds to take. x0 = the minimiser on the equalities alone (kept in S.npv: the anchor of the refresh further
+        // down). A seed is taken only if x0 violates it or comes close to it (within 0.25 max(1, |x0|_inf)): a constraint
+        // that is active at the solution almost always is, while a seed far on the feasible side (a velocity bound of tens of
+        // rad/s on a joint that hardly moves) would drag the iterate far away — harmless in exact arithmetic, but with
+        // cond(H) ~ 1e9 it costs digits along the weakly determined directions (tests/gi_variant.py solve_v3, `far`).
+        if (lane < 32) S.dv[lane] = (lane < q) ? y1 : ((lane < n) ? -bg : 0.0);
+        WSYNC();
+        double x0 = 0.0, x0b = 0.0;
+#pragma unroll
+        for (int k = 0; k < NM; k += 2) { const double2a v2 = lds2(S.dv + k); x0 = fma(y[k], v2.x, x0); x0b = fma(y[k + 1], v2.y, x0b); }
+        x0 += x0b;
+        if (lane >= n) x0 = 0.0;
+        const double near = 0.25 * fmax(1.0, -wmin(lane < 32 ? -fabs(x0) : 0.0));
+        if (lane < 32) S.npv[lane] = x0;
+        WSYNC();
+        bool okb = false, okr = false;
+        if (ws_b_in == 1) okb = (x0 - lb) <= near; else if (ws_b_in == 2) okb = (ub - x0) <= near;
+        if (p > 0) {
+          double v = 0.0, vb = 0.0;
+#pragma unroll
+          for (int k = 0; k < NM; k += 2) {
+            const double2a c2 = lds2(S.RC + (has_r ? lane : 0) * CS + k); const double2a x2 = lds2(S.npv + k);
+            v = fma(c2.x, x2.x, v); vb = fma(c2.y, x2.y, vb);
+          }
+          v += vb;
+          if (ws_r_in == 1) okr = (v - clb) <= near; else if (ws_r_in == 2) okr = (cub - v) <= near;
+        }
+        okm_b = __ballot(has_b && okb);
+        okm_r = __ballot(has_r && okr);
+      }
+      if (sb2) { const int c = ctz64(sb2); sb2 &= sb2 - 1; scode = c | ((rdli(ws_b_in, c) == 2) ? 256 : 0); take = (okm_b >> c) & 1ull; }
+      else { const int c = ctz64(sr2); sr2 &= sr2 - 1; scode = (n + c) | ((rdli(ws_r_in, c) == 2) ? 256 : 0); take = (okm_r >> c) & 1ull; }
+    } else ++iters;
     const double d = bq[0];
     const double zn = wsum(lane >= q ? d * d : 0.0);
     const double dy = any_be ? wsum(lane < q ? d * y1 : 0.0) : 0.0;   // y1 stays 0 when every right-hand side is 0
     const double b_e = S.dinv[e], np2 = S.lv[e];
     double beta = 0.0, v = 0.0;
-    if (zn > 100.0 * n * EPS2 * jf2 * np2) {
+    if (take && zn > 100.0 * n * EPS2 * jf2 * np2) {
+      if (seed) ++iters;
       const double dq = rdl(d, q);
       const double sz = sqrt(zn);
       const double delta = (dq >= 0.0) ? -sz : sz;
@@ -558,6 +590,7 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   // backwards: x <- x - u_l z, u <- u + u_l r with z, r of the dropped constraint on the new factors); what is left is an S-pair
   // (x minimises on the working set, u >= 0) and the dual iterations start from it.
   bool restoring = WARM && q > qe;
+  bool did_restore = false, refreshed = false;
 #pragma unroll 1
   for (;;) {
     int wc;
@@ -566,7 +599,52 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
     if (WARM && restoring) {
       const bool slot = lane >= qe && lane < q;
       const double um = wmin((lane < 32 && slot) ? u : 0.0);
-      if (!(um < 0.0)) { restoring = false; continue; }
+      if (!(um < 0.0)) {
+        restoring = false;
+        if (did_restore && !refreshed) {
+          // REFRESH. x and u went through the iterates the wrong seeds put them at, and with cond(H) ~ 1e9 that costs
+          // digits; the factors J and T did not (orthogonal updates only). Rebuild x and u from them: with s_j = b_j - n_j'x0
+          // the slacks of the remaining slots at the equalities-only minimiser x0 (S.npv),
+          //   w = T's,  x = x0 + J[:, qe:q] w,  u = T w      — then one more restoration pass on the accurate multipliers.
+          refreshed = true;
+          const double x0 = S.npv[lane & 31];
+          double v0 = 0.0;
+          if (p > 0) {
+            double vb = 0.0;
+#pragma unroll
+            for (int k = 0; k < NM; k += 2) {
+              const double2a c2 = lds2(Cm + (has_r ? lane : 0) * CS + k); const double2a x2 = lds2(S.npv + k);
+              v0 = fma(c2.x, x2.x, v0); vb = fma(c2.y, x2.y, vb);
+            }
+            v0 += vb;
+          }
+          if (lane < 32) {
+            S.xv[lane] = has_b ? (side_b ? x0 - ub : lb - x0) : 0.0;
+            S.yv[lane] = has_r ? (side_r ? v0 - cub : clb - v0) : 0.0;
+          }
+          WSYNC();
+          const int cc = a_code & 255;
+          const double sj = slot ? ((cc < n) ? S.xv[cc & 31] : S.yv[(cc - n) & 31]) : 0.0;
+          if (lane < 32) S.dv[lane] = sj;
+          WSYNC();
+          double w = 0.0;
+#pragma unroll 1
+          for (int j = qe; j < q; ++j) w = fma(T[j * LDJ + li], S.dv[j], w);
+          if (!slot) w = 0.0;
+          WSYNC();
+          if (lane < 32) S.dv[lane] = w;
+          WSYNC();
+          double xa = 0.0, ua = 0.0;
+#pragma unroll 1
+          for (int k = qe; k < q; ++k) { const double wk = S.dv[k]; xa = fma(J[li * LDJ + k], wk, xa); ua = fma(T[li * LDJ + k], wk, ua); }
+          x = (lane < n) ? x0 + xa : 0.0;
+          u = slot ? ua : 0.0;
+          WSYNC();
+          restoring = true;
+        }
+        continue;
+      }
+      did_restore = true;
       drop_l = ctz64(__ballot(slot && u == um));
       u_l = um;
       wc = rdli(a_code, drop_l);

@@ -298,7 +298,7 @@ def solve_v2(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, max_iter=None):
             s_ip = (-1.0 if side else 1.0) * value(ip, x) - b_ip
 
 
-def solve_v3(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, seeds=(), max_iter=None):
+def solve_v3(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, seeds=(), max_iter=None, refresh=True, far=0.1):
     """Kernel v3 algebra = solve_v2 + WARM START (the hot-start analogue of QP_Wrapper.py:55-73):
     `seeds` = [(constraint, side)] carried over from the previous tick's final working set.
       1. the seeds go through the same Householder QR as the equalities (cheap, register resident on the wavefront), each one
@@ -353,12 +353,22 @@ def solve_v3(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, seeds=(), max_i
                 not any(t[0] == c for t in todo):
             todo.append((c, side, False))
     todo = todo[:n]
+    x0f = None
     for c, side, eq in todo:
         if not eq and qe is None:
             qe = q
-        iters += 1
         npv = normal(c, side)
         b_e = lo(c) if side == 0 else -hi(c)
+        if not eq and far is not None:
+            # a seed is taken only if the equalities-only minimiser violates it or comes close to it: a constraint that is
+            # active at the solution almost always is, and a seed far on the feasible side (a velocity bound of tens of rad/s
+            # for a joint that hardly moves) would drag the iterate far away — harmless in exact arithmetic, digits at cond(H) ~ 1e9
+            if x0f is None:
+                dg0 = J.T @ g
+                x0f = J @ np.concatenate([y1[:q], -dg0[q:]])
+            if npv @ x0f - b_e > far * max(1.0, np.abs(x0f).max()):
+                continue
+        iters += 1
         d = J.T @ npv
         zn = d[q:] @ d[q:]
         dy = d[:q] @ y1[:q]
@@ -385,6 +395,8 @@ def solve_v3(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, seeds=(), max_i
         qe = q
     dg = J.T @ g
     x = J @ np.concatenate([y1[:q], -dg[q:]])
+    # the equalities-only minimiser (independent of whatever happens to the columns >= qe): anchor of the refresh below
+    x0 = J @ np.concatenate([y1[:qe], -dg[qe:]])
     u = np.zeros(n + 1)
     u[:q - qe] = T[qe:q, qe:q] @ (y1[qe:q] + dg[qe:q])
 
@@ -414,6 +426,7 @@ def solve_v3(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, seeds=(), max_i
         q -= 1
 
     # ---- restoration of dual feasibility
+    restored = False
     while q > qe and u[:q - qe].min() < 0.0:
         iters += 1
         if iters > max_iter:
@@ -427,6 +440,29 @@ def solve_v3(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, seeds=(), max_i
         r = T[qe:q, qe:q] @ d[qe:q]
         x = x - ul * z
         u[:q - qe] += ul * r
+        restored = True
+    if refresh and restored:
+        # x and u went through iterates as far away as the wrong seeds put them (a velocity bound is tens of rad/s), and with
+        # cond(H) ~ 1e9 that costs digits. The factors J, T did not (orthogonal updates only): rebuild x and u from them.
+        # With s_j = b_j - n_j'x0 the slacks of the remaining inequality slots at the equalities-only minimiser x0:
+        #   w = T's,  x = x0 + J[:, qe:q] w,  u = T w
+        sl = np.array([(lo(c) if sd == 0 else -hi(c)) - normal(c, sd) @ x0 for c, sd in act])
+        Tb = T[qe:q, qe:q]
+        w = Tb.T @ sl
+        x = x0 + J[:, qe:q] @ w
+        u[:q - qe] = Tb @ w
+        # (the refreshed multipliers may show a sign the drifted ones hid: restore once more on the accurate values)
+        while q > qe and u[:q - qe].min() < 0.0:
+            iters += 1
+            l = int(np.argmin(u[:q - qe]))
+            ul = u[l]
+            c, side = act[l]
+            drop(l)
+            d = J.T @ normal(c, side)
+            z = J[:, q:] @ d[q:]
+            r = T[qe:q, qe:q] @ d[qe:q]
+            x = x - ul * z
+            u[:q - qe] += ul * r
     # ---- dual iterations (solve_v2's inequality phase)
     while True:
         worst, ip = 0.0, -1
