@@ -1286,7 +1286,7 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
 // One instance: FK -> Jacobians -> task stack -> H, g, C, bounds [-> QP -> qdot -> q_next]
 // (inputs already staged in S.in)
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool WARM = false>
 __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
                                                  const DevPlan& P, const LaneConst& lc, const InRegs& inr, const int b,
                                                  const int lane, const unsigned long long t_entry = 0) {
@@ -1631,12 +1631,12 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
 #endif
   if (!contact_presolve(S, A, M, cfg, P, dpost, g, lb, ub, clb, cub, lane, ts, res)) {
     // warm start in the problem's own indexing: lane d <-> bound of DoF d, lane i <-> constraint row i
-    const unsigned long long w0 = A.ws_in ? A.ws_in[2 * (size_t)b] : 0ull, w1 = A.ws_in ? A.ws_in[2 * (size_t)b + 1] : 0ull;
+    const unsigned long long w0 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b] : 0ull, w1 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b + 1] : 0ull;
     const int sb = (lane < 32) ? (int)(((w0 >> lane) & 1ull) | (((w0 >> (32 + lane)) & 1ull) << 1)) : 0;
     const int sr = (lane < 32) ? (int)(((w1 >> lane) & 1ull) | (((w1 >> (32 + lane)) & 1ull) << 1)) : 0;
-    res = qp_core<NV, Smem, LDJ, true>(S, g, lb, ub, clb, cub, nv, A.prows, lane, ts, 0, sb == 3 ? 0 : sb, sr == 3 ? 0 : sr);
+    res = qp_core<NV, Smem, LDJ, WARM>(S, g, lb, ub, clb, cub, nv, A.prows, lane, ts, 0, sb == 3 ? 0 : sb, sr == 3 ? 0 : sr);
   }
-  if (A.ws_out) {   // (the in-kernel presolve path runs cold and carries nothing: res.ws_* = 0 there)
+  if (WARM && A.ws_out) {   // (the in-kernel presolve path runs cold and carries nothing: res.ws_* = 0 there)
     const unsigned long long o0 = (__ballot(res.ws_b == 1) & 0xFFFFFFFFull) | (__ballot(res.ws_b == 2) << 32);
     const unsigned long long o1 = (__ballot(res.ws_r == 1) & 0xFFFFFFFFull) | (__ballot(res.ws_r == 2) << 32);
     if (lane == 0) { A.ws_out[2 * (size_t)b] = o0; A.ws_out[2 * (size_t)b + 1] = o1; }
@@ -1682,7 +1682,8 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
 // kernels: single-wave workgroups, one per instance for the tick kernels (the QP / integrate kernels walk the batch with a
 // grid-stride loop whose exit, b >= B, every wave reaches).
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+// WARM: the variant that reads / writes working sets (warm start, KernelArgs.ws_in / ws_out); the cold variant carries none of it
+template <int MODE, bool WARM = false>
 __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                          const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   // models / cfgs are separate __restrict__ const parameters so that the compiler may read them with scalar loads
@@ -1709,7 +1710,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
   const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);   // L1/L2-resident 3 KB table
   stage_inputs(S, cur, lane, has2, has3);
   WSYNC();
-  process_instance<MODE>(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane, t_entry);
+  process_instance<MODE, WARM>(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane, t_entry);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1771,6 +1772,7 @@ __device__ __forceinline__ void jtj_block_c(SmemC& S, const double* At, const in
 #define DBG_STOP_ARG 0
 #endif
 
+template <bool WARM>
 __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
                                              const DevPlan& P, const Hdr& H, const LaneConst& lc, const InRegs& inr,
                                              const int b, const int lane, const unsigned long long ws0, const unsigned long long ws1) {
@@ -2132,17 +2134,19 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   // warm start: the carried working set (full-problem indexing, KernelArgs.ws_in) seen from the reduced problem — reduced
   // variable k is DoF Fd[k]; reduced row r is kept row my_orig or, from p_keep on, the velocity bound of an eliminated leg DoF
   int sd_b = 0, sd_r = 0;
-  if (lane < n_red) sd_b = (int)(((ws0 >> fj) & 1ull) | (((ws0 >> (32 + fj)) & 1ull) << 1));
-  if (my_orig >= 0) sd_r = (int)(((ws1 >> my_orig) & 1ull) | (((ws1 >> (32 + my_orig)) & 1ull) << 1));
-  else if (c_use_bounds && lane >= p_keep && lane < p_keep + nl) sd_r = (int)(((ws0 >> my_legd) & 1ull) | (((ws0 >> (32 + my_legd)) & 1ull) << 1));
-  QpResult res = qp_core<NR, SmemC, CSC, true>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, DBG_STOP_ARG,
+  if (WARM) {
+    if (lane < n_red) sd_b = (int)(((ws0 >> fj) & 1ull) | (((ws0 >> (32 + fj)) & 1ull) << 1));
+    if (my_orig >= 0) sd_r = (int)(((ws1 >> my_orig) & 1ull) | (((ws1 >> (32 + my_orig)) & 1ull) << 1));
+    else if (c_use_bounds && lane >= p_keep && lane < p_keep + nl) sd_r = (int)(((ws0 >> my_legd) & 1ull) | (((ws0 >> (32 + my_legd)) & 1ull) << 1));
+  }
+  QpResult res = qp_core<NR, SmemC, CSC, WARM>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, DBG_STOP_ARG,
                                                sd_b == 3 ? 0 : sd_b, sd_r == 3 ? 0 : sd_r);
   res.iters += nl;
   // ---- x = Z y
   WSYNC();
-  if (lane < 32) { S.xv[lane] = (lane < n_red) ? res.x : 0.0; S.lv[lane] = (double)res.ws_b; S.dinv[lane] = (double)res.ws_r; }
+  if (lane < 32) { S.xv[lane] = (lane < n_red) ? res.x : 0.0; if (WARM) { S.lv[lane] = (double)res.ws_b; S.dinv[lane] = (double)res.ws_r; } }
   WSYNC();
-  if (A.ws_out) {   // the final working set back in full-problem indexing: lane d = DoF d, lane i = original constraint row i
+  if (WARM && A.ws_out) {   // the final working set back in full-problem indexing: lane d = DoF d, lane i = original constraint row i
     int cb = 0, cr = 0;
     if (my_pos >= 0) cb = (int)S.lv[my_pos];
     else if (my_l >= 0 && c_use_bounds) cb = (int)S.dinv[(p_keep + my_l) & 31];
@@ -2190,6 +2194,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
 #endif
 }
 
+template <bool WARM>
 __global__ void __launch_bounds__(64, 3) wbc_tick_sim3_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                               const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   __shared__ SmemC S;
@@ -2203,10 +2208,10 @@ __global__ void __launch_bounds__(64, 3) wbc_tick_sim3_kernel(const KernelArgs A
   Hdr H = load_hdr(models[mid]);                 // one batch of scalar loads, waited for once
   asm volatile("" : "+s"(H.nq), "+s"(H.nv), "+s"(H.nj), "+s"(H.maxdepth), "+s"(H.nframes), "+s"(H.trunk_joint));
   // the carried working set (warm start): two uniform words, fetched with the other inputs
-  const unsigned long long ws0 = A.ws_in ? A.ws_in[2 * (size_t)b] : 0ull, ws1 = A.ws_in ? A.ws_in[2 * (size_t)b + 1] : 0ull;
+  const unsigned long long ws0 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b] : 0ull, ws1 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b + 1] : 0ull;
   stage_inputs(S, cur, lane, has2, false);
   WSYNC();
-  process_sim3(S, A, models[mid], cfgs[mid], plans[mid], H, lc, cur, b, lane, ws0, ws1);
+  process_sim3<WARM>(S, A, models[mid], cfgs[mid], plans[mid], H, lc, cur, b, lane, ws0, ws1);
 }
 
 // Second pass after wbc_tick_sim3_kernel: the instances it deferred (a stance-leg block it could not eliminate) are redone on
@@ -2236,7 +2241,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_deferred_kernel(const KernelAr
     const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);
     stage_inputs(S, cur, lane, has2, has3);
     WSYNC();
-    process_instance<MODE_TICK>(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane, 0ull);
+    process_instance<MODE_TICK, true>(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane, 0ull);
     WSYNC();
   }
 }
@@ -2574,13 +2579,15 @@ static int check_launch(const char* what) {
 
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (mode == MODE_TICK) hipLaunchKernelGGL(wbc_tick_kernel<MODE_TICK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
+  if (mode == MODE_TICK && (a.ws_in || a.ws_out)) hipLaunchKernelGGL((wbc_tick_kernel<MODE_TICK, true>), dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
+  else if (mode == MODE_TICK) hipLaunchKernelGGL(wbc_tick_kernel<MODE_TICK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
   else if (mode == MODE_ASSEMBLE) hipLaunchKernelGGL(wbc_tick_kernel<MODE_ASSEMBLE>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
   else hipLaunchKernelGGL(wbc_tick_kernel<MODE_FK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
   return check_launch("tick");
 }
 int launch_tick_sim3(const KernelArgs& a, int grid, void* stream) {
-  hipLaunchKernelGGL(wbc_tick_sim3_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  if (a.ws_in || a.ws_out) hipLaunchKernelGGL(wbc_tick_sim3_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  else hipLaunchKernelGGL(wbc_tick_sim3_kernel<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   return check_launch("tick_sim3");
 }
 int launch_tick_deferred(const KernelArgs& a, void* stream) {
