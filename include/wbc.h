@@ -302,8 +302,11 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          instances whose leg blocks it could not eliminate); 0: the general kernel does the elimination.
  *   "presolve_tol_exp" [7] a stance-leg 3 x 3 block K with |det K| <= 10^-value (sum |K_ij|)^3 is treated as singular
  *                          (0: every block, i.e. the fallback for singular blocks is forced on every instance).
- *   "warm_start"       [1] wbc_rollout carries every instance's final working set into its next tick (the hot start the
+ *   "warm_start"       [0] 1: wbc_rollout carries every instance's final working set into its next tick (the hot start the
  *                          reference gets from QP.solveQPHotstart, Robot_Wrapper4.py:1389-1394); 0: every tick starts cold.
+ *                          Same minimiser either way (H > 0). Off by default because it measured 4 % SLOWER on MI355X
+ *                          (profiles/r02_rollout_warm_vs_cold.txt): a sim3 tick has ~1.6 active inequalities, and seeding them
+ *                          costs the wavefront as much as the ~1.6 dual iterations it replaces.
  *                          (wbc_tick is warm exactly when WbcTickIn.working_set is passed.)
  *   "grid"                 workgroups of the grid-stride kernels (wbc_qp_solve*, wbc_integrate); default = what fills the chip.
  *   "dbg_alias_inputs" [0] diagnostic: every instance reads instance 0's inputs (isolates input latency in timings).

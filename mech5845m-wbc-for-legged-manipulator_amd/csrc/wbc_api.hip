@@ -46,7 +46,7 @@ struct WbcBatch {
   int sim3_kernel;       // 1 (default): batches that qualify run on wbc_tick_sim3_kernel (compact LDS) + a deferred pass
   int32_t* d_status;     // status buffer of our own when the caller passes none (the deferred pass needs one)
   int dbg_alias, dbg_stop;
-  int warm_start;        // 1 (default): wbc_rollout carries each instance's working set from tick to tick
+  int warm_start;        // 1: wbc_rollout carries each instance's working set from tick to tick (default 0: measured slower)
   int32_t* d_defer;      // [1 + max_batch]: count + compact list of the instances the sim3 kernel deferred (lazy)
   int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass)
   int max_nj, max_nf;    // FK output strides: the largest model's joint / frame counts
@@ -144,7 +144,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
   b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
-  b->jtj_mfma = -1; b->warm_start = 1;
+  b->jtj_mfma = -1; b->warm_start = 0;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }

@@ -387,7 +387,7 @@ class WbcBatch:
                  trunk_prev_rot=np.zeros((B, 9)))                          # old_ref_trunk_rot_matrix = zeros before initialiseWBC (:150)
         if mid is not None:
             d["model_id"] = mid
-        warm = getattr(self, "_options", {}).get("warm_start", 1)
+        warm = getattr(self, "_options", {}).get("warm_start", 0)
         self.set_option("warm_start", 0)                                   # the reference builds a fresh QP object every iteration (:320): cold
         try:
             ro = self.rollout(d, dt, n, ee_target_step=(goal - ee) / n, want_trace=False, mode=capi.ROLLOUT_WARMUP, hold_ticks=n)

@@ -559,6 +559,7 @@ def test_rollout_equals_tick_plus_update_state(wx200):
     step[:, 4] = [1e-4, -5e-5, 2e-5]
     bt = WbcBatch(wx200, B)
     bt.configure(cfg)
+    bt.set_option("warm_start", 1)
     got = bt.rollout(d, DT, K, ee_target_step=step)
     s = {k: v.copy() for k, v in d.items()}
     for _ in range(K):
