@@ -263,10 +263,18 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
   if (!nelim || !c.task_joint || c.task_com) return;
   for (int e = 0; e < WBC_NEE; ++e) if (c.task_ee[e] && (M.frame_support[WBC_FR_EE0 + e] & legmask)) return;
   if (c.task_trunk && (M.frame_support[WBC_FR_TRUNK] & legmask)) return;
-  const int n_red = M.nv - 3 * nelim, p_keep = prows - 3 * nelim;
+  // DoF the velocity box locks at 0 (lb = ub = 0 from lock_from on, Robot_Wrapper4.py:627-630) are known: they leave the reduced
+  // problem altogether (their q̇ is 0, they contribute to nothing else) — which also leaves room in qp_core<16> for the
+  // extra unknown a rank-deficient stance-leg block keeps (pivoted elimination in wbc_tick_sim3_kernel)
+  uint32_t lockmask = 0;
+  if (c.use_bounds) for (int d = c.lock_from; d < M.nv; ++d) if (d >= 6 && !((legmask >> d) & 1u)) lockmask |= 1u << d;
+  // (exact whatever rows touch them: a column that multiplies a velocity fixed at 0 contributes to nothing)
+  const int nlock = __builtin_popcount(lockmask);
+  const int n_red = M.nv - 3 * nelim - nlock, p_keep = prows - 3 * nelim;
   if (n_red > WBC_PLAN_NR || n_red < 6 || p_keep + (c.use_bounds ? 3 * nelim : 0) > WBC_MAX_P) return;
   int cnt = 0;
-  for (int d = 0; d < M.nv; ++d) if (!((legmask >> d) & 1u)) { P->pos[d] = cnt; P->Fd[cnt++] = d; }
+  for (int d = 0; d < M.nv; ++d) if (!(((legmask | lockmask) >> d) & 1u)) { P->pos[d] = cnt; P->Fd[cnt++] = d; }
+  P->nlock = nlock;
   for (int f = 0; f < M.nframes; ++f)
     for (int d = 0; d < M.nv; ++d)
       if (((M.frame_support[f] >> d) & 1u) && P->pos[d] >= 0) P->redsup[f] |= 1u << P->pos[d];

@@ -36,6 +36,7 @@ struct DevModel {
 constexpr int WBC_QP_DEFERRED = -1;     // internal status: set by wbc_tick_sim3_kernel, never visible to the caller
 struct DevPlan {
   int32_t enabled, nelim, n_red, p_keep;
+  int32_t nlock, pad_[3];            // DoF locked at 0 by the velocity box (>= lock_from, use_bounds): left out of the reduced problem
   uint32_t elimrows;                 // bit i: constraint row i belongs to an eliminated foot
   uint32_t legrows;                  // bit i: kept constraint row i has support on eliminated leg DoF (needs C Z)
   // qpJointb "MANI"/"HYBRID" when EVERY finite difference is structurally zero (the perturbed joint is not a proper ancestor

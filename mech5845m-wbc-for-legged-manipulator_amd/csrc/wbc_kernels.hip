@@ -1131,7 +1131,7 @@ __device__ __forceinline__ void fk_pass(SM& S, double* const oMi, const double* 
 // LDS: G lives at RB[16 LDJ ..] (rows >= 16 of RB are never touched by qp_core<16>, so it survives the solve).
 // ------------------------------------------------------------------------------------------------
 constexpr int NR = WBC_PLAN_NR;        // compiled size cap of the reduced problem (16)
-constexpr int GS = 8;                  // row stride of G
+constexpr int GS = 10;                 // row stride of G: 6 base columns + up to 4 extra unknowns (one per rank-deficient stance-leg block)
 __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
                                                  const DevPlan& P, const double dpost, const double g, const double lb,
                                                  const double ub, const double clb, const double cub, const int lane,
@@ -1139,7 +1139,7 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
   if (!A.presolve || !P.enabled) return false;
   const int nv = M.nv, p = A.prows;
   const int nelim = P.nelim, n_red = P.n_red, nl = 3 * nelim;
-  double* const Gm = S.RB + NR * LDJ;            // [12][GS]: row l = eliminated leg DoF l, columns = base DoF
+  double* const Gm = S.RB + NR * LDJ;            // [12][GS]: row l = eliminated leg DoF l, columns = base DoF (the extra columns stay unused here)
   double* const Cm = S.RC;
   // the plan's index maps, fetched up front in one batch of scalar loads (loaded where they are used, each value costs
   // its own s_load + full wait inside the dependent chain: profiles/r01_phase_cycles_v9a.json, 29k cycles of presolve)
@@ -1267,7 +1267,7 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
   WSYNC();
   STAMP(ts, T_PRE);
   res = qp_core<NR>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
-  res.iters += nl;                                   // the eliminated equalities, so that `iters` keeps its meaning
+  res.iters += nl + P.nlock;                         // the eliminated equalities and the locked DoF, so that `iters` keeps its meaning
   // ---- x = Z y
   WSYNC();
   if (lane < 32) S.xv[lane] = (lane < n_red) ? res.x : 0.0;
@@ -1732,7 +1732,7 @@ struct __attribute__((aligned(16))) SmemC {
   double pf[WBC_MAX_FRAMES * 3];
   double dv[32], xv[32], npv[32], lv[32], dinv[32], yv[32];
   double cl[48];                        // Cholesky column broadcast; entries 16..47 stay zero
-  double Gm[12 * GS];                   // G: eliminated leg DoF l (row) x base DoF (column)
+  double Gm[12 * GS];                   // G: eliminated leg DoF l (row) x [base DoF | extra unknowns of the pivoted feet] (column)
 };
 
 // H'[lane][k] += sum_r At[k][row0 + r] At[lane][row0 + r] for the reduced variables k in `mask`
@@ -2040,7 +2040,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
 
   // ---- G_e = -K_e^-1 B_e, all feet at once (see contact_presolve)
   double* const Gm = S.Gm;
-  bool singular = false;
+  unsigned smask = 0;                  // feet whose leg block K_e is (numerically) rank deficient
   {
     const int f = (lane < 24) ? lane / 6 : 0, c = (lane < 24) ? lane - 6 * f : 0;
     int d0 = legd[0], d1 = legd[1], d2 = legd[2], rs = rowstart[0];
@@ -2056,7 +2056,8 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     const double det = k00 * a00 + k01 * a10 + k02 * a20;
     const double sc = fabs(k00) + fabs(k01) + fabs(k02) + fabs(k10) + fabs(k11) + fabs(k12) + fabs(k20) + fabs(k21) + fabs(k22);
     const bool live = lane < 6 * nelim;
-    singular = __ballot(live && !(fabs(det) > A.sing_tol * sc * sc * sc)) != 0;
+    const unsigned long long sb = __ballot(live && c == 0 && !(fabs(det) > A.sing_tol * sc * sc * sc));   // lanes 0, 6, 12, 18
+    smask = (unsigned)((sb & 1ull) | ((sb >> 5) & 2ull) | ((sb >> 10) & 4ull) | ((sb >> 15) & 8ull));
     const double id = -1.0 / det;
     if (lane < 24) {
       Gm[(3 * f + 0) * GS + c] = live ? id * (a00 * b0 + a01 * b1 + a02 * b2) : 0.0;
@@ -2064,27 +2065,123 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
       Gm[(3 * f + 2) * GS + c] = live ? id * (a20 * b0 + a21 * b1 + a22 * b2) : 0.0;
     }
   }
-  if (singular) {   // left to the general kernel's second pass: appended to the compact list that pass walks
-    if (lane == 0) {
-      A.out.status[b] = WBC_QP_DEFERRED;
-      const int slot = atomicAdd(A.defer, 1);
-      A.defer[1 + slot] = b;
-    }
+  // ---- PIVOTED ELIMINATION of a rank-deficient leg block (rare; uniform branch). K_e P = Q R by column-pivoted Gram-Schmidt
+  // (third direction = q0 x q1, so nothing is divided by the small pivot): with z = P'q̇_leg the contact rows read
+  // Q'B q̇_base + R z = 0. The first two are solved for z0, z1 as before; the third, (Q'B)_2 q̇_base + r22 z2 = 0, is KEPT as an
+  // equality row of the reduced QP and z2 — the velocity of the leg DoF pivoted last — stays an unknown of its own (reduced
+  // variable n_red + j, column 6 + j of G). Exact, and as well conditioned as the rank-2 part of K_e; nothing is deferred unless a
+  // block has rank < 2. Per flagged foot f, lane f does the 3 x 3 work; E (the kept equality row) and the pivot index go to the
+  // dead tail of S.in.
+  int nsing = 0;
+  double* const Em = S.in + 96;        // [4][8]: 6 base coefficients, r22, index l of the leg DoF kept as unknown
+  if (smask) {
+    nsing = __popc(smask);
+    bool bad_rank = false;
+    if (lane < 48) Gm[(lane >> 2) * GS + 6 + (lane & 3)] = 0.0;     // extra columns of every row
     WSYNC();
-    return;
+    if (lane < 4 && ((smask >> lane) & 1u)) {
+      const int f = lane, j = __popc(smask & ((1u << f) - 1u));
+      int rs = rowstart[0], d0 = legd[0], d1 = legd[1], d2 = legd[2];
+#pragma unroll
+      for (int t = 1; t < 4; ++t) { const bool m = f == t; d0 = m ? legd[3 * t] : d0; d1 = m ? legd[3 * t + 1] : d1; d2 = m ? legd[3 * t + 2] : d2; rs = m ? rowstart[t] : rs; }
+      const double* r0 = Co + rs * LDJ; const double* r1 = r0 + LDJ; const double* r2 = r1 + LDJ;
+      // columns of K (as 3-vectors)
+      double ca[3] = {r0[d0], r1[d0], r2[d0]}, cb[3] = {r0[d1], r1[d1], r2[d1]}, cc[3] = {r0[d2], r1[d2], r2[d2]};
+      const double na = ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2], nb = cb[0] * cb[0] + cb[1] * cb[1] + cb[2] * cb[2],
+                   nc = cc[0] * cc[0] + cc[1] * cc[1] + cc[2] * cc[2];
+      // first pivot: the longest column -> (u, then v, w the other two in index order)
+      const int p0 = (na >= nb && na >= nc) ? 0 : ((nb >= nc) ? 1 : 2);
+      double u[3], v[3], w[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        u[i] = (p0 == 0) ? ca[i] : (p0 == 1) ? cb[i] : cc[i];
+        v[i] = (p0 == 0) ? cb[i] : ca[i];
+        w[i] = (p0 == 2) ? cb[i] : cc[i];
+      }
+      const int iv = (p0 == 0) ? 1 : 0, iw = (p0 == 2) ? 1 : 2;
+      const double r00 = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+      const double q0[3] = {u[0] / r00, u[1] / r00, u[2] / r00};
+      const double rv = q0[0] * v[0] + q0[1] * v[1] + q0[2] * v[2], rw = q0[0] * w[0] + q0[1] * w[1] + q0[2] * w[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { v[i] = fma(-rv, q0[i], v[i]); w[i] = fma(-rw, q0[i], w[i]); }
+      const double nv2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], nw2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+      const bool sw = nw2 > nv2;                       // second pivot: the longer remainder
+      const int p1 = sw ? iw : iv, p2 = sw ? iv : iw;
+      const double r01 = sw ? rw : rv, r02 = sw ? rv : rw;
+      double s1[3], s2[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { s1[i] = sw ? w[i] : v[i]; s2[i] = sw ? v[i] : w[i]; }
+      const double r11 = sqrt(sw ? nw2 : nv2);
+      const double q1[3] = {s1[0] / r11, s1[1] / r11, s1[2] / r11};
+      const double r12 = q1[0] * s2[0] + q1[1] * s2[1] + q1[2] * s2[2];
+      double q2[3];
+      cross3(q0, q1, q2);
+      const double r22 = q2[0] * s2[0] + q2[1] * s2[1] + q2[2] * s2[2];
+      bad_rank = !(r11 > 1e-9 * r00) || !(r00 > 0.0);    // rank < 2 (or NaN): nothing sensible to eliminate
+      // Q'B, then back substitution
+      const int l0 = 3 * f + p0, l1 = 3 * f + p1, l2 = 3 * f + p2;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double bx = r0[c], by = r1[c], bz = r2[c];
+        const double t0 = q0[0] * bx + q0[1] * by + q0[2] * bz, t1 = q1[0] * bx + q1[1] * by + q1[2] * bz,
+                     t2 = q2[0] * bx + q2[1] * by + q2[2] * bz;
+        const double g1 = -t1 / r11;
+        Gm[l1 * GS + c] = g1;
+        Gm[l0 * GS + c] = -(t0 + r01 * g1) / r00;
+        Gm[l2 * GS + c] = 0.0;
+        Em[8 * f + c] = t2;
+      }
+      const double g1x = -r12 / r11;
+      Gm[l1 * GS + 6 + j] = g1x;
+      Gm[l0 * GS + 6 + j] = -(r01 * g1x + r02) / r00;
+      Gm[l2 * GS + 6 + j] = 1.0;
+      Em[8 * f + 6] = r22;
+      Em[8 * f + 7] = (double)l2;
+    }
+    if (__ballot(bad_rank) || n_red + nsing > NR) {   // left to the general kernel's second pass (compact list)
+      if (lane == 0) {
+        A.out.status[b] = WBC_QP_DEFERRED;
+        const int slot = atomicAdd(A.defer, 1);
+        A.defer[1 + slot] = b;
+      }
+      WSYNC();
+      return;
+    }
   }
   WSYNC();
   STAMP(ts, T_P1);
+  // per-lane views of the extra unknowns (all -1 / 0 without pivoted feet): ex_f = foot whose kept leg velocity is reduced
+  // variable `lane`, ex_l its leg index, ex_d its DoF; my_x = reduced position of DoF `lane` if it is such a kept velocity
+  const int n_eff = n_red + nsing;
+  int ex_f = -1, ex_l = -1, my_x = -1;
+  if (nsing) {
+    int cnt = 0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      if ((smask >> f) & 1u) {                     // uniform
+        const int l2 = (int)Em[8 * f + 7];
+        if (lane == n_red + cnt) { ex_f = f; ex_l = l2; }
+        if (my_l == l2) my_x = n_red + cnt;
+        ++cnt;
+      }
+    }
+  }
+  int ex_d = 0;
+#pragma unroll
+  for (int l = 0; l < 12; ++l) ex_d = (ex_l == l) ? legd[l] : ex_d;
+  const bool is_ex = ex_f >= 0;
+  const int fjb = is_ex ? ex_d : fj;   // DoF whose velocity bound / carried working-set bit belongs to reduced variable `lane`
   double gcol[12];
 #pragma unroll
-  for (int l = 0; l < 12; ++l) gcol[l] = (lane < 6) ? Gm[l * GS + lane] : 0.0;   // rows >= nl are zero
+  for (int l = 0; l < 12; ++l) gcol[l] = (lane < 6) ? Gm[l * GS + lane] : (is_ex ? Gm[l * GS + 6 + (lane - n_red)] : 0.0);   // rows >= nl are zero
   // g' = Z'g
-  double g_red = S.npv[fj];
+  double g_red = is_ex ? 0.0 : S.npv[fj];
 #pragma unroll
   for (int l = 0; l < 12; ++l) g_red = fma(gcol[l], S.npv[legd[l]], g_red);
-  if (lane >= n_red) g_red = 0.0;
+  if (lane >= n_eff) g_red = 0.0;
   STAMP(ts, T_P2);
-  // ---- C' = C Z for the rows that stay, then the eliminated legs' bounds as rows G_l
+  // ---- C' = C Z for the rows that stay, then the eliminated legs' bounds as rows G_l (for a pivoted foot the row of its kept
+  // leg velocity holds the kept contact equality instead; that velocity's own bounds are variable bounds now)
   double* const Cm = S.RC;
   double nclb = 0.0, ncub = 0.0;
   int i2 = 0, my_orig = -1;            // my_orig: original index of the kept row that becomes reduced row `lane`
@@ -2107,24 +2204,54 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
       if (l < nl) { if (lane < CSC) Cm[(i2 + l) * CSC + lane] = gcol[l]; }
     }
     if (lane >= i2 && lane < i2 + nl) { nclb = S.xv[my_legd]; ncub = S.yv[my_legd]; }
-    i2 += nl;
   }
-  const double lb_red = (lane < n_red) ? S.xv[fj] : 0.0, ub_red = (lane < n_red) ? S.yv[fj] : 0.0;
+  if (nsing) {
+    if (!c_use_bounds) {               // no leg-bound rows to take over: clear the slots the kept equalities go into
+#pragma unroll
+      for (int l = 0; l < 12; ++l) { if (l < nl && lane < CSC) Cm[(i2 + l) * CSC + lane] = 0.0; }
+      if (lane >= i2 && lane < i2 + nl) { nclb = -1e30; ncub = 1e30; }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      if ((smask >> f) & 1u) {                     // uniform
+        const int l2 = (int)Em[8 * f + 7];
+        const double ev = (lane < 6) ? Em[8 * f + lane] : ((ex_f == f) ? Em[8 * f + 6] : 0.0);
+        if (lane < CSC) Cm[(i2 + l2) * CSC + lane] = ev;
+        if (lane == i2 + l2) { nclb = 0.0; ncub = 0.0; }
+      }
+    }
+  }
+  if (c_use_bounds || nsing) i2 += nl;
+  const double lb_red = (lane < n_eff) ? S.xv[fjb] : 0.0, ub_red = (lane < n_eff) ? S.yv[fjb] : 0.0;
   STAMP(ts, T_P3);
-  // ---- H' += d^2 G'G on the base block (H_ll = d^2 I, H_lf = 0: DevPlan.enabled)
+  // ---- H' += d^2 G'G on the base block and the extra unknowns (H_ll = d^2 I, H_lf = 0: DevPlan.enabled)
   {
+    const double d2 = dpost * dpost;
     double gg[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int l = 0; l < 12; ++l) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) gg[c] = fma(gcol[l], Gm[l * GS + c], gg[c]);
     }
-    const double d2 = dpost * dpost;
-    if (lane < 6) {
+    if (lane < 6 || is_ex) {
 #pragma unroll
       for (int c = 0; c < 6; c += 2) {
-        const double2a h2 = lds2(S.RA + lane * LDJ + c);
+        const double2a h2 = lane < 6 ? lds2(S.RA + lane * LDJ + c) : double2a{0.0, 0.0};     // (an extra unknown's row starts empty)
         sts2(S.RA + lane * LDJ + c, fma(d2, gg[c], h2.x), fma(d2, gg[c + 1], h2.y));
+      }
+    }
+    if (nsing) {                                    // columns of the extra unknowns
+      double gx[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int l = 0; l < 12; ++l) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gx[j] = fma(gcol[l], Gm[l * GS + 6 + j], gx[j]);
+      }
+      if (lane < NR) {   // (this also replaces the identity padding's 1.0 on the extra unknowns' diagonal: the padding starts at n_eff)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j < nsing) S.RA[lane * LDJ + n_red + j] = (lane < 6 || is_ex) ? d2 * gx[j] : 0.0;
+        }
       }
     }
   }
@@ -2132,23 +2259,25 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   STAMP(ts, T_PRE);
   DBG_STOP(5, g_red + lb_red + ub_red + nclb + ncub + S.RA[(lane & 15) * LDJ + 1] + Cm[(lane & 15) * CSC + 1]);
   // warm start: the carried working set (full-problem indexing, KernelArgs.ws_in) seen from the reduced problem — reduced
-  // variable k is DoF Fd[k]; reduced row r is kept row my_orig or, from p_keep on, the velocity bound of an eliminated leg DoF
+  // variable k is DoF Fd[k] (or the kept leg DoF of a pivoted foot); reduced row r is kept row my_orig or, from p_keep on, the
+  // velocity bound of an eliminated leg DoF
   int sd_b = 0, sd_r = 0;
   if (WARM) {
-    if (lane < n_red) sd_b = (int)(((ws0 >> fj) & 1ull) | (((ws0 >> (32 + fj)) & 1ull) << 1));
+    if (lane < n_eff) sd_b = (int)(((ws0 >> fjb) & 1ull) | (((ws0 >> (32 + fjb)) & 1ull) << 1));
     if (my_orig >= 0) sd_r = (int)(((ws1 >> my_orig) & 1ull) | (((ws1 >> (32 + my_orig)) & 1ull) << 1));
     else if (c_use_bounds && lane >= p_keep && lane < p_keep + nl) sd_r = (int)(((ws0 >> my_legd) & 1ull) | (((ws0 >> (32 + my_legd)) & 1ull) << 1));
   }
-  QpResult res = qp_core<NR, SmemC, CSC, WARM>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, DBG_STOP_ARG,
+  QpResult res = qp_core<NR, SmemC, CSC, WARM>(S, g_red, lb_red, ub_red, nclb, ncub, n_eff, i2, lane, ts, DBG_STOP_ARG,
                                                sd_b == 3 ? 0 : sd_b, sd_r == 3 ? 0 : sd_r);
-  res.iters += nl;
+  res.iters += nl - nsing + P.nlock;   // the eliminated equalities and the locked DoF, so that `iters` keeps its meaning
   // ---- x = Z y
   WSYNC();
-  if (lane < 32) { S.xv[lane] = (lane < n_red) ? res.x : 0.0; if (WARM) { S.lv[lane] = (double)res.ws_b; S.dinv[lane] = (double)res.ws_r; } }
+  if (lane < 32) { S.xv[lane] = (lane < n_eff) ? res.x : 0.0; if (WARM) { S.lv[lane] = (double)res.ws_b; S.dinv[lane] = (double)res.ws_r; } }
   WSYNC();
   if (WARM && A.ws_out) {   // the final working set back in full-problem indexing: lane d = DoF d, lane i = original constraint row i
     int cb = 0, cr = 0;
     if (my_pos >= 0) cb = (int)S.lv[my_pos];
+    else if (my_x >= 0) cb = (int)S.lv[my_x & 31];
     else if (my_l >= 0 && c_use_bounds) cb = (int)S.dinv[(p_keep + my_l) & 31];
     if (lane < p && !((elimrows >> lane) & 1u)) cr = (int)S.dinv[__popc(~elimrows & ((1u << lane) - 1u)) & 31];
     const unsigned long long o0 = (__ballot(cb == 1) & 0xFFFFFFFFull) | (__ballot(cb == 2) << 32);
@@ -2160,6 +2289,10 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   else if (my_l >= 0) {
 #pragma unroll
     for (int c = 0; c < 6; ++c) x = fma(Gm[my_l * GS + c], S.xv[c], x);
+    if (nsing) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { if (j < nsing) x = fma(Gm[my_l * GS + 6 + j], S.xv[n_red + j], x); }
+    }
   }
   if (lane >= nv) x = 0.0;
   if (A.out.qdot && lane < NV) A.out.qdot[(size_t)b * NV + lane] = x;
