@@ -300,8 +300,14 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *   "sim3_kernel"      [1] batches whose every model has such an elimination plan, <= 16 constraint rows and no orientation
  *                          references run on the compact wbc_tick_sim3_kernel (+ a second pass of the general kernel over the
  *                          instances whose leg blocks it could not eliminate); 0: the general kernel does the elimination.
- *   "presolve_tol_exp" [7] a stance-leg 3 x 3 block K with |det K| <= 10^-value (sum |K_ij|)^3 is treated as singular
- *                          (0: every block, i.e. the fallback for singular blocks is forced on every instance).
+ *   "presolve_tol_exp" [7] a stance-leg 3 x 3 block K with |det K| <= 10^-value (sum |K_ij|)^3 is treated as rank deficient: the
+ *                          compact kernel eliminates it with column pivoting and keeps one leg velocity + one contact equality
+ *                          in the reduced QP (the general kernel's in-kernel presolve falls back to the full problem).
+ *                          0: every block of every instance takes that path.
+ *   "count_pivoted"    [0] diagnostic: count the instances that took the pivoted elimination (statistic "pivoted_last"; one
+ *                          atomic per such instance — leave it off when timing).
+ *   "dbg_force_defer"  [0] diagnostic: an instance with a flagged block is handed to the second pass (general kernel over the
+ *                          compact list) instead — the path a block of rank < 2 takes.
  *   "warm_start"       [0] 1: wbc_rollout carries every instance's final working set into its next tick (the hot start the
  *                          reference gets from QP.solveQPHotstart, Robot_Wrapper4.py:1389-1394); 0: every tick starts cold.
  *                          Same minimiser either way (H > 0). Off by default because it measured 4 % SLOWER on MI355X
@@ -315,7 +321,8 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
 int wbc_batch_set_option(WbcBatch* b, const char* name, int value);
 
 /* Read-only statistics of a handle: "last_path" (kernel the last tick ran on: 0 general, 1 compact sim3 + second pass),
- * "deferred_last" (instances the last sim3-kernel tick left to the second pass; waits for `stream`),
+ * "deferred_last" (instances the last sim3-kernel tick left to the second pass; waits for `stream`), "pivoted_last" (instances
+ * that took the pivoted elimination, with option "count_pivoted"),
  * "sim3_lds_bytes" / "tick_lds_bytes" (LDS per instance of the two tick kernels). */
 int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, int64_t* out);
 

@@ -46,6 +46,7 @@ struct WbcBatch {
   int sim3_kernel;       // 1 (default): batches that qualify run on wbc_tick_sim3_kernel (compact LDS) + a deferred pass
   int32_t* d_status;     // status buffer of our own when the caller passes none (the deferred pass needs one)
   int dbg_alias, dbg_stop;
+  int count_pivoted, force_defer;   // diagnostics of the sim3 kernel's pivoted elimination / second pass
   int warm_start;        // 1: wbc_rollout carries each instance's working set from tick to tick (default 0: measured slower)
   int32_t* d_defer;      // [1 + max_batch]: count + compact list of the instances the sim3 kernel deferred (lazy)
   int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass)
@@ -330,6 +331,8 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
   if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
   if (!strcmp(name, "warm_start")) { b->warm_start = value != 0; return WBC_OK; }
+  if (!strcmp(name, "count_pivoted")) { b->count_pivoted = value != 0; return WBC_OK; }
+  if (!strcmp(name, "dbg_force_defer")) { b->force_defer = value != 0; return WBC_OK; }
   if (!strcmp(name, "dbg_stop")) {
 #ifdef WBC_ABLATE
     b->dbg_stop = value; return WBC_OK;
@@ -351,6 +354,15 @@ extern "C" int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, i
     int32_t c = 0;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(hipMemcpy(&c, b->d_defer, sizeof c, hipMemcpyDeviceToHost));
+    *out = c;
+    return WBC_OK;
+  }
+  if (!strcmp(name, "pivoted_last")) {       // needs option "count_pivoted"; waits for `stream`
+    *out = 0;
+    if (!b->d_defer || !b->last_path || !b->count_pivoted) return WBC_OK;
+    int32_t c = 0;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(&c, b->d_defer + 1 + b->max_batch, sizeof c, hipMemcpyDeviceToHost));
     *out = c;
     return WBC_OK;
   }
@@ -533,9 +545,17 @@ static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
     if (!b->d_status) HIP_TRY(hipMalloc((void**)&b->d_status, sizeof(int32_t) * (size_t)b->max_batch));
     a.out.status = b->d_status;
   }
-  if (!b->d_defer) HIP_TRY(hipMalloc((void**)&b->d_defer, sizeof(int32_t) * ((size_t)b->max_batch + 1)));
+  if (!b->d_defer) {
+    HIP_TRY(hipMalloc((void**)&b->d_defer, sizeof(int32_t) * ((size_t)b->max_batch + 2)));
+    HIP_TRY(hipMemset(b->d_defer, 0, sizeof(int32_t) * ((size_t)b->max_batch + 2)));
+  }
   a.defer = b->d_defer;
+  a.dbg_force_defer = b->force_defer;
   HIP_TRY(hipMemsetAsync(b->d_defer, 0, sizeof(int32_t), (hipStream_t)stream));   // (a memset node when the call is captured into a graph)
+  if (b->count_pivoted) {
+    a.pivot_count = b->d_defer + 1 + b->max_batch;
+    HIP_TRY(hipMemsetAsync(a.pivot_count, 0, sizeof(int32_t), (hipStream_t)stream));
+  }
   if (int e = launch_tick_sim3(a, B, stream)) return fail(WBC_E_HIP, "sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   if (int e = launch_tick_deferred(a, stream)) return fail(WBC_E_HIP, "deferred tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return WBC_OK;

@@ -70,6 +70,8 @@ struct KernelArgs {
   int32_t jtj_mfma, presolve;  // presolve: structural elimination of the contact equalities (default on)
   int32_t fk_nj, fk_nf;             // oMi / oMf output strides = max njoints / nframes over the handle's models
   int32_t* defer;                   // [1 + max_batch]: count, then the instances wbc_tick_sim3_kernel left to the general path
+  int32_t* pivot_count;             // diagnostic (option "count_pivoted"): instances that took the pivoted elimination; else null
+  int32_t dbg_force_defer, pad2_;   // diagnostic: every instance with a flagged leg block is deferred instead of pivoted
   // warm start: the final working set of the previous tick, [B][2] words in FULL-problem indexing whatever
   // kernel wrote them: word 0 = velocity bounds (bit d: DoF d at its lower bound, bit 32 + d: at its upper bound), word 1 =
   // constraint rows of findConstraints' order (bit i / 32 + i). Either may be null (cold start / nothing carried); they may alias.

@@ -2076,7 +2076,8 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
   double* const Em = S.in + 96;        // [4][8]: 6 base coefficients, r22, index l of the leg DoF kept as unknown
   if (smask) {
     nsing = __popc(smask);
-    bool bad_rank = false;
+    bool bad_rank = A.dbg_force_defer != 0;
+    if (A.pivot_count && lane == 0 && !bad_rank) atomicAdd(A.pivot_count, 1);
     if (lane < 48) Gm[(lane >> 2) * GS + 6 + (lane & 3)] = 0.0;     // extra columns of every row
     WSYNC();
     if (lane < 4 && ((smask >> lane) & 1u)) {
@@ -2117,7 +2118,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
       double q2[3];
       cross3(q0, q1, q2);
       const double r22 = q2[0] * s2[0] + q2[1] * s2[1] + q2[2] * s2[2];
-      bad_rank = !(r11 > 1e-9 * r00) || !(r00 > 0.0);    // rank < 2 (or NaN): nothing sensible to eliminate
+      bad_rank = bad_rank || !(r11 > 1e-9 * r00) || !(r00 > 0.0);    // rank < 2 (or NaN): nothing sensible to eliminate
       // Q'B, then back substitution
       const int l0 = 3 * f + p0, l1 = 3 * f + p1, l2 = 3 * f + p2;
 #pragma unroll

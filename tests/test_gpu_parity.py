@@ -279,11 +279,11 @@ def _leg_block_ratio(a):
     return r
 
 
-def test_sim3_kernel_defers_singular_leg_blocks(wx200):
-    """A stance leg whose 3 x 3 WORLD-frame block is (nearly) singular cannot be eliminated: the compact kernel hands the
-    instance to the general kernel's second pass. The 64 instances of a 4096-instance sample with the smallest
-    |det K| / scale^3 are run at the default threshold (1e-7): whichever of them fall below it must be deferred (count
-    checked against the same test on the oracle's C), and every one must match the oracle."""
+def test_sim3_kernel_pivots_rank_deficient_leg_blocks(wx200):
+    """A stance leg whose 3 x 3 WORLD-frame block is (nearly) singular is eliminated with column pivoting by the compact kernel
+    (one leg velocity + one contact equality stay in the reduced QP): nothing is deferred. The 64 instances of a 4096-instance
+    sample with the smallest |det K| / scale^3 are run at the default threshold (1e-7): whichever fall below it must take that
+    path (count checked against the same test on the oracle's C), and every one must match the oracle."""
     B = 4096
     cfg = common.config("c3", wx200)
     d = common.tick_inputs(wx200, cfg, B, seed=77)
@@ -294,22 +294,24 @@ def test_sim3_kernel_defers_singular_leg_blocks(wx200):
     ref = oracle.tick([wx200], [cfg], sub, DT, len(idx), nthreads=8)
     bt = WbcBatch(wx200, len(idx))
     bt.configure(cfg)
+    bt.set_option("count_pivoted", 1)
     got = bt.tick(sub, DT)
-    assert bt.stat("last_path") == 1
+    assert bt.stat("last_path") == 1 and bt.stat("deferred_last") == 0
     expect = int((ratio[idx] <= 1e-7).sum())
-    assert abs(bt.stat("deferred_last") - expect) <= 1          # (a ratio within rounding of the threshold may fall either way)
+    assert abs(bt.stat("pivoted_last") - expect) <= 1          # (a ratio within rounding of the threshold may fall either way)
     assert (got["status"] == ref["status"]).all() and (got["status"] >= 0).all()
     ok = ref["status"] == 0
     assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
-    print("smallest |det K| / scale^3 in the sample: %.2e, deferred %d" % (ratio[idx[0]], bt.stat("deferred_last")))
+    print("smallest |det K| / scale^3 in the sample: %.2e, pivoted %d" % (ratio[idx[0]], bt.stat("pivoted_last")))
     bt.close()
 
 
-@pytest.mark.parametrize("tol_exp", [0, 3, 5])
-def test_forced_deferral_matches_the_oracle(wx200, px100, tol_exp):
-    """The second pass under load: option presolve_tol_exp lowers the bar for "singular" so that a known share of the
-    batch (all of it at 0) is deferred by the compact kernel and redone by the general kernel from the compact list.
-    The deferred count is the one predicted from the oracle's constraint rows; q̇, status and q_next match the oracle."""
+@pytest.mark.parametrize("tol_exp,defer", [(0, 0), (3, 0), (5, 0), (0, 1), (3, 1)])
+def test_pivoted_elimination_and_second_pass_match_the_oracle(wx200, px100, tol_exp, defer):
+    """Both answers to a rank-deficient stance-leg block under load: option presolve_tol_exp lowers the bar for "rank deficient"
+    so that a known share of the batch (all of it, on all four legs, at 0) takes the pivoted elimination inside the compact
+    kernel — or, with dbg_force_defer, is handed to the general kernel's second pass over the compact list (the path of a block of
+    rank < 2). The count is the one predicted from the oracle's constraint rows; q̇, status and q_next match the oracle."""
     B = 3000                                        # > 2048: the list is longer than the second pass's grid at tol_exp = 0
     models = [wx200, px100]
     cfgs = [common.config("c3", m) for m in models]
@@ -319,24 +321,26 @@ def test_forced_deferral_matches_the_oracle(wx200, px100, tol_exp):
     d["model_id"] = mid
     ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
     ratio = _leg_block_ratio(oracle.assemble(models, cfgs, d, DT, B))
-    tol = 10.0 ** -tol_exp
-    expect = int((ratio <= tol).sum())
+    expect = int((ratio <= 10.0 ** -tol_exp).sum())
     bt = WbcBatch(models, B)
     for i, c in enumerate(cfgs):
         bt.configure(c, i)
     bt.set_option("presolve_tol_exp", tol_exp)
+    bt.set_option("count_pivoted", 1)
+    bt.set_option("dbg_force_defer", defer)
     got = bt.tick(d, DT, want_q_next=True)
-    n_def = bt.stat("deferred_last")
-    print("tol 1e-%d: deferred %d of %d (predicted %d)" % (tol_exp, n_def, B, expect))
-    assert n_def > 0 and abs(n_def - expect) <= max(2, expect // 200)
-    if tol_exp == 0:
-        assert n_def == B
-    else:
-        assert n_def < B
+    n_def, n_piv = bt.stat("deferred_last"), bt.stat("pivoted_last")
+    print("tol 1e-%d, force_defer %d: pivoted %d, deferred %d of %d (predicted %d)" % (tol_exp, defer, n_piv, n_def, B, expect))
+    n = n_def if defer else n_piv
+    assert (n_piv if defer else n_def) == 0
+    assert n > 0 and abs(n - expect) <= max(2, expect // 200)
+    assert n == B if tol_exp == 0 else n < B
     assert (got["status"] == ref["status"]).all()
     ok = ref["status"] == 0
     assert ok.mean() > 0.9
-    assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+    err = np.abs(got["qdot"] - ref["qdot"])[ok].max()
+    print("   qdot max-abs err %.3e, working-set changes %.2f (oracle %.2f)" % (err, got["iters"][ok].mean(), ref["iters"][ok].mean()))
+    assert err < QDOT_TOL
     assert np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
     bt.close()
 
