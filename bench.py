@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak
 ALGO_FLOP_PER_TICK = 5.5e4     # dense count of the n = 26 problem (+ ~1e4 per working-set change)
 REDUCED_FLOP_PER_TICK = 1.4e4  # the problem the sim3 kernel actually solves (n' = 14, no equalities): DESIGN.md §4
-PMC_PROFILE = "r01_pmc_summary_v12.txt"   # committed rocprofv3 PMC passes the static roofline.traffic / roofline.issue fields come from
+PMC_PROFILE = "r02_pmc_summary.txt"   # committed rocprofv3 PMC passes the static roofline.traffic / roofline.issue fields come from
 DT = 0.002
 QDOT_TOL = 1e-5
 
