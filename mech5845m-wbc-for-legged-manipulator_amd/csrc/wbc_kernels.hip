@@ -336,16 +336,8 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   WSYNC();
 #pragma unroll 1
   for (int j = 0; j < NM; ++j) {
-    if (j >= n) {
-      // padded rows (n < NM) are exactly identity rows with no coupling: the step's column of L is e_j, so it only rotates the
-      // registers — no pivot broadcast, no LDS round trip, no FMAs (5 of the 16 steps of the sim3 problem, n' = 11)
-      const double y0 = y[0];
-#pragma unroll
-      for (int r = 1; r < NM; ++r) { h[r - 1] = h[r]; y[r - 1] = y[r]; }
-      h[NM - 1] = 0.0;
-      y[NM - 1] = y0;
-      continue;
-    }
+    // (skipping the FMAs of the padded steps j >= n — their column of L is e_j — and only rotating the registers measured 2 % SLOWER:
+    //  the 2 x 15 register moves cost more than the LDS round trip they avoid; same-box A/B, tools/ab_bench.sh)
     const double pj = rdl(h[0], j);
     pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;            // (a NaN pivot must fail the test below; fmin would drop it)
     const double rinv = rsqrt(pj);
