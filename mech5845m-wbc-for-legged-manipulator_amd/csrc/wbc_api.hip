@@ -47,6 +47,7 @@ struct WbcBatch {
   int32_t* d_status;     // status buffer of our own when the caller passes none (the deferred pass needs one)
   int dbg_alias, dbg_stop;
   int count_pivoted, force_defer;   // diagnostics of the sim3 kernel's pivoted elimination / second pass
+  int packed_kernel;     // 1 (default): eligible batches run four instances per wavefront (wbc_tick_sim3p_kernel)
   int warm_start;        // 1: wbc_rollout carries each instance's working set from tick to tick (default 0: measured slower)
   int32_t* d_defer;      // [1 + max_batch]: count + compact list of the instances the sim3 kernel deferred (lazy)
   int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass)
@@ -145,7 +146,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
   b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
-  b->jtj_mfma = -1; b->warm_start = 0;
+  b->jtj_mfma = -1; b->warm_start = 0; b->packed_kernel = 1;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
@@ -291,6 +292,25 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
     }
   }
   P->nelim = nelim; P->n_red = n_red; P->p_keep = p_keep; P->enabled = 1;
+  // ---- the packed kernel (wbc_tick_sim3p_kernel) covers the sim3 switch-set family only: Grip task or none, no trunk / CoM
+  // task, the kept rows = the trunk box (base support only), velocity bounds on, a posture mode it can form itself, every
+  // joint it needs within tree depth 6 and at most 16 joints per level
+  bool ok = c.use_bounds && !c.task_trunk && !c.task_com && !c.con_com && !c.con_ee[4] && p_keep == (c.con_trunk ? 4 : 0) &&
+            n_red <= 16 && (P->task_ee_mask & ~16u) == 0 && P->legrows == 0 &&
+            (c.task_joint == WBC_JOINT_TIKHONOV || c.task_joint == WBC_JOINT_PREV || (c.task_joint >= WBC_JOINT_MANI && c.task_joint <= WBC_JOINT_HYBRID && P->post_static && !P->post_fk2));
+  int need_depth = 0;
+  for (int k = 0; k < n_red; ++k) if (M.depth[M.col_joint[P->Fd[k]]] > need_depth) need_depth = M.depth[M.col_joint[P->Fd[k]]];
+  for (int l = 0; l < 3 * nelim; ++l) if (M.depth[M.col_joint[P->legd[l]]] > need_depth) need_depth = M.depth[M.col_joint[P->legd[l]]];
+  if (M.depth[M.frame_joint[WBC_FR_EE0 + 4]] > need_depth) need_depth = M.depth[M.frame_joint[WBC_FR_EE0 + 4]];
+  if (need_depth > 6) ok = false;
+  for (int L = 0; L < 5 && ok; ++L) {
+    int cnt = 0;
+    for (int i = 0; i < 16; ++i) P->fk_sched[L][i] = -1;
+    for (int j = 2; j < M.njoints; ++j)
+      if (M.depth[j] == L + 2 && M.depth[j] <= need_depth) { if (cnt < 16) P->fk_sched[L][cnt] = j; ++cnt; }
+    if (cnt > 16) ok = false;
+  }
+  P->packed_ok = ok ? 1 : 0;
 }
 
 extern "C" int wbc_batch_configure(WbcBatch* b, int mi, const WbcConfig* cfg) {
@@ -329,6 +349,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!strcmp(name, "presolve")) { b->presolve = value; return WBC_OK; }
   if (!strcmp(name, "presolve_tol_exp")) { double t = 1.0; for (int i = 0; i < value; ++i) t *= 0.1; b->sing_tol = t; return WBC_OK; }
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
+  if (!strcmp(name, "packed_kernel")) { b->packed_kernel = value; return WBC_OK; }
   if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
   if (!strcmp(name, "warm_start")) { b->warm_start = value != 0; return WBC_OK; }
   if (!strcmp(name, "count_pivoted")) { b->count_pivoted = value != 0; return WBC_OK; }
@@ -556,7 +577,13 @@ static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
     a.pivot_count = b->d_defer + 1 + b->max_batch;
     HIP_TRY(hipMemsetAsync(a.pivot_count, 0, sizeof(int32_t), (hipStream_t)stream));
   }
-  if (int e = launch_tick_sim3(a, B, stream)) return fail(WBC_E_HIP, "sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  bool packed = b->packed_kernel && !a.ws_in && !a.ws_out && !a.in.q_con && !a.in.posture_u &&
+                !b->force_defer && !b->count_pivoted && !b->dbg_stop && !b->dbg_alias;
+  for (int i = 0; i < b->n_models && packed; ++i) packed = b->plan_host[i].packed_ok != 0;
+  if (packed) {
+    b->last_path = 2;
+    if (int e = launch_tick_sim3p(a, stream)) return fail(WBC_E_HIP, "packed sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  } else if (int e = launch_tick_sim3(a, B, stream)) return fail(WBC_E_HIP, "sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   if (int e = launch_tick_deferred(a, stream)) return fail(WBC_E_HIP, "deferred tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return WBC_OK;
 }

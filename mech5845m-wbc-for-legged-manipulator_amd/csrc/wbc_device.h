@@ -36,7 +36,10 @@ struct DevModel {
 constexpr int WBC_QP_DEFERRED = -1;     // internal status: set by wbc_tick_sim3_kernel, never visible to the caller
 struct DevPlan {
   int32_t enabled, nelim, n_red, p_keep;
-  int32_t nlock, pad_[3];            // DoF locked at 0 by the velocity box (>= lock_from, use_bounds): left out of the reduced problem
+  int32_t nlock;                     // DoF locked at 0 by the velocity box (>= lock_from, use_bounds): left out of the reduced problem
+  int32_t packed_ok;                 // the packed kernel (four instances per wavefront) can run this (model, configuration)
+  int32_t pad_[2];
+  int32_t fk_sched[5][16];           // packed kernel: joints of tree depth 2 + L, one per lane-in-instance (-1: none)
   uint32_t elimrows;                 // bit i: constraint row i belongs to an eliminated foot
   uint32_t legrows;                  // bit i: kept constraint row i has support on eliminated leg DoF (needs C Z)
   // qpJointb "MANI"/"HYBRID" when EVERY finite difference is structurally zero (the perturbed joint is not a proper ancestor
@@ -132,6 +135,8 @@ struct UpdateArgs {
 // launchers (wbc_kernels.hip): single-wave workgroups; tick kernels take grid = B, the QP / integrate kernels min(B, resident waves)
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream);
 int launch_tick_sim3(const KernelArgs& a, int grid, void* stream);
+int launch_tick_sim3p(const KernelArgs& a, void* stream);      // packed: four instances per wavefront, grid = ceil(B / 4)
+int sim3p_lds_bytes();
 int launch_tick_deferred(const KernelArgs& a, void* stream);   // general path for the instances the sim3 kernel deferred
 int sim3_lds_bytes();
 int launch_qp(const QpArgs& a, int grid, void* stream);

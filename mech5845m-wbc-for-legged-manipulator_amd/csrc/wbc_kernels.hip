@@ -2707,6 +2707,638 @@ __global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, cons
   }
 }
 
+// ================================================================================================
+// The PACKED sim3-tick kernel: FOUR robot instances per wavefront, one per 16-lane DPP row.
+//
+// The compact kernel above keeps one instance per wave, and its reduced QP (n' = 11 unknowns, <= 16 rows) lights 11-16 of the 64
+// lanes: 3.3 k VALU wave-instructions per tick for ~1.4e4 useful flops. Here lane = 16 r + s: instance r of the wave, s = reduced
+// variable / constraint row / FK slot. Every stage is written for 16 lanes:
+//   FK          level-synchronous over a per-plan schedule (DevPlan.fk_sched: at most five joints per tree level — four legs + the
+//               arm chain), sin/cos of the joint angles computed beforehand two per lane;
+//   columns     lane s owns the WORLD Jacobian column of reduced variable s (task rows, trunk-box rows) and of eliminated leg DoF
+//               s < 12 (contact rows -> K_e, velocity bounds);
+//   assembly    row s of H' accumulated straight into registers from the task image At (LDS), G = -K^-1 B on lanes s < 12;
+//   QP          the dual active-set of qp_core with per-row state: reductions are DPP row butterflies (no v_readlane), a value
+//               at a row-dependent lane comes through ds_bpermute, the Cholesky column is broadcast through a per-instance LDS
+//               vector, control flow is per-row predication with the loops running to the slowest of the four instances.
+// Applies to the sim3 switch-set family only (launch_tick_auto): Grip task or none, posture PREV / Tikhonov / static HYBRID, trunk
+// box + foot contacts, velocity bounds on, no CoM rows, no orientation references, nothing warm. Instances with a rank-deficient
+// leg block go to the compact list and are redone by the one-instance kernels. Same arithmetic per instance as process_sim3.
+// ================================================================================================
+constexpr int PLD = 18;                     // row stride of the 16 x 16 matrices (even: rows are 16-byte aligned for ds_read_b128)
+constexpr int PN = 16;                      // lanes, reduced variables and rows per instance
+struct __attribute__((aligned(16))) PInst {
+  double M1[PN * PLD];                      // oMi scratch [24][12] -> T = R^-1
+  double M2[PN * PLD];                      // At [16][6], K / B scratch -> J
+  double Cq[PN * 6];                        // reduced constraint rows x base columns (all the reduced rows touch the base only)
+  double G[12 * 6];                         // eliminated leg DoF l (row) x base DoF (column)
+  double in[48];                            // q [27], gripper target [3] @28, previous [3] @31, trunk box centre [4] @34
+  double sc[48];                            // sin, cos of joint j's angle at [2 j]
+  double xv[PN], dv[PN], yv[PN], tv[PN];
+  double cl[32];                            // Cholesky column broadcast; entries 16..31 stay zero
+  double rb[32];                            // row bounds staging: clb [16], cub [16]
+  double qd[32];                            // by-DoF staging: posture term of the leg DoF, later qdot
+  double pad_[24];                          // instance stride = 1024 doubles: the four instances' rows fall on the same banks pattern
+};
+static_assert(sizeof(PInst) == 8192, "PInst must be 8 KB");
+struct __attribute__((aligned(16))) SmemP { PInst I[4]; };
+
+__device__ __forceinline__ double rsum16(double v) {     // sum over the lane's 16-lane row, result in every lane of the row
+  v += dpp<DPP_XOR1>(v); v += dpp<DPP_XOR2>(v); v += dpp<DPP_HALF_MIRROR>(v); v += dpp<DPP_MIRROR>(v);
+  return v;
+}
+__device__ __forceinline__ double rmin16(double v) {
+  v = fmin(v, dpp<DPP_XOR1>(v)); v = fmin(v, dpp<DPP_XOR2>(v)); v = fmin(v, dpp<DPP_HALF_MIRROR>(v)); v = fmin(v, dpp<DPP_MIRROR>(v));
+  return v;
+}
+__device__ __forceinline__ double bperm(double v, int src_lane) {     // v of lane src_lane (any lane index 0..63, per lane)
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int bpermi(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+
+__global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs A, const DevModel* __restrict__ models,
+                                                               const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
+  __shared__ SmemP SP;
+  const int lane = threadIdx.x, r = lane >> 4, s = lane & 15, rbase = lane & 48;
+  PInst& I = SP.I[r];
+  const int b_raw = 4 * blockIdx.x + r;
+  const bool valid = b_raw < A.B;
+  const int b = valid ? b_raw : A.B - 1;
+  int mid = 0;
+  if (A.in.model_id) { mid = A.in.model_id[b]; mid = mid < 0 ? 0 : (mid >= A.n_models ? A.n_models - 1 : mid); }
+  const DevModel& M = models[mid];
+  const WbcConfig& cfg = cfgs[mid];
+  const DevPlan& P = plans[mid];
+  const double dt = A.dt, inv_dt = 1.0 / A.dt;
+
+  // ---- loads: inputs (coalesced per instance), then the per-lane tables
+  {
+    const double* qg = A.in.q + (size_t)b * NQ;
+    const double q0 = qg[s], q1 = (16 + s < NQ) ? qg[16 + s] : 0.0;
+    double ex = 0.0;
+    if (s < 3) ex = A.in.ee_target ? A.in.ee_target[(size_t)b * 15 + 12 + s] : 0.0;
+    else if (s < 6) ex = A.in.prev_ee_target ? A.in.prev_ee_target[(size_t)b * 15 + 12 + (s - 3)] : 0.0;
+    else if (s < 10) ex = A.in.trunk_box_center ? A.in.trunk_box_center[(size_t)b * 4 + (s - 6)] : 0.0;
+    I.in[s] = q0;
+    I.in[16 + s] = q1;
+    if (s < 10) I.in[28 + s] = ex;
+    I.cl[s] = 0.0; I.cl[16 + s] = 0.0;
+  }
+  const int nv = M.nv, nq = M.nq, n = P.n_red, nelim = P.nelim, nl = 3 * nelim, p_keep = P.p_keep, p = p_keep + nl;
+  const unsigned fl = P.flags;
+  const bool c_con_trunk = fl & 2u;
+  const int c_task_joint = (fl >> 4) & 7u;
+  const bool has_grip = (P.task_ee_mask >> 4) & 1u;
+  // FK schedule of this lane (tree depth 2..6) and its joints' constants
+  int fj_[5], fpar_[5], fa0_[5], fa1_[5], fa2_[5], fq_[5], frev_[5];
+  double ft_[5][3];
+#pragma unroll
+  for (int L = 0; L < 5; ++L) {
+    const int j = P.fk_sched[L][s];
+    const int jj = j < 0 ? 1 : j;
+    fj_[L] = j; fpar_[L] = M.parent[jj]; fq_[L] = M.idx_q[jj];
+    fa0_[L] = 3 * M.ax0[jj]; fa1_[L] = 3 * M.ax1[jj]; fa2_[L] = 3 * M.ax2[jj];
+    const int jt = M.jtype[jj];
+    frev_[L] = (jt >= WBC_JT_RX && jt <= WBC_JT_RZ) ? 1 : 0;
+    ft_[L][0] = M.tp[jj][0]; ft_[L][1] = M.tp[jj][1]; ft_[L][2] = M.tp[jj][2];
+  }
+  // columns: pass 0 = reduced variable s, pass 1 = eliminated leg DoF s
+  const int dof0 = (s < n) ? P.Fd[s] : 0, dof1 = (s < nl) ? P.legd[s < 12 ? s : 0] : 0;
+  const int c0_joint = M.col_joint[dof0], c0_lin = M.col_lin[dof0], c0_ang = M.col_ang[dof0];
+  const int c1_joint = M.col_joint[dof1], c1_lin = M.col_lin[dof1], c1_ang = M.col_ang[dof1];
+  const int dq0 = cfg.damper_qidx[dof0], dq1 = cfg.damper_qidx[dof1];
+  const double dlo0 = cfg.damper_lo[dof0], dhi0 = cfg.damper_hi[dof0], dvm0 = cfg.damper_vmax[dof0];
+  const double dlo1 = cfg.damper_lo[dof1], dhi1 = cfg.damper_hi[dof1], dvm1 = cfg.damper_vmax[dof1];
+  const double dcoef = cfg.damper_coef, dqi = cfg.damper_qi, dqs = cfg.damper_qs;
+  const int gj = M.frame_joint[WBC_FR_EE0 + 4];
+  const double gp0 = M.frame_p[WBC_FR_EE0 + 4][0], gp1 = M.frame_p[WBC_FR_EE0 + 4][1], gp2 = M.frame_p[WBC_FR_EE0 + 4][2];
+  const unsigned gsup = P.redsup[WBC_FR_EE0 + 4];
+  const double ee_w = cfg.ee_w[4];
+  double eW[6], eG[3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) eW[i] = cfg.ee_W[4][i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) eG[i] = cfg.ee_gain[4][i];
+  const double joint_w = cfg.joint_w, tb_z = cfg.trunk_box_z_frac, tb_a = cfg.trunk_box_ang, tb_s = cfg.trunk_box_scale;
+  WSYNC();
+  const double* const qv = I.in;
+
+  // ---- sin / cos of the joint angles: joint j (>= 2) reads q[idx_q[j]]; two joints per lane
+  double* const oMi = I.M1;
+  {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = 2 + s + 16 * h;
+      if (j < M.njoints) {
+        const int jt = M.jtype[j];
+        const double th = qv[M.idx_q[j]];
+        const SinCos t = sincos_cw((jt >= WBC_JT_RX && jt <= WBC_JT_RZ) ? th : 0.0);
+        I.sc[2 * j] = t.s; I.sc[2 * j + 1] = t.c;
+      }
+    }
+    // root free-flyer (joint 1): R from the quaternion exactly as Eigen's toRotationMatrix, p = xyz; R column-major then p
+    if (s == 0) {
+      double Rt[9];
+      quat_to_R(qv + 3, Rt);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) oMi[12 + 3 * c + rr] = Rt[3 * rr + c];
+      oMi[12 + 9] = qv[0]; oMi[12 + 10] = qv[1]; oMi[12 + 11] = qv[2];
+    }
+  }
+  WSYNC();
+  // ---- P1: pin.forwardKinematics, level by level (Robot_Wrapper4.py:400)
+#pragma unroll
+  for (int L = 0; L < 5; ++L) {
+    if (fj_[L] >= 0) {
+      const double* Pp = oMi + 12 * fpar_[L];
+      const double sn = frev_[L] ? I.sc[2 * fj_[L]] : 0.0, cs = frev_[L] ? I.sc[2 * fj_[L] + 1] : 1.0;
+      const double pris = frev_[L] ? 0.0 : qv[fq_[L]];
+      double Av[3], Bv[3], Cv[3], Pv[3];
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) { Av[rr] = Pp[fa0_[L] + rr]; Bv[rr] = Pp[fa1_[L] + rr]; Cv[rr] = Pp[fa2_[L] + rr]; Pv[rr] = Pp[9 + rr]; }
+      double* Po = oMi + 12 * fj_[L];
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        Po[fa0_[L] + rr] = Av[rr];
+        Po[fa1_[L] + rr] = cs * Bv[rr] + sn * Cv[rr];
+        Po[fa2_[L] + rr] = cs * Cv[rr] - sn * Bv[rr];
+        Po[9 + rr] = Pv[rr] + Av[rr] * (ft_[L][0] + pris) + Bv[rr] * ft_[L][1] + Cv[rr] * ft_[L][2];
+      }
+    }
+    WSYNC();
+  }
+  // ---- P3: Jacobian columns (WORLD): of reduced variable s, and (linear part) of eliminated leg DoF s
+  double lin0[3] = {0, 0, 0}, ang0[3] = {0, 0, 0}, lin1[3] = {0, 0, 0};
+  if (s < n) {
+    const double* Pj = oMi + 12 * c0_joint;
+    const double pj[3] = {Pj[9], Pj[10], Pj[11]};
+    if (c0_ang >= 0) { ang0[0] = Pj[3 * c0_ang]; ang0[1] = Pj[3 * c0_ang + 1]; ang0[2] = Pj[3 * c0_ang + 2]; cross3(pj, ang0, lin0); }
+    if (c0_lin >= 0) { lin0[0] = Pj[3 * c0_lin]; lin0[1] = Pj[3 * c0_lin + 1]; lin0[2] = Pj[3 * c0_lin + 2]; }
+  }
+  if (s < nl) {
+    const double* Pj = oMi + 12 * c1_joint;
+    const double pj[3] = {Pj[9], Pj[10], Pj[11]};
+    if (c1_ang >= 0) { const double a1[3] = {Pj[3 * c1_ang], Pj[3 * c1_ang + 1], Pj[3 * c1_ang + 2]}; cross3(pj, a1, lin1); }
+    if (c1_lin >= 0) { lin1[0] = Pj[3 * c1_lin]; lin1[1] = Pj[3 * c1_lin + 1]; lin1[2] = Pj[3 * c1_lin + 2]; }
+  }
+  // trunk frame = the root joint's placement (imu frame: identity offset); gripper_bar origin
+  double Rtr[9], ptr[3], pfe[3];
+  {
+    const double* Pr = oMi + 12 * M.frame_joint[WBC_FR_TRUNK];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) Rtr[3 * rr + c] = Pr[3 * c + rr];
+    ptr[0] = Pr[9]; ptr[1] = Pr[10]; ptr[2] = Pr[11];
+    const double* Pg = oMi + 12 * gj;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) pfe[rr] = Pg[9 + rr] + Pg[rr] * gp0 + Pg[3 + rr] * gp1 + Pg[6 + rr] * gp2;
+  }
+  WSYNC();   // oMi is dead: M1 / M2 are free
+
+  // ---- task stack (qpA / qpb, Robot_Wrapper4.py:1271-1294): Grip rows of reduced variable s -> At[s][6]; g
+  double* const At = I.M2;                 // [16][6]
+  double* const Kb = I.M2 + 16 * 6;        // [12][4]: linear WORLD column of leg DoF l
+  double* const Bb = I.M2 + 16 * 6 + 48;   // [6][4]:  linear WORLD column of base DoF c
+  double g = 0.0;
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  if (has_grip) {
+    const bool sup = (s < n) && ((gsup >> s) & 1u);
+    double wxp[3];
+    cross3(ang0, pfe, wxp);                // endEffectorA2 (:474-484): LOCAL_WORLD_ALIGNED = lin + ang x p_f
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      a[rr] = sup ? eW[rr] * ((lin0[rr] + wxp[rr]) * ee_w) : 0.0;
+      a[3 + rr] = sup ? eW[3 + rr] * (ang0[rr] * ee_w) : 0.0;
+    }
+    const double* xt = I.in + 28;
+    const double* xp = I.in + 31;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {          // calcTargetVelEE3 (:1052-1157) with R* == R*_prev; EndEffectorB2 (:907-910)
+      const double br = ((xt[i] - xp[i]) * inv_dt + eG[i] * ((xt[i] - pfe[i]) * inv_dt)) * ee_w;
+      g = fma(-a[i], br, g);
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 6; rr += 2) sts2(At + s * 6 + rr, a[rr], a[rr + 1]);
+  if (s < nl) { Kb[4 * s] = lin1[0]; Kb[4 * s + 1] = lin1[1]; Kb[4 * s + 2] = lin1[2]; }
+  if (s < 6) { Bb[4 * s] = lin0[0]; Bb[4 * s + 1] = lin0[1]; Bb[4 * s + 2] = lin0[2]; }
+  // posture rows (qpJointA / qpJointb, :1199-1268) of reduced variable s and of leg DoF s
+  const double dpost = (1.0 / nv) * joint_w;
+  double g1 = 0.0;                          // posture term of leg DoF s in g
+  {
+    const bool prev0 = (c_task_joint == WBC_JOINT_PREV) || (c_task_joint >= WBC_JOINT_MANI && !((P.post_zero >> dof0) & 1u));
+    const bool prev1 = (c_task_joint == WBC_JOINT_PREV) || (c_task_joint >= WBC_JOINT_MANI && !((P.post_zero >> dof1) & 1u));
+    const double u0 = (prev0 && s < n) ? qv[dof0 < 6 ? dof0 : dof0 + 1] : 0.0;
+    const double u1 = (prev1 && s < nl) ? qv[dof1 < 6 ? dof1 : dof1 + 1] : 0.0;
+    if (s < n) g = fma(-dpost, (1.0 / nv) * u0 * joint_w, g);
+    if (s < nl) g1 = -dpost * ((1.0 / nv) * u1 * joint_w);
+  }
+  if (s >= n) g = 0.0;
+  if (A.post_static && P.post_pert) {     // the state qpJointb leaves behind: bounds and integrate see it
+    WSYNC();
+    if (((P.post_pert >> s) & 1u)) I.in[s] = (qv[s] + 0.0002) - (0.0002 * 2);
+    if (16 + s < NQ && ((P.post_pert >> (16 + s)) & 1u)) I.in[16 + s] = (qv[16 + s] + 0.0002) - (0.0002 * 2);
+  }
+  WSYNC();
+  // row s of H' = sum_r At[s][r] At[k][r] (+ posture): straight into the registers the Cholesky sweep works on
+  double h[PN];
+  {
+#pragma unroll
+    for (int k = 0; k < PN; ++k) {
+      const double2a t0 = lds2(At + k * 6), t1 = lds2(At + k * 6 + 2), t2 = lds2(At + k * 6 + 4);
+      h[k] = fma(a[0], t0.x, fma(a[1], t0.y, fma(a[2], t1.x, fma(a[3], t1.y, fma(a[4], t2.x, a[5] * t2.y)))));
+    }
+#pragma unroll
+    for (int k = 0; k < PN; ++k) if (k == s) h[k] += (s < n) ? dpost * dpost : 1.0;
+  }
+
+  // ---- constraint rows that stay: trunk box (trunkConstraint, :707-754) on the base columns; bounds on the row's own lane
+  double clb = 0.0, cub = 0.0;
+  if (c_con_trunk) {
+    double wxp[3];
+    cross3(ang0, ptr, wxp);
+    if (s < 6) { I.Cq[0 * 6 + s] = lin0[2] + wxp[2]; I.Cq[1 * 6 + s] = ang0[0]; I.Cq[2 * 6 + s] = ang0[1]; I.Cq[3 * 6 + s] = ang0[2]; }
+    const double ay = (s == 1) ? Rtr[7] : ((s == 2) ? -Rtr[6] : Rtr[3]);
+    const double ax = (s == 1) ? Rtr[8] : ((s == 2) ? sqrt(fma(Rtr[7], Rtr[7], Rtr[8] * Rtr[8])) : Rtr[0]);
+    const double eul = atan2(ay, ax);        // lanes 1, 2, 3 hold roll, pitch, yaw
+    const double* bc = I.in + 34;
+    if (s < 4) {
+      const double cr = (s == 0) ? ptr[2] : eul;
+      const double vr = (s == 0) ? bc[0] * tb_z : tb_a;
+      clb = (((bc[s] - vr) - cr) * inv_dt) * tb_s;
+      cub = (((bc[s] + vr) - cr) * inv_dt) * tb_s;
+    }
+  }
+  // ---- velDamperJointConstraints (:572-637): of reduced variable s and of leg DoF s
+  double lb = 0.0, ub = 0.0, lb1 = 0.0, ub1 = 0.0;
+  {
+    auto damper = [&](const double qi, const double lo, const double hi, const double vm, double& l_, double& u_) {
+      if (qi <= lo + dqi) { l_ = -dcoef * (qi - lo - dqs) / (dqi - dqs); if (l_ > vm) l_ = vm; if (l_ < -vm) l_ = -vm; } else l_ = -vm;
+      if (qi >= hi - dqi) { u_ = dcoef * (hi - qi - dqs) / (dqi - dqs); if (u_ < -vm) u_ = -vm; if (u_ > vm) u_ = vm; } else u_ = vm;
+      if (l_ > 0) l_ = -l_;
+      if (u_ < 0) u_ = -u_;
+    };
+    if (s < n) damper(qv[dq0], dlo0, dhi0, dvm0, lb, ub);
+    if (s < nl) damper(qv[dq1], dlo1, dhi1, dvm1, lb1, ub1);
+  }
+  WSYNC();
+
+  // ---- G_e = -K_e^-1 B_e: lane l = 3 f + i owns row i of foot f (the base block B is the same for every foot)
+  bool flagged = false;
+  double grow[6] = {0, 0, 0, 0, 0, 0};
+  {
+    const int f = (s < nl) ? s / 3 : 0, i = (s < nl) ? s - 3 * f : 0;
+    const double* k0 = Kb + 4 * (3 * f); const double* k1 = k0 + 4; const double* k2 = k1 + 4;   // columns of K_f (leg DoF 0, 1, 2 of the foot)
+    const double k00 = k0[0], k10 = k0[1], k20 = k0[2], k01 = k1[0], k11 = k1[1], k21 = k1[2], k02 = k2[0], k12 = k2[1], k22 = k2[2];
+    const double a00 = k11 * k22 - k12 * k21, a01 = k02 * k21 - k01 * k22, a02 = k01 * k12 - k02 * k11;
+    const double a10 = k12 * k20 - k10 * k22, a11 = k00 * k22 - k02 * k20, a12 = k02 * k10 - k00 * k12;
+    const double a20 = k10 * k21 - k11 * k20, a21 = k01 * k20 - k00 * k21, a22 = k00 * k11 - k01 * k10;
+    const double det = k00 * a00 + k01 * a10 + k02 * a20;
+    const double sc = fabs(k00) + fabs(k01) + fabs(k02) + fabs(k10) + fabs(k11) + fabs(k12) + fabs(k20) + fabs(k21) + fabs(k22);
+    const bool bad = (s < nl) && !(fabs(det) > A.sing_tol * sc * sc * sc);
+    flagged = (__ballot(bad) >> rbase) & 0xFFFFull;
+    const double id = -1.0 / det;
+    const double r0 = (i == 0) ? a00 : (i == 1) ? a10 : a20, r1 = (i == 0) ? a01 : (i == 1) ? a11 : a21, r2 = (i == 0) ? a02 : (i == 1) ? a12 : a22;
+    if (s < nl) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) grow[c] = id * (r0 * Bb[4 * c] + r1 * Bb[4 * c + 1] + r2 * Bb[4 * c + 2]);
+    }
+    if (s < 12) {
+#pragma unroll
+      for (int c = 0; c < 6; c += 2) sts2(I.G + s * 6 + c, grow[c], grow[c + 1]);
+    }
+    if (s < 12) I.qd[s] = g1;
+  }
+  // leg-bound rows: row p_keep + l = G_l with the leg DoF's velocity bounds; the bounds move p_keep lanes up through LDS
+  if (s < nl) {
+#pragma unroll
+    for (int c = 0; c < 6; c += 2) sts2(I.Cq + (p_keep + s) * 6 + c, grow[c], grow[c + 1]);
+    I.rb[p_keep + s] = lb1; I.rb[16 + p_keep + s] = ub1;
+  }
+  if (s < p_keep) { I.rb[s] = clb; I.rb[16 + s] = cub; }
+  WSYNC();
+  clb = (s < p) ? I.rb[s] : 0.0;
+  cub = (s < p) ? I.rb[16 + s] : 0.0;
+  // g' = Z'g and H' += d^2 G'G on the base block
+  if (s < 6) {
+    const double d2 = dpost * dpost;
+    double gg[6] = {0, 0, 0, 0, 0, 0}, gs = 0.0;
+#pragma unroll
+    for (int l = 0; l < 12; ++l) {
+      const double gl = I.G[l * 6 + s];
+      const double2a t0 = lds2(I.G + l * 6), t1 = lds2(I.G + l * 6 + 2), t2 = lds2(I.G + l * 6 + 4);
+      gg[0] = fma(gl, t0.x, gg[0]); gg[1] = fma(gl, t0.y, gg[1]); gg[2] = fma(gl, t1.x, gg[2]);
+      gg[3] = fma(gl, t1.y, gg[3]); gg[4] = fma(gl, t2.x, gg[4]); gg[5] = fma(gl, t2.y, gg[5]);
+      gs = fma(gl, I.qd[l], gs);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) h[c] = fma(d2, gg[c], h[c]);
+    g += gs;
+  }
+  // a row of the batch tail does nothing; a flagged instance is left to the one-instance kernels (compact list)
+  bool live = valid && !flagged;
+  if (valid && flagged && s == 0) {
+    A.out.status[b] = WBC_QP_DEFERRED;
+    const int slot = atomicAdd(A.defer, 1);
+    A.defer[1 + slot] = b;
+  }
+  WSYNC();
+
+  // ================================ the QP, four at a time =========================================
+  // (qp_core's method; no equalities and no fixed variables are left in this problem, so slot 0 is the first inequality slot)
+  const bool has_b = s < n, has_r = s < p;
+  int status = WBC_QP_OPTIMAL;
+  if (live && ((has_b && ((lb != lb) || (ub != ub))) || (has_r && ((clb != clb) || (cub != cub))))) status = WBC_QP_NUMERICAL;
+  {
+    const unsigned long long nb = __ballot(status != WBC_QP_OPTIMAL);
+    if ((nb >> rbase) & 0xFFFFull) { status = WBC_QP_NUMERICAL; live = false; }
+  }
+  // ---- Cholesky H' = L L' fused with the substitution L y = e_s (rotating registers; column broadcast through I.cl)
+  double y[PN];
+#pragma unroll
+  for (int k = 0; k < PN; ++k) y[k] = (k == s) ? 1.0 : 0.0;
+  double pmin = 1.0;
+#pragma unroll 1
+  for (int j = 0; j < PN; ++j) {
+    I.cl[s] = h[0];
+    WSYNC();
+    const double* cj = I.cl + j;
+    const double pj = cj[0];
+    pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;
+    const double rinv = rsqrt(pj), ipj = rinv * rinv;
+    double cm[PN];
+#pragma unroll
+    for (int rr = 1; rr < PN; ++rr) cm[rr] = cj[rr];
+    const double th = h[0] * ipj, ty = y[0] * ipj, yk = y[0] * rinv;
+#pragma unroll
+    for (int rr = 1; rr < PN; ++rr) h[rr - 1] = fma(-th, cm[rr], h[rr]);
+#pragma unroll
+    for (int rr = 1; rr < PN; ++rr) y[rr - 1] = fma(-ty, cm[rr], y[rr]);
+    y[PN - 1] = yk;
+    LDS_THEN_VALU(PN, 2 * PN + 2);
+    h[PN - 1] = 0.0;
+    WSYNC();
+  }
+  if (live && !(pmin > 0.0)) { status = WBC_QP_NUMERICAL; live = false; }
+  // y = row s of J0 = L^-T.  jf2 = |J0|_F^2 per instance
+  double sq = 0.0;
+#pragma unroll
+  for (int k = 0; k < PN; ++k) sq = fma(y[k], y[k], sq);
+  const double jf2 = rsum16(sq);
+  double* const J = I.M2;
+  double* const T = I.M1;
+#pragma unroll
+  for (int k = 0; k < PN; k += 2) { sts2(J + s * PLD + k, y[k], y[k + 1]); sts2(T + s * PLD + k, 0.0, 0.0); }
+  I.tv[s] = g;
+  // |C_r|^2 of row s
+  double cn2 = 0.0;
+  if (has_r) {
+    const double2a t0 = lds2(I.Cq + s * 6), t1 = lds2(I.Cq + s * 6 + 2), t2 = lds2(I.Cq + s * 6 + 4);
+    cn2 = t0.x * t0.x + t0.y * t0.y + t1.x * t1.x + t1.y * t1.y + t2.x * t2.x + t2.y * t2.y;
+  }
+  WSYNC();
+  // x0 = -J0 (J0' g): the unconstrained minimiser
+  double x;
+  {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < PN; ++i) t = fma(J[i * PLD + s], I.tv[i], t);
+    I.dv[s] = -t;
+    WSYNC();
+    double xa = 0.0, xb = 0.0;
+#pragma unroll
+    for (int k = 0; k < PN; k += 2) { const double2a v2 = lds2(I.dv + k); xa = fma(y[k], v2.x, xa); xb = fma(y[k + 1], v2.y, xb); }
+    x = has_b ? xa + xb : 0.0;
+  }
+  // ---- dual active-set iterations (per-row state; loops run until every row of the wave is done)
+  bool act_b = false, act_r = false;
+  double u = 0.0;
+  int a_code = 0, q = 0, iters = 0;
+  const int max_iter = 10 * (n + p) + 20;
+  bool searching = live;                    // row still iterating
+#pragma unroll 1
+  for (;;) {
+    // most violated inactive inequality of each row
+    WSYNC();
+    I.xv[s] = x;
+    WSYNC();
+    double best = 0.0; int code = -1;
+    if (has_b && !act_b) {
+      if (lb > -QP_INF) { const double sl = x - lb; if (sl < -1e-9 * fmax(1.0, fabs(lb)) && sl < best) { best = sl; code = s; } }
+      if (ub < QP_INF) { const double sl = ub - x; if (sl < -1e-9 * fmax(1.0, fabs(ub)) && sl < best) { best = sl; code = s | 256; } }
+    }
+    if (has_r && !act_r) {
+      const double2a c0 = lds2(I.Cq + s * 6), c1 = lds2(I.Cq + s * 6 + 2), c2 = lds2(I.Cq + s * 6 + 4);
+      const double2a x0 = lds2(I.xv), x1 = lds2(I.xv + 2), x2 = lds2(I.xv + 4);
+      const double v = fma(c0.x, x0.x, fma(c0.y, x0.y, fma(c1.x, x1.x, fma(c1.y, x1.y, fma(c2.x, x2.x, c2.y * x2.y)))));
+      if (clb > -QP_INF) { const double sl = v - clb; if (sl < -1e-9 * fmax(1.0, fabs(clb)) && sl < best) { best = sl; code = n + s; } }
+      if (cub < QP_INF) { const double sl = cub - v; if (sl < -1e-9 * fmax(1.0, fabs(cub)) && sl < best) { best = sl; code = (n + s) | 256; } }
+    }
+    const double worst = rmin16(best);
+    if (searching && !(worst < 0.0)) searching = false;               // primal feasible -> this row is optimal
+    if (!__ballot(searching)) break;
+    const unsigned long long wm = __ballot(searching && best == worst);
+    const int wl = __ffs((int)((wm >> rbase) & 0xFFFFull)) - 1;      // first lane of the row holding the worst violation
+    const int wc = bpermi(code, rbase + (wl < 0 ? 0 : wl));
+    const int ip = wc & 255, ip_side = (wc >> 8) & 1;
+    const bool is_row = ip >= n;
+    const int rr_ = is_row ? ip - n : 0;
+    const int src = rbase + (is_row ? rr_ : (ip & 15));
+    const double b_ip = bperm(is_row ? (ip_side ? -cub : clb) : (ip_side ? -ub : lb), src);
+    const double np2 = is_row ? bperm(cn2, src) : 1.0;
+    const double sgn = ip_side ? -1.0 : 1.0;
+    double s_ip = worst, u_ip = 0.0;
+    bool stepping = searching;              // row inside the partial-step loop for its constraint
+    int drop_l = -1;
+#pragma unroll 1
+    for (;;) {
+      if (stepping && ++iters > max_iter) { status = WBC_QP_MAX_ITER; stepping = false; searching = false; }
+      // ---- drop slot l of the rows that ask for it: Givens sequence read off the removed row of T (rare path)
+      if (__ballot(stepping && drop_l >= 0)) {
+        const bool dr = stepping && drop_l >= 0;
+        const int l = dr ? drop_l : 0;
+        const int lc = bpermi(a_code, rbase + l) & 255;
+        if (dr) { if (lc >= n) { if (s == lc - n) act_r = false; } else { if (s == lc) act_b = false; } }
+        WSYNC();
+        I.yv[s] = u; I.tv[s] = (double)a_code;
+        WSYNC();
+        if (dr && s >= l && s < q - 1) { u = I.yv[s + 1]; a_code = (int)I.tv[s + 1]; }
+        if (dr && s == q - 1) { u = 0.0; a_code = 0; }
+        const int srow = (s >= l) ? ((s + 1 < PN) ? s + 1 : s) : s;
+        double tx = T[srow * PLD + l];
+        double jx = J[s * PLD + l];
+        double hrun = T[l * PLD + l];
+        const int kend = dr ? q - 1 : 0;    // this row's rotations run k = l .. q - 2
+#pragma unroll 1
+        for (int k0 = 0; k0 < PN - 1; ++k0) {
+          const bool on = dr && (l + k0 < kend);
+          if (!__ballot(on)) break;
+          const int k = on ? l + k0 : 0;
+          const double tb = T[l * PLD + k + 1];
+          const double nrm2 = fma(hrun, hrun, tb * tb);
+          double c_ = 1.0, s_ = 0.0, rho = 0.0;
+          if (nrm2 > 0.0) { const double ri = rsqrt(nrm2); c_ = tb * ri; s_ = -hrun * ri; rho = nrm2 * ri; }
+          const double ty_ = T[srow * PLD + k + 1];
+          const double jy = J[s * PLD + k + 1];
+          WSYNC();
+          if (on) {
+            hrun = rho;
+            if (s < q - 1) T[s * PLD + k] = fma(c_, tx, s_ * ty_);
+            if (s < n) J[s * PLD + k] = fma(c_, jx, s_ * jy);
+            tx = fma(-s_, tx, c_ * ty_);
+            jx = fma(-s_, jx, c_ * jy);
+          }
+          WSYNC();
+        }
+        WSYNC();
+        if (dr) {
+          if (s < q) T[s * PLD + q - 1] = 0.0;
+        }
+        WSYNC();
+        if (dr) {
+          if (s < q) T[(q - 1) * PLD + s] = 0.0;
+          if (s < n) J[s * PLD + q - 1] = jx;
+          --q;
+        }
+        WSYNC();
+        // slack of the constraint being added, at the current x
+        I.xv[s] = x;
+        WSYNC();
+        if (dr) {
+          double v;
+          if (is_row) {
+            const double2a c0 = lds2(I.Cq + rr_ * 6), c1 = lds2(I.Cq + rr_ * 6 + 2), c2 = lds2(I.Cq + rr_ * 6 + 4);
+            const double2a x0 = lds2(I.xv), x1 = lds2(I.xv + 2), x2 = lds2(I.xv + 4);
+            v = fma(c0.x, x0.x, fma(c0.y, x0.y, fma(c1.x, x1.x, fma(c1.y, x1.y, fma(c2.x, x2.x, c2.y * x2.y)))));
+          } else v = I.xv[ip & 15];
+          s_ip = sgn * v - b_ip;
+          drop_l = -1;
+        }
+      }
+      if (!__ballot(stepping)) break;
+      // ---- d = J'n, z = J2 d2, r = T d1
+      double d = 0.0;
+      if (is_row) {
+        const double2a c0 = lds2(I.Cq + rr_ * 6), c1 = lds2(I.Cq + rr_ * 6 + 2), c2 = lds2(I.Cq + rr_ * 6 + 4);
+        d = fma(J[0 * PLD + s], c0.x, fma(J[1 * PLD + s], c0.y, fma(J[2 * PLD + s], c1.x, fma(J[3 * PLD + s], c1.y,
+            fma(J[4 * PLD + s], c2.x, J[5 * PLD + s] * c2.y))))) * sgn;
+      } else d = sgn * J[(ip & 15) * PLD + s];
+      if (!has_b || !stepping) d = 0.0;
+      WSYNC();
+      I.dv[s] = d; I.yv[s] = (s >= q) ? d : 0.0;
+      WSYNC();
+      const double zn = rsum16(s >= q ? d * d : 0.0);
+      double z = 0.0, zb = 0.0, rv = 0.0, rvb = 0.0;
+#pragma unroll
+      for (int k = 0; k < PN; k += 2) {
+        const double2a j2 = lds2(J + s * PLD + k); const double2a y2 = lds2(I.yv + k);
+        z = fma(j2.x, y2.x, z); zb = fma(j2.y, y2.y, zb);
+      }
+      z += zb;
+#pragma unroll
+      for (int k = 0; k < PN; k += 2) {
+        const double2a t2 = lds2(T + s * PLD + k); const double2a d2 = lds2(I.dv + k);
+        rv = fma(t2.x, d2.x, rv); rvb = fma(t2.y, d2.y, rvb);
+      }
+      rv += rvb;
+      if (s >= q) rv = 0.0;
+      if (!has_b) z = 0.0;
+      const bool have_step = zn > 100.0 * n * EPS2 * jf2 * np2;
+      const bool cand = (s < q) && (rv > 0.0);
+      const double ratio = cand ? u / rv : INFINITY;
+      const double t1 = rmin16(ratio);
+      const unsigned long long lm = __ballot(cand && ratio == t1);
+      const int l = (t1 < INFINITY) ? __ffs((int)((lm >> rbase) & 0xFFFFull)) - 1 : -1;
+      const double t2 = have_step ? -s_ip / zn : INFINITY;
+      const double t = fmin(t1, t2);
+      if (stepping && !(t < INFINITY)) { status = WBC_QP_INFEASIBLE; stepping = false; searching = false; }
+      if (stepping) {
+        if (have_step) x = fma(t, z, x);
+        u = fma(-t, rv, u);
+        u_ip += t;
+      }
+      const bool add = stepping && have_step && t == t2;
+      if (__ballot(add)) {
+        // ---- add: Householder P with P d2 = delta e1; J2 <- J2 P; T gets column (-r/delta, 1/delta)
+        const double dq = bperm(d, rbase + (q & 15));
+        const double sz = sqrt(zn);
+        const double delta = (dq >= 0.0) ? -sz : sz;
+        const double vv = 2.0 * (zn - delta * dq);
+        const double w = (z - delta * J[s * PLD + (q & 15)]) * ((vv > 0.0) ? 2.0 / vv : 0.0);
+        if (add && has_b && vv > 0.0) {
+#pragma unroll
+          for (int k = 0; k < PN; k += 2) {
+            const double2a j2 = lds2(J + s * PLD + k); const double2a y2 = lds2(I.yv + k);   // yv = d for k >= q, else 0
+            const double v0 = (k == q) ? y2.x - delta : y2.x;
+            const double v1 = (k + 1 == q) ? y2.y - delta : y2.y;
+            sts2(J + s * PLD + k, fma(-w, v0, j2.x), fma(-w, v1, j2.y));
+          }
+        }
+        if (add) {
+          const double idel = 1.0 / delta;
+          if (s < q) T[s * PLD + q] = -rv * idel;
+          if (s == q) { T[s * PLD + q] = idel; u = u_ip; a_code = wc; }
+          if (is_row) { if (s == rr_) act_r = true; } else { if (s == (ip & 15)) act_b = true; }
+          ++q;
+          stepping = false;                 // this row goes back to the search
+        }
+      }
+      if (stepping) drop_l = l;             // blocking slot: dropped at the top of the next pass, then the step is retried
+    }
+  }
+  if (status == WBC_QP_OPTIMAL) {
+    const unsigned long long bad = __ballot(has_b && !(fabs(x) <= 1.7976931348623157e308));
+    if ((bad >> rbase) & 0xFFFFull) status = WBC_QP_NUMERICAL;
+  }
+  if (status != WBC_QP_OPTIMAL) x = 0.0;
+
+  // ---- x = Z y, q̇ by DoF through LDS, outputs
+  WSYNC();
+  I.xv[s] = has_b ? x : 0.0;
+  I.qd[s] = 0.0; I.qd[16 + s] = 0.0;
+  WSYNC();
+  double x1 = 0.0;
+  if (s < nl) {
+    const double2a v0 = lds2(I.xv), v1 = lds2(I.xv + 2), v2 = lds2(I.xv + 4);
+    x1 = fma(grow[0], v0.x, fma(grow[1], v0.y, fma(grow[2], v1.x, fma(grow[3], v1.y, fma(grow[4], v2.x, grow[5] * v2.y)))));
+    I.qd[dof1] = x1;
+  }
+  if (s < n) I.qd[dof0] = x;
+  WSYNC();
+  const bool wr = valid && !flagged;
+  if (wr) {
+    double* qo = A.out.qdot + (size_t)b * NV;
+    qo[s] = I.qd[s];
+    if (16 + s < NV) qo[16 + s] = I.qd[16 + s];
+    if (s == 0) {
+      A.out.status[b] = status;
+      if (A.out.iters) A.out.iters[b] = iters + nl + P.nlock;
+    }
+  }
+  // ---- jointVelocitiestoConfig (Robot_Wrapper4.py:440-441)
+  if (A.out.q_next) {
+    WSYNC();
+    I.xv[s] = (s < 6) ? I.qd[s] * dt : 0.0;
+    WSYNC();
+    double* qn = A.out.q_next + (size_t)b * NQ;
+    if (wr) {
+      integrate_ff(I, s, qn);
+      // 1-DoF joints: q + v dt, DoF by DoF (two per lane; a locked DoF's velocity is 0, the padding of a smaller model stays 0)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int d = 6 + s + 16 * hh;
+        if (d < nv) { const int qi = M.col_q[d]; qn[qi] = qv[qi] + I.qd[d] * dt; }
+      }
+      if (s < NQ - nq) qn[nq + s] = 0.0;
+    }
+  }
+}
+
 static int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   (void)what;
@@ -2731,7 +3363,12 @@ int launch_tick_deferred(const KernelArgs& a, void* stream) {
   hipLaunchKernelGGL(wbc_tick_deferred_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   return check_launch("tick_deferred");
 }
+int launch_tick_sim3p(const KernelArgs& a, void* stream) {
+  hipLaunchKernelGGL(wbc_tick_sim3p_kernel, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  return check_launch("tick_sim3p");
+}
 int sim3_lds_bytes() { return (int)sizeof(SmemC); }
+int sim3p_lds_bytes() { return (int)sizeof(SmemP); }
 int launch_qp(const QpArgs& a, int grid, void* stream) {
   hipLaunchKernelGGL(wbc_qp_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a);
   return check_launch("qp");
