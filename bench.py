@@ -134,8 +134,8 @@ class GpuEngine:
         self.cfg = wbc_model.sim3_config(self.model, Joint=args.posture)
         self.bt = WbcBatch(self.model, args.batch, device_id=local)
         self.bt.configure(self.cfg)
-        self.options = {"jtj_mfma": int(args.jtj_mfma), "presolve": 1, "sim3_kernel": 1, "dbg_alias_inputs": 0}
-        for env, opt in (("WBC_PRESOLVE", "presolve"), ("WBC_SIM3_KERNEL", "sim3_kernel"), ("WBC_DBG_ALIAS", "dbg_alias_inputs")):
+        self.options = {"jtj_mfma": int(args.jtj_mfma), "presolve": 1, "sim3_kernel": 1, "packed_kernel": 1, "dbg_alias_inputs": 0}
+        for env, opt in (("WBC_PRESOLVE", "presolve"), ("WBC_SIM3_KERNEL", "sim3_kernel"), ("WBC_PACKED_KERNEL", "packed_kernel"), ("WBC_DBG_ALIAS", "dbg_alias_inputs")):
             if os.environ.get(env) not in (None, ""):       # diagnostic A/B switches: they change WHAT is measured, so they are reported
                 self.options[opt] = int(os.environ[env])
         for k, v in self.options.items():
@@ -168,7 +168,8 @@ class GpuEngine:
         return {k: v.cpu().numpy() for k, v in self.dev_out.items()}
 
     def path(self):
-        return "wbc_tick_sim3_kernel (+ wbc_tick_deferred_kernel)" if self.bt.stat("last_path") == 1 else "wbc_tick_kernel<MODE_TICK>"
+        return {2: "wbc_tick_sim3p_kernel (packed: four instances per wavefront; + wbc_tick_deferred_kernel)",
+                1: "wbc_tick_sim3_kernel (+ wbc_tick_deferred_kernel)"}.get(self.bt.stat("last_path"), "wbc_tick_kernel<MODE_TICK>")
 
     def closed_loop(self, host_in, ticks):
         t = self.torch

@@ -300,6 +300,9 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *   "sim3_kernel"      [1] batches whose every model has such an elimination plan, <= 16 constraint rows and no orientation
  *                          references run on the compact wbc_tick_sim3_kernel (+ a second pass of the general kernel over the
  *                          instances whose leg blocks it could not eliminate); 0: the general kernel does the elimination.
+ *   "packed_kernel"    [1] batches of the sim3 switch-set family itself (Grip task or none, trunk box + foot contacts, velocity
+ *                          bounds, posture PREV / Tikhonov / static HYBRID; no warm start, no orientation references) run FOUR
+ *                          instances per wavefront (wbc_tick_sim3p_kernel); 0: one instance per wavefront (wbc_tick_sim3_kernel).
  *   "presolve_tol_exp" [7] a stance-leg 3 x 3 block K with |det K| <= 10^-value (sum |K_ij|)^3 is treated as rank deficient: the
  *                          compact kernel eliminates it with column pivoting and keeps one leg velocity + one contact equality
  *                          in the reduced QP (the general kernel's in-kernel presolve falls back to the full problem).
@@ -320,7 +323,8 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          only the run time means something (tools/ablate_sim3.py). */
 int wbc_batch_set_option(WbcBatch* b, const char* name, int value);
 
-/* Read-only statistics of a handle: "last_path" (kernel the last tick ran on: 0 general, 1 compact sim3 + second pass),
+/* Read-only statistics of a handle: "last_path" (kernel the last tick ran on: 0 general, 1 compact sim3 + second pass, 2 packed
+ * compact sim3 — four instances per wavefront — + second pass),
  * "deferred_last" (instances the last sim3-kernel tick left to the second pass; waits for `stream`), "pivoted_last" (instances
  * that took the pivoted elimination, with option "count_pivoted"),
  * "sim3_lds_bytes" / "tick_lds_bytes" (LDS per instance of the two tick kernels). */

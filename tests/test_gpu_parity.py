@@ -296,7 +296,7 @@ def test_sim3_kernel_pivots_rank_deficient_leg_blocks(wx200):
     bt.configure(cfg)
     bt.set_option("count_pivoted", 1)
     got = bt.tick(sub, DT)
-    assert bt.stat("last_path") == 1 and bt.stat("deferred_last") == 0
+    assert bt.stat("last_path") == 1 and bt.stat("deferred_last") == 0      # (count_pivoted selects the one-instance compact kernel)
     expect = int((ratio[idx] <= 1e-7).sum())
     assert abs(bt.stat("pivoted_last") - expect) <= 1          # (a ratio within rounding of the threshold may fall either way)
     assert (got["status"] == ref["status"]).all() and (got["status"] >= 0).all()
@@ -364,7 +364,7 @@ def test_tick_and_assemble_on_the_matrix_cores(wx200, cfg_name):
         assert relerr(a[k], ar[k]) < 1e-11, (k, relerr(a[k], ar[k]))
     got = bt.tick(d, DT, want_q_next=True)
     assert bt.stat("last_path") == 0                                  # general kernel
-    assert path_default == (1 if cfg_name == "c3" else 0)
+    assert path_default == (2 if cfg_name == "c3" else 0)               # 2: the packed compact kernel (four instances per wavefront)
     assert (got["status"] == ref["status"]).all()
     ok = ref["status"] == 0
     assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
@@ -898,7 +898,7 @@ def test_mixed_morphology_full_size_properties(wx200, px100):
     for i, c in enumerate(cfgs):
         bt.configure(c, i)
     got = bt.tick(d, DT)
-    assert bt.stat("last_path") == 1
+    assert bt.stat("last_path") == 2                                   # the packed compact kernel, both morphologies in one wavefront
     a = bt.assemble(d, DT, want=("C", "Clb", "Cub", "lb", "ub"))
     ok = got["status"] == 0
     assert ok.mean() > 0.98
@@ -1013,7 +1013,7 @@ def test_warm_started_tick_reaches_the_cold_optimum(wx200, px100, cfg_name):
             assert (got["working_set"][ok] == cold["working_set"][ok]).mean() > 0.98
     # the working set means the same constraints on every kernel path: general-path sets seed the compact kernel and back
     if cfg_name == "c3":
-        assert bt.stat("last_path") == 1
+        assert bt.stat("last_path") == 1                               # a working set was passed: the warm one-instance compact kernel
         bt.set_option("sim3_kernel", 0)
         bt.set_option("presolve", 0)
         gen = bt.tick(dict(d, working_set=cold["working_set"]), DT, want_working_set=True)
