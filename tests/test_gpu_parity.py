@@ -249,23 +249,31 @@ def test_contact_presolve_and_general_path_agree(wx200, px100, cfg_name):
     for i, c in enumerate(cfgs):
         bt.configure(c, i)
     res = {}
-    # (presolve, sim3_kernel): compact sim3 kernel + deferred pass / general kernel with presolve / general path only
-    for key in ((1, 1), (1, 0), (0, 0)):
+    # (presolve, sim3_kernel, packed_kernel): packed compact kernel (four instances per wavefront; where the configuration is of
+    # the sim3 family, else the same as the next) / compact sim3 kernel / general kernel with presolve / general path only
+    for key in ((1, 1, 1), (1, 1, 0), (1, 0, 0), (0, 0, 0)):
         bt.set_option("presolve", key[0])
         bt.set_option("sim3_kernel", key[1])
+        bt.set_option("packed_kernel", key[2])
         res[key] = bt.tick(d, DT, want_q_next=True)
         assert (res[key]["status"] == ref["status"]).all(), key
+        if key == (1, 1, 1):
+            packed_ran = bt.stat("last_path") == 2
     ok = ref["status"] == 0
     assert ok.mean() > 0.9
     errs = {k: np.abs(v["qdot"] - ref["qdot"])[ok].max() for k, v in res.items()}
-    print("%s: sim3 kernel err %.3e, presolve err %.3e, general err %.3e, iters %.2f / %.2f / %.2f / oracle %.2f" % (
-        cfg_name, errs[(1, 1)], errs[(1, 0)], errs[(0, 0)], res[(1, 1)]["iters"][ok].mean(), res[(1, 0)]["iters"][ok].mean(),
-        res[(0, 0)]["iters"][ok].mean(), ref["iters"][ok].mean()))
+    print("%s: packed (%s) err %.3e, sim3 kernel err %.3e, presolve err %.3e, general err %.3e, iters %.2f / %.2f / %.2f / %.2f / oracle %.2f" % (
+        cfg_name, "ran" if packed_ran else "not eligible", errs[(1, 1, 1)], errs[(1, 1, 0)], errs[(1, 0, 0)], errs[(0, 0, 0)],
+        res[(1, 1, 1)]["iters"][ok].mean(), res[(1, 1, 0)]["iters"][ok].mean(), res[(1, 0, 0)]["iters"][ok].mean(),
+        res[(0, 0, 0)]["iters"][ok].mean(), ref["iters"][ok].mean()))
+    assert packed_ran == (cfg_name == "c3")
     assert max(errs.values()) < QDOT_TOL
-    assert np.abs(res[(1, 1)]["qdot"] - res[(0, 0)]["qdot"])[ok].max() < QDOT_TOL
-    assert np.abs(res[(1, 1)]["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    for key in ((1, 1, 1), (1, 1, 0)):
+        assert np.abs(res[key]["qdot"] - res[(0, 0, 0)]["qdot"])[ok].max() < QDOT_TOL
+        assert np.abs(res[key]["q_next"] - ref["q_next"])[ok].max() < 1e-7
     if cfg_name == "c3":
-        assert np.abs(res[(1, 1)]["qdot"] - res[(1, 0)]["qdot"])[ok].max() < 1e-9      # same reduced QP on both kernels
+        assert np.abs(res[(1, 1, 0)]["qdot"] - res[(1, 0, 0)]["qdot"])[ok].max() < 1e-9      # same reduced QP on both one-instance kernels
+        assert (res[(1, 1, 1)]["iters"] == res[(1, 1, 0)]["iters"])[ok].mean() > 0.98        # and the same working-set changes when packed
     bt.close()
 
 
