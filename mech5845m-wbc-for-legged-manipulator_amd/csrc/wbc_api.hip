@@ -296,7 +296,7 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
   // task, the kept rows = the trunk box (base support only), velocity bounds on, a posture mode it can form itself, every
   // joint it needs within tree depth 6 and at most 16 joints per level
   bool ok = c.use_bounds && !c.task_trunk && !c.task_com && !c.con_com && !c.con_ee[4] && p_keep == (c.con_trunk ? 4 : 0) &&
-            n_red <= 16 && (P->task_ee_mask & ~16u) == 0 && P->legrows == 0 &&
+            n_red <= 12 && (P->task_ee_mask & ~16u) == 0 && P->legrows == 0 &&
             (c.task_joint == WBC_JOINT_TIKHONOV || c.task_joint == WBC_JOINT_PREV || (c.task_joint >= WBC_JOINT_MANI && c.task_joint <= WBC_JOINT_HYBRID && P->post_static && !P->post_fk2));
   int need_depth = 0;
   for (int k = 0; k < n_red; ++k) if (M.depth[M.col_joint[P->Fd[k]]] > need_depth) need_depth = M.depth[M.col_joint[P->Fd[k]]];

@@ -2725,22 +2725,20 @@ __global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, cons
 // box + foot contacts, velocity bounds on, no CoM rows, no orientation references, nothing warm. Instances with a rank-deficient
 // leg block go to the compact list and are redone by the one-instance kernels. Same arithmetic per instance as process_sim3.
 // ================================================================================================
-constexpr int PLD = 18;                     // row stride of the 16 x 16 matrices (even: rows are 16-byte aligned for ds_read_b128)
-constexpr int PN = 16;                      // lanes, reduced variables and rows per instance
+constexpr int PLD = 18;                     // row stride of the matrices (even: rows are 16-byte aligned for ds_read_b128)
+constexpr int PN = 16;                      // lanes = constraint rows per instance
+constexpr int PV = 12;                      // reduced variables per instance the packed kernel is compiled for (n' = 11 / 10 here)
 struct __attribute__((aligned(16))) PInst {
-  double M1[PN * PLD];                      // oMi scratch [24][12] -> T = R^-1
-  double M2[PN * PLD];                      // At [16][6], K / B scratch -> J
+  double M1[PV * PLD];                      // oMi scratch (runs on into M2: 24 x 12 doubles) -> T = R^-1
+  double M2[PV * PLD];                      // ... At [16][6], K / B scratch; sin / cos table in its tail during FK -> J
   double Cq[PN * 6];                        // reduced constraint rows x base columns (all the reduced rows touch the base only)
   double G[12 * 6];                         // eliminated leg DoF l (row) x base DoF (column)
-  double in[48];                            // q [27], gripper target [3] @28, previous [3] @31, trunk box centre [4] @34
-  double sc[48];                            // sin, cos of joint j's angle at [2 j]
+  double in[40];                            // q [27], gripper target [3] @28, previous [3] @31, trunk box centre [4] @34
   double xv[PN], dv[PN], yv[PN], tv[PN];
-  double cl[32];                            // Cholesky column broadcast; entries 16..31 stay zero
-  double rb[32];                            // row bounds staging: clb [16], cub [16]
+  double cl[32];                            // Cholesky column broadcast (entries 12..31 stay zero); before that: row-bound staging
   double qd[32];                            // by-DoF staging: posture term of the leg DoF, later qdot
-  double pad_[24];                          // instance stride = 1024 doubles: the four instances' rows fall on the same banks pattern
 };
-static_assert(sizeof(PInst) == 8192, "PInst must be 8 KB");
+static_assert(sizeof(PInst) == 6144, "PInst: 768 doubles, so that the four instances' rows fall on the same bank pattern");
 struct __attribute__((aligned(16))) SmemP { PInst I[4]; };
 
 __device__ __forceinline__ double rsum16(double v) {     // sum over the lane's 16-lane row, result in every lane of the row
@@ -2782,7 +2780,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     else if (s < 6) ex = A.in.prev_ee_target ? A.in.prev_ee_target[(size_t)b * 15 + 12 + (s - 3)] : 0.0;
     else if (s < 10) ex = A.in.trunk_box_center ? A.in.trunk_box_center[(size_t)b * 4 + (s - 6)] : 0.0;
     I.in[s] = q0;
-    I.in[16 + s] = q1;
+    if (16 + s < 28) I.in[16 + s] = q1;
     if (s < 10) I.in[28 + s] = ex;
     I.cl[s] = 0.0; I.cl[16 + s] = 0.0;
   }
@@ -2791,19 +2789,6 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   const bool c_con_trunk = fl & 2u;
   const int c_task_joint = (fl >> 4) & 7u;
   const bool has_grip = (P.task_ee_mask >> 4) & 1u;
-  // FK schedule of this lane (tree depth 2..6) and its joints' constants
-  int fj_[5], fpar_[5], fa0_[5], fa1_[5], fa2_[5], fq_[5], frev_[5];
-  double ft_[5][3];
-#pragma unroll
-  for (int L = 0; L < 5; ++L) {
-    const int j = P.fk_sched[L][s];
-    const int jj = j < 0 ? 1 : j;
-    fj_[L] = j; fpar_[L] = M.parent[jj]; fq_[L] = M.idx_q[jj];
-    fa0_[L] = 3 * M.ax0[jj]; fa1_[L] = 3 * M.ax1[jj]; fa2_[L] = 3 * M.ax2[jj];
-    const int jt = M.jtype[jj];
-    frev_[L] = (jt >= WBC_JT_RX && jt <= WBC_JT_RZ) ? 1 : 0;
-    ft_[L][0] = M.tp[jj][0]; ft_[L][1] = M.tp[jj][1]; ft_[L][2] = M.tp[jj][2];
-  }
   // columns: pass 0 = reduced variable s, pass 1 = eliminated leg DoF s
   const int dof0 = (s < n) ? P.Fd[s] : 0, dof1 = (s < nl) ? P.legd[s < 12 ? s : 0] : 0;
   const int c0_joint = M.col_joint[dof0], c0_lin = M.col_lin[dof0], c0_ang = M.col_ang[dof0];
@@ -2826,7 +2811,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   const double* const qv = I.in;
 
   // ---- sin / cos of the joint angles: joint j (>= 2) reads q[idx_q[j]]; two joints per lane
-  double* const oMi = I.M1;
+  double* const oMi = I.M1;                 // [24][12], runs on into M2
+  double* const sc = I.M2 + PV * PLD - 48;  // sin / cos table: the tail of M2, free until J is written
   {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -2835,7 +2821,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         const int jt = M.jtype[j];
         const double th = qv[M.idx_q[j]];
         const SinCos t = sincos_cw((jt >= WBC_JT_RX && jt <= WBC_JT_RZ) ? th : 0.0);
-        I.sc[2 * j] = t.s; I.sc[2 * j + 1] = t.c;
+        sc[2 * j] = t.s; sc[2 * j + 1] = t.c;
       }
     }
     // root free-flyer (joint 1): R from the quaternion exactly as Eigen's toRotationMatrix, p = xyz; R column-major then p
@@ -2850,23 +2836,29 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     }
   }
   WSYNC();
-  // ---- P1: pin.forwardKinematics, level by level (Robot_Wrapper4.py:400)
-#pragma unroll
+  // ---- P1: pin.forwardKinematics, level by level (Robot_Wrapper4.py:400). The level's joint and its constants are fetched
+  // inside the loop (L1-resident tables): kept live for all five levels they cost 60 VGPRs
+#pragma unroll 1
   for (int L = 0; L < 5; ++L) {
-    if (fj_[L] >= 0) {
-      const double* Pp = oMi + 12 * fpar_[L];
-      const double sn = frev_[L] ? I.sc[2 * fj_[L]] : 0.0, cs = frev_[L] ? I.sc[2 * fj_[L] + 1] : 1.0;
-      const double pris = frev_[L] ? 0.0 : qv[fq_[L]];
+    const int j = P.fk_sched[L][s];
+    if (j >= 0) {
+      const int jt = M.jtype[j];
+      const bool rev = jt >= WBC_JT_RX && jt <= WBC_JT_RZ;
+      const int a0 = 3 * M.ax0[j], a1 = 3 * M.ax1[j], a2 = 3 * M.ax2[j];
+      const double t0 = M.tp[j][0], t1 = M.tp[j][1], t2 = M.tp[j][2];
+      const double* Pp = oMi + 12 * M.parent[j];
+      const double sn = rev ? sc[2 * j] : 0.0, cs = rev ? sc[2 * j + 1] : 1.0;
+      const double pris = rev ? 0.0 : qv[M.idx_q[j]];
       double Av[3], Bv[3], Cv[3], Pv[3];
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr) { Av[rr] = Pp[fa0_[L] + rr]; Bv[rr] = Pp[fa1_[L] + rr]; Cv[rr] = Pp[fa2_[L] + rr]; Pv[rr] = Pp[9 + rr]; }
-      double* Po = oMi + 12 * fj_[L];
+      for (int rr = 0; rr < 3; ++rr) { Av[rr] = Pp[a0 + rr]; Bv[rr] = Pp[a1 + rr]; Cv[rr] = Pp[a2 + rr]; Pv[rr] = Pp[9 + rr]; }
+      double* Po = oMi + 12 * j;
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr) {
-        Po[fa0_[L] + rr] = Av[rr];
-        Po[fa1_[L] + rr] = cs * Bv[rr] + sn * Cv[rr];
-        Po[fa2_[L] + rr] = cs * Cv[rr] - sn * Bv[rr];
-        Po[9 + rr] = Pv[rr] + Av[rr] * (ft_[L][0] + pris) + Bv[rr] * ft_[L][1] + Cv[rr] * ft_[L][2];
+        Po[a0 + rr] = Av[rr];
+        Po[a1 + rr] = cs * Bv[rr] + sn * Cv[rr];
+        Po[a2 + rr] = cs * Cv[rr] - sn * Bv[rr];
+        Po[9 + rr] = Pv[rr] + Av[rr] * (t0 + pris) + Bv[rr] * t1 + Cv[rr] * t2;
       }
     }
     WSYNC();
@@ -2946,15 +2938,15 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   }
   WSYNC();
   // row s of H' = sum_r At[s][r] At[k][r] (+ posture): straight into the registers the Cholesky sweep works on
-  double h[PN];
+  double h[PV];
   {
 #pragma unroll
-    for (int k = 0; k < PN; ++k) {
+    for (int k = 0; k < PV; ++k) {
       const double2a t0 = lds2(At + k * 6), t1 = lds2(At + k * 6 + 2), t2 = lds2(At + k * 6 + 4);
       h[k] = fma(a[0], t0.x, fma(a[1], t0.y, fma(a[2], t1.x, fma(a[3], t1.y, fma(a[4], t2.x, a[5] * t2.y)))));
     }
 #pragma unroll
-    for (int k = 0; k < PN; ++k) if (k == s) h[k] += (s < n) ? dpost * dpost : 1.0;
+    for (int k = 0; k < PV; ++k) if (k == s) h[k] += (s < n) ? dpost * dpost : 1.0;   // (lanes >= PV carry an all-zero row: harmless)
   }
 
   // ---- constraint rows that stay: trunk box (trunkConstraint, :707-754) on the base columns; bounds on the row's own lane
@@ -3018,12 +3010,12 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   if (s < nl) {
 #pragma unroll
     for (int c = 0; c < 6; c += 2) sts2(I.Cq + (p_keep + s) * 6 + c, grow[c], grow[c + 1]);
-    I.rb[p_keep + s] = lb1; I.rb[16 + p_keep + s] = ub1;
+    I.cl[p_keep + s] = lb1; I.cl[16 + p_keep + s] = ub1;
   }
-  if (s < p_keep) { I.rb[s] = clb; I.rb[16 + s] = cub; }
+  if (s < p_keep) { I.cl[s] = clb; I.cl[16 + s] = cub; }
   WSYNC();
-  clb = (s < p) ? I.rb[s] : 0.0;
-  cub = (s < p) ? I.rb[16 + s] : 0.0;
+  clb = (s < p) ? I.cl[s] : 0.0;
+  cub = (s < p) ? I.cl[16 + s] : 0.0;
   // g' = Z'g and H' += d^2 G'G on the base block
   if (s < 6) {
     const double d2 = dpost * dpost;
@@ -3059,41 +3051,46 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     if ((nb >> rbase) & 0xFFFFull) { status = WBC_QP_NUMERICAL; live = false; }
   }
   // ---- Cholesky H' = L L' fused with the substitution L y = e_s (rotating registers; column broadcast through I.cl)
-  double y[PN];
+  WSYNC();
+  I.cl[s] = 0.0; I.cl[16 + s] = 0.0;        // (the row bounds were staged there)
+  double y[PV];
 #pragma unroll
-  for (int k = 0; k < PN; ++k) y[k] = (k == s) ? 1.0 : 0.0;
+  for (int k = 0; k < PV; ++k) y[k] = (k == s) ? 1.0 : 0.0;
   double pmin = 1.0;
 #pragma unroll 1
-  for (int j = 0; j < PN; ++j) {
-    I.cl[s] = h[0];
+  for (int j = 0; j < PV; ++j) {
+    WSYNC();
+    if (s < PV) I.cl[s] = h[0];
     WSYNC();
     const double* cj = I.cl + j;
     const double pj = cj[0];
     pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;
     const double rinv = rsqrt(pj), ipj = rinv * rinv;
-    double cm[PN];
+    double cm[PV];
 #pragma unroll
-    for (int rr = 1; rr < PN; ++rr) cm[rr] = cj[rr];
+    for (int rr = 1; rr < PV; ++rr) cm[rr] = cj[rr];
     const double th = h[0] * ipj, ty = y[0] * ipj, yk = y[0] * rinv;
 #pragma unroll
-    for (int rr = 1; rr < PN; ++rr) h[rr - 1] = fma(-th, cm[rr], h[rr]);
+    for (int rr = 1; rr < PV; ++rr) h[rr - 1] = fma(-th, cm[rr], h[rr]);
 #pragma unroll
-    for (int rr = 1; rr < PN; ++rr) y[rr - 1] = fma(-ty, cm[rr], y[rr]);
-    y[PN - 1] = yk;
-    LDS_THEN_VALU(PN, 2 * PN + 2);
-    h[PN - 1] = 0.0;
-    WSYNC();
+    for (int rr = 1; rr < PV; ++rr) y[rr - 1] = fma(-ty, cm[rr], y[rr]);
+    y[PV - 1] = yk;
+    LDS_THEN_VALU(PV, 2 * PV + 2);
+    h[PV - 1] = 0.0;
   }
   if (live && !(pmin > 0.0)) { status = WBC_QP_NUMERICAL; live = false; }
   // y = row s of J0 = L^-T.  jf2 = |J0|_F^2 per instance
   double sq = 0.0;
 #pragma unroll
-  for (int k = 0; k < PN; ++k) sq = fma(y[k], y[k], sq);
-  const double jf2 = rsum16(sq);
+  for (int k = 0; k < PV; ++k) sq = fma(y[k], y[k], sq);
+  const double jf2 = rsum16(s < PV ? sq : 0.0);
   double* const J = I.M2;
   double* const T = I.M1;
+  WSYNC();
+  if (s < PV) {
 #pragma unroll
-  for (int k = 0; k < PN; k += 2) { sts2(J + s * PLD + k, y[k], y[k + 1]); sts2(T + s * PLD + k, 0.0, 0.0); }
+    for (int k = 0; k < PV; k += 2) { sts2(J + s * PLD + k, y[k], y[k + 1]); sts2(T + s * PLD + k, 0.0, 0.0); }
+  }
   I.tv[s] = g;
   // |C_r|^2 of row s
   double cn2 = 0.0;
@@ -3107,12 +3104,12 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   {
     double t = 0.0;
 #pragma unroll
-    for (int i = 0; i < PN; ++i) t = fma(J[i * PLD + s], I.tv[i], t);
-    I.dv[s] = -t;
+    for (int i = 0; i < PV; ++i) t = fma(J[i * PLD + (s < PV ? s : 0)], I.tv[i], t);
+    I.dv[s] = has_b ? -t : 0.0;
     WSYNC();
     double xa = 0.0, xb = 0.0;
 #pragma unroll
-    for (int k = 0; k < PN; k += 2) { const double2a v2 = lds2(I.dv + k); xa = fma(y[k], v2.x, xa); xb = fma(y[k + 1], v2.y, xb); }
+    for (int k = 0; k < PV; k += 2) { const double2a v2 = lds2(I.dv + k); xa = fma(y[k], v2.x, xa); xb = fma(y[k + 1], v2.y, xb); }
     x = has_b ? xa + xb : 0.0;
   }
   // ---- dual active-set iterations (per-row state; loops run until every row of the wave is done)
@@ -3169,13 +3166,14 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         WSYNC();
         if (dr && s >= l && s < q - 1) { u = I.yv[s + 1]; a_code = (int)I.tv[s + 1]; }
         if (dr && s == q - 1) { u = 0.0; a_code = 0; }
-        const int srow = (s >= l) ? ((s + 1 < PN) ? s + 1 : s) : s;
+        const int sv = s < PV ? s : PV - 1;   // (lanes beyond the variables shadow the last row; they never write)
+        const int srow = (sv >= l) ? ((sv + 1 < PV) ? sv + 1 : sv) : sv;
         double tx = T[srow * PLD + l];
-        double jx = J[s * PLD + l];
+        double jx = J[sv * PLD + l];
         double hrun = T[l * PLD + l];
         const int kend = dr ? q - 1 : 0;    // this row's rotations run k = l .. q - 2
 #pragma unroll 1
-        for (int k0 = 0; k0 < PN - 1; ++k0) {
+        for (int k0 = 0; k0 < PV - 1; ++k0) {
           const bool on = dr && (l + k0 < kend);
           if (!__ballot(on)) break;
           const int k = on ? l + k0 : 0;
@@ -3184,7 +3182,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
           double c_ = 1.0, s_ = 0.0, rho = 0.0;
           if (nrm2 > 0.0) { const double ri = rsqrt(nrm2); c_ = tb * ri; s_ = -hrun * ri; rho = nrm2 * ri; }
           const double ty_ = T[srow * PLD + k + 1];
-          const double jy = J[s * PLD + k + 1];
+          const double jy = J[sv * PLD + k + 1];
           WSYNC();
           if (on) {
             hrun = rho;
@@ -3228,21 +3226,22 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         d = fma(J[0 * PLD + s], c0.x, fma(J[1 * PLD + s], c0.y, fma(J[2 * PLD + s], c1.x, fma(J[3 * PLD + s], c1.y,
             fma(J[4 * PLD + s], c2.x, J[5 * PLD + s] * c2.y))))) * sgn;
       } else d = sgn * J[(ip & 15) * PLD + s];
-      if (!has_b || !stepping) d = 0.0;
+      if (!has_b || !stepping) d = 0.0;      // (lanes >= n read padding: masked here)
       WSYNC();
       I.dv[s] = d; I.yv[s] = (s >= q) ? d : 0.0;
       WSYNC();
       const double zn = rsum16(s >= q ? d * d : 0.0);
       double z = 0.0, zb = 0.0, rv = 0.0, rvb = 0.0;
+      const int srd = s < PV ? s : PV - 1;
 #pragma unroll
-      for (int k = 0; k < PN; k += 2) {
-        const double2a j2 = lds2(J + s * PLD + k); const double2a y2 = lds2(I.yv + k);
+      for (int k = 0; k < PV; k += 2) {
+        const double2a j2 = lds2(J + srd * PLD + k); const double2a y2 = lds2(I.yv + k);
         z = fma(j2.x, y2.x, z); zb = fma(j2.y, y2.y, zb);
       }
       z += zb;
 #pragma unroll
-      for (int k = 0; k < PN; k += 2) {
-        const double2a t2 = lds2(T + s * PLD + k); const double2a d2 = lds2(I.dv + k);
+      for (int k = 0; k < PV; k += 2) {
+        const double2a t2 = lds2(T + srd * PLD + k); const double2a d2 = lds2(I.dv + k);
         rv = fma(t2.x, d2.x, rv); rvb = fma(t2.y, d2.y, rvb);
       }
       rv += rvb;
@@ -3269,10 +3268,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         const double sz = sqrt(zn);
         const double delta = (dq >= 0.0) ? -sz : sz;
         const double vv = 2.0 * (zn - delta * dq);
-        const double w = (z - delta * J[s * PLD + (q & 15)]) * ((vv > 0.0) ? 2.0 / vv : 0.0);
+        const double w = (z - delta * J[srd * PLD + (q & 15)]) * ((vv > 0.0) ? 2.0 / vv : 0.0);
         if (add && has_b && vv > 0.0) {
 #pragma unroll
-          for (int k = 0; k < PN; k += 2) {
+          for (int k = 0; k < PV; k += 2) {
             const double2a j2 = lds2(J + s * PLD + k); const double2a y2 = lds2(I.yv + k);   // yv = d for k >= q, else 0
             const double v0 = (k == q) ? y2.x - delta : y2.x;
             const double v1 = (k + 1 == q) ? y2.y - delta : y2.y;
@@ -3305,7 +3304,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   double x1 = 0.0;
   if (s < nl) {
     const double2a v0 = lds2(I.xv), v1 = lds2(I.xv + 2), v2 = lds2(I.xv + 4);
-    x1 = fma(grow[0], v0.x, fma(grow[1], v0.y, fma(grow[2], v1.x, fma(grow[3], v1.y, fma(grow[4], v2.x, grow[5] * v2.y)))));
+    const double2a g0 = lds2(I.G + s * 6), g1_ = lds2(I.G + s * 6 + 2), g2 = lds2(I.G + s * 6 + 4);
+    x1 = fma(g0.x, v0.x, fma(g0.y, v0.y, fma(g1_.x, v1.x, fma(g1_.y, v1.y, fma(g2.x, v2.x, g2.y * v2.y)))));
     I.qd[dof1] = x1;
   }
   if (s < n) I.qd[dof0] = x;
