@@ -2725,20 +2725,21 @@ __global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, cons
 // box + foot contacts, velocity bounds on, no CoM rows, no orientation references, nothing warm. Instances with a rank-deficient
 // leg block go to the compact list and are redone by the one-instance kernels. Same arithmetic per instance as process_sim3.
 // ================================================================================================
-constexpr int PLD = 18;                     // row stride of the matrices (even: rows are 16-byte aligned for ds_read_b128)
+constexpr int PLD = 14;                     // row stride of the matrices (even: rows are 16-byte aligned for ds_read_b128; 7 s mod 16 is a
+                                            // permutation, so "lane = row" b128 reads of two instances interleave conflict-free)
 constexpr int PN = 16;                      // lanes = constraint rows per instance
 constexpr int PV = 12;                      // reduced variables per instance the packed kernel is compiled for (n' = 11 / 10 here)
 struct __attribute__((aligned(16))) PInst {
-  double M1[PV * PLD];                      // oMi scratch (runs on into M2: 24 x 12 doubles) -> T = R^-1
-  double M2[PV * PLD];                      // ... At [16][6], K / B scratch; sin / cos table in its tail during FK -> J
-  double Cq[PN * 6];                        // reduced constraint rows x base columns (all the reduced rows touch the base only)
-  double G[12 * 6];                         // eliminated leg DoF l (row) x base DoF (column)
+  double M1[PV * PLD];                      // oMi scratch (runs on into M2: 22 joints x 12 doubles) -> T = R^-1
+  double M2[PV * PLD];                      // ... sin / cos table in its tail during FK; then At [16][6], K / B scratch -> J
+  double Cq[PN * 6];                        // reduced constraint rows x base columns (all the reduced rows touch the base only);
+                                            // rows p_keep + l are the rows of G (eliminated leg DoF l x base DoF)
   double in[40];                            // q [27], gripper target [3] @28, previous [3] @31, trunk box centre [4] @34
   double xv[PN], dv[PN], yv[PN], tv[PN];
-  double cl[32];                            // Cholesky column broadcast (entries 12..31 stay zero); before that: row-bound staging
-  double qd[32];                            // by-DoF staging: posture term of the leg DoF, later qdot
+  double cl[32];                            // row-bound staging -> Cholesky column broadcast (entries 12..31 zero) -> qdot by DoF
+  double pad_[8];
 };
-static_assert(sizeof(PInst) == 6144, "PInst: 768 doubles, so that the four instances' rows fall on the same bank pattern");
+static_assert(sizeof(PInst) == 4608, "PInst: 576 doubles (= 0 mod 32), so that the four instances' rows fall on the same bank pattern; 18 KB per wave");
 struct __attribute__((aligned(16))) SmemP { PInst I[4]; };
 
 __device__ __forceinline__ double rsum16(double v) {     // sum over the lane's 16-lane row, result in every lane of the row
@@ -2811,7 +2812,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   const double* const qv = I.in;
 
   // ---- sin / cos of the joint angles: joint j (>= 2) reads q[idx_q[j]]; two joints per lane
-  double* const oMi = I.M1;                 // [24][12], runs on into M2
+  double* const oMi = I.M1;                 // [22][12], runs on into M2
   double* const sc = I.M2 + PV * PLD - 48;  // sin / cos table: the tail of M2, free until J is written
   {
 #pragma unroll
@@ -3000,11 +3001,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
 #pragma unroll
       for (int c = 0; c < 6; ++c) grow[c] = id * (r0 * Bb[4 * c] + r1 * Bb[4 * c + 1] + r2 * Bb[4 * c + 2]);
     }
-    if (s < 12) {
-#pragma unroll
-      for (int c = 0; c < 6; c += 2) sts2(I.G + s * 6 + c, grow[c], grow[c + 1]);
-    }
-    if (s < 12) I.qd[s] = g1;
+    if (s < 12) I.xv[s] = g1;
   }
   // leg-bound rows: row p_keep + l = G_l with the leg DoF's velocity bounds; the bounds move p_keep lanes up through LDS
   if (s < nl) {
@@ -3020,13 +3017,15 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   if (s < 6) {
     const double d2 = dpost * dpost;
     double gg[6] = {0, 0, 0, 0, 0, 0}, gs = 0.0;
+    const double* const Gr = I.Cq + p_keep * 6;   // G rows (rows beyond nl: never written here -> must not be read)
 #pragma unroll
     for (int l = 0; l < 12; ++l) {
-      const double gl = I.G[l * 6 + s];
-      const double2a t0 = lds2(I.G + l * 6), t1 = lds2(I.G + l * 6 + 2), t2 = lds2(I.G + l * 6 + 4);
+      if (l >= nl) break;
+      const double gl = Gr[l * 6 + s];
+      const double2a t0 = lds2(Gr + l * 6), t1 = lds2(Gr + l * 6 + 2), t2 = lds2(Gr + l * 6 + 4);
       gg[0] = fma(gl, t0.x, gg[0]); gg[1] = fma(gl, t0.y, gg[1]); gg[2] = fma(gl, t1.x, gg[2]);
       gg[3] = fma(gl, t1.y, gg[3]); gg[4] = fma(gl, t2.x, gg[4]); gg[5] = fma(gl, t2.y, gg[5]);
-      gs = fma(gl, I.qd[l], gs);
+      gs = fma(gl, I.xv[l], gs);
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) h[c] = fma(d2, gg[c], h[c]);
@@ -3299,22 +3298,22 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // ---- x = Z y, q̇ by DoF through LDS, outputs
   WSYNC();
   I.xv[s] = has_b ? x : 0.0;
-  I.qd[s] = 0.0; I.qd[16 + s] = 0.0;
+  I.cl[s] = 0.0; I.cl[16 + s] = 0.0;
   WSYNC();
   double x1 = 0.0;
   if (s < nl) {
     const double2a v0 = lds2(I.xv), v1 = lds2(I.xv + 2), v2 = lds2(I.xv + 4);
-    const double2a g0 = lds2(I.G + s * 6), g1_ = lds2(I.G + s * 6 + 2), g2 = lds2(I.G + s * 6 + 4);
+    const double2a g0 = lds2(I.Cq + (p_keep + s) * 6), g1_ = lds2(I.Cq + (p_keep + s) * 6 + 2), g2 = lds2(I.Cq + (p_keep + s) * 6 + 4);
     x1 = fma(g0.x, v0.x, fma(g0.y, v0.y, fma(g1_.x, v1.x, fma(g1_.y, v1.y, fma(g2.x, v2.x, g2.y * v2.y)))));
-    I.qd[dof1] = x1;
+    I.cl[dof1] = x1;
   }
-  if (s < n) I.qd[dof0] = x;
+  if (s < n) I.cl[dof0] = x;
   WSYNC();
   const bool wr = valid && !flagged;
   if (wr) {
     double* qo = A.out.qdot + (size_t)b * NV;
-    qo[s] = I.qd[s];
-    if (16 + s < NV) qo[16 + s] = I.qd[16 + s];
+    qo[s] = I.cl[s];
+    if (16 + s < NV) qo[16 + s] = I.cl[16 + s];
     if (s == 0) {
       A.out.status[b] = status;
       if (A.out.iters) A.out.iters[b] = iters + nl + P.nlock;
@@ -3323,7 +3322,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // ---- jointVelocitiestoConfig (Robot_Wrapper4.py:440-441)
   if (A.out.q_next) {
     WSYNC();
-    I.xv[s] = (s < 6) ? I.qd[s] * dt : 0.0;
+    I.xv[s] = (s < 6) ? I.cl[s] * dt : 0.0;
     WSYNC();
     double* qn = A.out.q_next + (size_t)b * NQ;
     if (wr) {
@@ -3332,7 +3331,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int d = 6 + s + 16 * hh;
-        if (d < nv) { const int qi = M.col_q[d]; qn[qi] = qv[qi] + I.qd[d] * dt; }
+        if (d < nv) { const int qi = M.col_q[d]; qn[qi] = qv[qi] + I.cl[d] * dt; }
       }
       if (s < NQ - nq) qn[nq + s] = 0.0;
     }
