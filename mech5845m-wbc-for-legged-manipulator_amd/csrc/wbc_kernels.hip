@@ -2982,9 +2982,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   WSYNC();
 
   // ---- G_e = -K_e^-1 B_e: lane l = 3 f + i owns row i of foot f (the base block B is the same for every foot)
-  bool flagged = false;
-  double grow[6] = {0, 0, 0, 0, 0, 0};
+  unsigned fmask = 0;                      // per instance: bit f = foot f's leg block K_f is (numerically) rank deficient
   {
+    double grow[6] = {0, 0, 0, 0, 0, 0};
     const int f = (s < nl) ? s / 3 : 0, i = (s < nl) ? s - 3 * f : 0;
     const double* k0 = Kb + 4 * (3 * f); const double* k1 = k0 + 4; const double* k2 = k1 + 4;   // columns of K_f (leg DoF 0, 1, 2 of the foot)
     const double k00 = k0[0], k10 = k0[1], k20 = k0[2], k01 = k1[0], k11 = k1[1], k21 = k1[2], k02 = k2[0], k12 = k2[1], k22 = k2[2];
@@ -2992,9 +2992,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     const double a10 = k12 * k20 - k10 * k22, a11 = k00 * k22 - k02 * k20, a12 = k02 * k10 - k00 * k12;
     const double a20 = k10 * k21 - k11 * k20, a21 = k01 * k20 - k00 * k21, a22 = k00 * k11 - k01 * k10;
     const double det = k00 * a00 + k01 * a10 + k02 * a20;
-    const double sc = fabs(k00) + fabs(k01) + fabs(k02) + fabs(k10) + fabs(k11) + fabs(k12) + fabs(k20) + fabs(k21) + fabs(k22);
-    const bool bad = (s < nl) && !(fabs(det) > A.sing_tol * sc * sc * sc);
-    flagged = (__ballot(bad) >> rbase) & 0xFFFFull;
+    const double sc_ = fabs(k00) + fabs(k01) + fabs(k02) + fabs(k10) + fabs(k11) + fabs(k12) + fabs(k20) + fabs(k21) + fabs(k22);
+    const bool bad = (s < nl) && !(fabs(det) > A.sing_tol * sc_ * sc_ * sc_);
+    const unsigned rowbits = (unsigned)((__ballot(bad) >> rbase) & 0xFFFull);
+    fmask = ((rowbits & 0x7u) ? 1u : 0u) | ((rowbits & 0x38u) ? 2u : 0u) | ((rowbits & 0x1C0u) ? 4u : 0u) | ((rowbits & 0xE00u) ? 8u : 0u);
     const double id = -1.0 / det;
     const double r0 = (i == 0) ? a00 : (i == 1) ? a10 : a20, r1 = (i == 0) ? a01 : (i == 1) ? a11 : a21, r2 = (i == 0) ? a02 : (i == 1) ? a12 : a22;
     if (s < nl) {
@@ -3002,17 +3003,77 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       for (int c = 0; c < 6; ++c) grow[c] = id * (r0 * Bb[4 * c] + r1 * Bb[4 * c + 1] + r2 * Bb[4 * c + 2]);
     }
     if (s < 12) I.xv[s] = g1;
-  }
-  // leg-bound rows: row p_keep + l = G_l with the leg DoF's velocity bounds; the bounds move p_keep lanes up through LDS
-  if (s < nl) {
+    // leg-bound rows: row p_keep + l = G_l with the leg DoF's velocity bounds; the bounds move p_keep lanes up through LDS
+    if (s < nl) {
 #pragma unroll
-    for (int c = 0; c < 6; c += 2) sts2(I.Cq + (p_keep + s) * 6 + c, grow[c], grow[c + 1]);
-    I.cl[p_keep + s] = lb1; I.cl[16 + p_keep + s] = ub1;
+      for (int c = 0; c < 6; c += 2) sts2(I.Cq + (p_keep + s) * 6 + c, grow[c], grow[c + 1]);
+      I.cl[p_keep + s] = lb1; I.cl[16 + p_keep + s] = ub1;
+    }
   }
   if (s < p_keep) { I.cl[s] = clb; I.cl[16 + s] = cub; }
   WSYNC();
   clb = (s < p) ? I.cl[s] : 0.0;
   cub = (s < p) ? I.cl[16 + s] : 0.0;
+  // ---- a rank-deficient leg block (rare; whole-wave branch, per-instance predicates): K_f P = Q R by column-pivoted Gram-Schmidt
+  // on lane f of the instance (see process_sim3): z0, z1 are eliminated as usual, the third contact row E q̇_base + r22 z2 = 0 and
+  // the leg velocity z2 pivoted last are dealt with by the SWAP further down. Ex[f] = E [6], r22, g0x, g1x, l0, l1, l2.
+  double* const Ex = I.M2 + 16 * 6 + 48 + 24;     // [4][12], behind At / Kb / Bb
+  bool defer = false;
+  if (__ballot(valid && fmask != 0)) {
+    bool bad_rank = false;
+    if (s < 4 && ((fmask >> s) & 1u)) {
+      const int f = s;
+      const double* k0 = Kb + 4 * (3 * f); const double* k1 = k0 + 4; const double* k2 = k1 + 4;
+      const double ca[3] = {k0[0], k0[1], k0[2]}, cb[3] = {k1[0], k1[1], k1[2]}, cc[3] = {k2[0], k2[1], k2[2]};
+      const double na = ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2], nb = cb[0] * cb[0] + cb[1] * cb[1] + cb[2] * cb[2],
+                   nc = cc[0] * cc[0] + cc[1] * cc[1] + cc[2] * cc[2];
+      const int p0 = (na >= nb && na >= nc) ? 0 : ((nb >= nc) ? 1 : 2);
+      double u_[3], v_[3], w_[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        u_[i] = (p0 == 0) ? ca[i] : (p0 == 1) ? cb[i] : cc[i];
+        v_[i] = (p0 == 0) ? cb[i] : ca[i];
+        w_[i] = (p0 == 2) ? cb[i] : cc[i];
+      }
+      const int iv = (p0 == 0) ? 1 : 0, iw = (p0 == 2) ? 1 : 2;
+      const double r00 = sqrt(u_[0] * u_[0] + u_[1] * u_[1] + u_[2] * u_[2]);
+      const double q0[3] = {u_[0] / r00, u_[1] / r00, u_[2] / r00};
+      const double rv = q0[0] * v_[0] + q0[1] * v_[1] + q0[2] * v_[2], rw = q0[0] * w_[0] + q0[1] * w_[1] + q0[2] * w_[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { v_[i] = fma(-rv, q0[i], v_[i]); w_[i] = fma(-rw, q0[i], w_[i]); }
+      const double nv2 = v_[0] * v_[0] + v_[1] * v_[1] + v_[2] * v_[2], nw2 = w_[0] * w_[0] + w_[1] * w_[1] + w_[2] * w_[2];
+      const bool sw = nw2 > nv2;
+      const int p1 = sw ? iw : iv, p2 = sw ? iv : iw;
+      const double r01 = sw ? rw : rv, r02 = sw ? rv : rw;
+      double s1[3], s2[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { s1[i] = sw ? w_[i] : v_[i]; s2[i] = sw ? v_[i] : w_[i]; }
+      const double r11 = sqrt(sw ? nw2 : nv2);
+      const double q1[3] = {s1[0] / r11, s1[1] / r11, s1[2] / r11};
+      const double r12 = q1[0] * s2[0] + q1[1] * s2[1] + q1[2] * s2[2];
+      double q2[3];
+      cross3(q0, q1, q2);
+      const double r22 = q2[0] * s2[0] + q2[1] * s2[1] + q2[2] * s2[2];
+      bad_rank = !(r11 > 1e-9 * r00) || !(r00 > 0.0);
+      const int l0 = 3 * f + p0, l1 = 3 * f + p1, l2 = 3 * f + p2;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double bx = Bb[4 * c], by = Bb[4 * c + 1], bz = Bb[4 * c + 2];
+        const double t0 = q0[0] * bx + q0[1] * by + q0[2] * bz, t1 = q1[0] * bx + q1[1] * by + q1[2] * bz,
+                     t2 = q2[0] * bx + q2[1] * by + q2[2] * bz;
+        const double g1c = -t1 / r11;
+        I.Cq[(p_keep + l1) * 6 + c] = g1c;
+        I.Cq[(p_keep + l0) * 6 + c] = -(t0 + r01 * g1c) / r00;
+        I.Cq[(p_keep + l2) * 6 + c] = 0.0;
+        Ex[12 * f + c] = t2;
+      }
+      const double g1x = -r12 / r11;
+      Ex[12 * f + 6] = r22; Ex[12 * f + 7] = -(r01 * g1x + r02) / r00; Ex[12 * f + 8] = g1x;
+      Ex[12 * f + 9] = (double)l0; Ex[12 * f + 10] = (double)l1; Ex[12 * f + 11] = (double)l2;
+    }
+    defer = ((__ballot(bad_rank) >> rbase) & 0xFFFFull) != 0;
+    WSYNC();
+  }
   // g' = Z'g and H' += d^2 G'G on the base block
   if (s < 6) {
     const double d2 = dpost * dpost;
@@ -3031,7 +3092,98 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     for (int c = 0; c < 6; ++c) h[c] = fma(d2, gg[c], h[c]);
     g += gs;
   }
-  // a row of the batch tail does nothing; a flagged instance is left to the one-instance kernels (compact list)
+  // ---- the SWAP: for a pivoted foot the kept row E y_base + r22 z2 = 0 is solved for the base unknown with the largest
+  // coefficient, y_c* = u'(y, z2), and z2 takes that unknown's slot. The reduced problem keeps its size (n' unknowns, the same 16
+  // rows) however many feet are pivoted, nothing is divided by r22, and the pivot |E_c*| >= 0.4 |E| (the first three columns
+  // of Q'B are rows of a rotation). In the new unknowns: H'' = M'H_ext M, g'' = M'g_ext, every row C_r <- C_r + C_rc* u' (+ its z2
+  // coefficient in slot c*), the bound row of leg DoF l2 becomes the bound row of base DoF c* and vice versa; at the end lane c*
+  // delivers z2 = q̇ of leg DoF l2 and row lane l2 delivers q̇ of base DoF c*.
+  int dofA = dof0, dofB = dof1;            // DoF whose velocity lane s delivers as reduced variable / as eliminated-leg row
+  if (__ballot(valid && fmask != 0 && !defer)) {
+    unsigned swapped = 0;
+#pragma unroll 1
+    for (int f = 0; f < 4; ++f) {
+      const bool on = valid && !defer && ((fmask >> f) & 1u);
+      if (!__ballot(on)) continue;
+      const double d2 = dpost * dpost;
+      const double Ec = (on && s < 6) ? Ex[12 * f + s] : 0.0;
+      const double cand = (on && s < 6 && !((swapped >> s) & 1u)) ? fabs(Ec) : -1.0;
+      const double emax = -rmin16(-cand);
+      const int cstar_ = __ffs((int)((__ballot(cand == emax && cand >= 0.0) >> rbase) & 0xFFFFull)) - 1;
+      const int cstar = cstar_ < 0 ? 0 : cstar_;
+      const double Ecs = bperm(Ec, rbase + cstar);
+      const double r22 = Ex[12 * f + 6], g0x = Ex[12 * f + 7], g1x = Ex[12 * f + 8];
+      const int l0 = on ? (int)Ex[12 * f + 9] : 0, l1 = on ? (int)Ex[12 * f + 10] : 0, l2 = on ? (int)Ex[12 * f + 11] : 0;
+      const double wz = -r22 / Ecs;
+      const double us = (s < 6) ? ((s == cstar) ? wz : -Ec / Ecs) : 0.0;
+      const double hyz = (s < 6) ? d2 * (I.Cq[(p_keep + l0) * 6 + s] * g0x + I.Cq[(p_keep + l1) * 6 + s] * g1x) : 0.0;
+      const double hzz = d2 * (g0x * g0x + g1x * g1x + 1.0);
+      const double gz = g0x * I.xv[l0] + g1x * I.xv[l1] + I.xv[l2];
+      WSYNC();
+      if (on) {
+        I.yv[s] = us; I.dv[s] = hyz;
+        if (s == cstar) {
+#pragma unroll
+          for (int k = 0; k < PV; ++k) I.tv[k] = h[k];
+        }
+      }
+      WSYNC();
+      const double gcs = bperm(g, rbase + cstar);
+      if (on && s < n) {
+        const double Hcc = I.tv[cstar], hyzc = I.dv[cstar];
+        double hic = 0.0;
+#pragma unroll
+        for (int j = 0; j < PV; ++j) hic = (j == cstar) ? h[j] : hic;
+        const double kz = wz * Hcc + hyzc;
+        if (s != cstar) {
+#pragma unroll
+          for (int j = 0; j < PV; ++j) {
+            const double uj = I.yv[j], Hcj = I.tv[j];
+            h[j] = (j == cstar) ? wz * hic + hyz + us * kz : h[j] + us * Hcj + hic * uj + us * uj * Hcc;
+          }
+          g = fma(us, gcs, g);
+        } else {
+#pragma unroll
+          for (int j = 0; j < PV; ++j) {
+            const double uj = I.yv[j], Hcj = I.tv[j], hj = I.dv[j];
+            h[j] = (j == cstar) ? wz * wz * Hcc + 2.0 * wz * hyzc + hzz : wz * Hcj + hj + uj * kz;
+          }
+          g = wz * gcs + gz;
+        }
+      }
+      // rows, in place (each lane its own row); row p_keep + l2 becomes the expression of base DoF c*
+      if (on && s < p) {
+        double* row = I.Cq + s * 6;
+        const double crc = row[cstar];
+        const double crz = (s == p_keep + l0) ? g0x : ((s == p_keep + l1) ? g1x : 0.0);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double uc = I.yv[c];
+          row[c] = (s == p_keep + l2) ? uc : ((c == cstar) ? crc * wz + crz : row[c] + crc * uc);
+        }
+      }
+      // the kept rows of the feet still to come, in the new unknowns
+#pragma unroll 1
+      for (int f2 = f + 1; f2 < 4; ++f2) {
+        const double e2 = Ex[12 * f2 + cstar];
+        WSYNC();
+        if (on && s < 6) Ex[12 * f2 + s] = (s == cstar) ? e2 * wz : Ex[12 * f2 + s] + e2 * I.yv[s];
+      }
+      // bounds: slot c* is leg DoF l2 now, row p_keep + l2 is base DoF c*; and what the two lanes deliver at the end
+      {
+        const int rl2 = rbase + ((p_keep + l2) & 15);
+        const double nl_ = bperm(clb, rl2), nu_ = bperm(cub, rl2), ol_ = bperm(lb, rbase + cstar), ou_ = bperm(ub, rbase + cstar);
+        const int dB = bpermi(dofB, rbase + (l2 & 15)), dA = bpermi(dofA, rbase + cstar);
+        if (on && s == cstar) { lb = nl_; ub = nu_; dofA = dB; }
+        if (on && s == p_keep + l2) { clb = ol_; cub = ou_; }
+        if (on && s == l2) dofB = dA;
+      }
+      if (on) swapped |= 1u << cstar;
+      WSYNC();
+    }
+  }
+  // a row of the batch tail does nothing; an instance with a leg block of rank < 2 is left to the general kernel (compact list)
+  const bool flagged = defer;
   bool live = valid && !flagged;
   if (valid && flagged && s == 0) {
     A.out.status[b] = WBC_QP_DEFERRED;
@@ -3305,9 +3457,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     const double2a v0 = lds2(I.xv), v1 = lds2(I.xv + 2), v2 = lds2(I.xv + 4);
     const double2a g0 = lds2(I.Cq + (p_keep + s) * 6), g1_ = lds2(I.Cq + (p_keep + s) * 6 + 2), g2 = lds2(I.Cq + (p_keep + s) * 6 + 4);
     x1 = fma(g0.x, v0.x, fma(g0.y, v0.y, fma(g1_.x, v1.x, fma(g1_.y, v1.y, fma(g2.x, v2.x, g2.y * v2.y)))));
-    I.cl[dof1] = x1;
+    I.cl[dofB] = x1;
   }
-  if (s < n) I.cl[dof0] = x;
+  if (s < n) I.cl[dofA] = x;
   WSYNC();
   const bool wr = valid && !flagged;
   if (wr) {

@@ -314,6 +314,36 @@ def test_sim3_kernel_pivots_rank_deficient_leg_blocks(wx200):
     bt.close()
 
 
+@pytest.mark.parametrize("tol_exp", [0, 1, 3, 5])
+def test_packed_kernel_pivots_in_place(wx200, px100, tol_exp):
+    """The packed kernel (four instances per wavefront) answers a rank-deficient leg block itself: pivoted elimination + SWAP
+    of the kept leg velocity into the slot of a base unknown, so the reduced problem keeps its size — at presolve_tol_exp = 0
+    every instance swaps on all four legs (four of its six base unknowns become leg velocities), at 3 and 5 the wavefronts mix
+    pivoted and plain instances. Nothing may be deferred, and q̇, status, q_next match the oracle."""
+    B = 3001
+    models = [wx200, px100]
+    cfgs = [common.config("c3", m) for m in models]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=183 + i) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    bt.set_option("presolve_tol_exp", tol_exp)
+    got = bt.tick(d, DT, want_q_next=True)
+    assert bt.stat("last_path") == 2 and bt.stat("deferred_last") == 0
+    assert (got["status"] == ref["status"]).all()
+    ok = ref["status"] == 0
+    assert ok.mean() > 0.9
+    err = np.abs(got["qdot"] - ref["qdot"])[ok].max()
+    print("packed, tol 1e-%d: qdot max-abs err %.3e, working-set changes %.2f (oracle %.2f)" % (tol_exp, err, got["iters"][ok].mean(), ref["iters"][ok].mean()))
+    assert err < QDOT_TOL
+    assert np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    bt.close()
+
+
 @pytest.mark.parametrize("tol_exp,defer", [(0, 0), (3, 0), (5, 0), (0, 1), (3, 1)])
 def test_pivoted_elimination_and_second_pass_match_the_oracle(wx200, px100, tol_exp, defer):
     """Both answers to a rank-deficient stance-leg block under load: option presolve_tol_exp lowers the bar for "rank deficient"
