@@ -3017,7 +3017,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // ---- a rank-deficient leg block (rare; whole-wave branch, per-instance predicates): K_f P = Q R by column-pivoted Gram-Schmidt
   // on lane f of the instance (see process_sim3): z0, z1 are eliminated as usual, the third contact row E q̇_base + r22 z2 = 0 and
   // the leg velocity z2 pivoted last are dealt with by the SWAP further down. Ex[f] = E [6], r22, g0x, g1x, l0, l1, l2.
-  double* const Ex = I.M2 + 16 * 6 + 48 + 24;     // [4][12], behind At / Kb / Bb
+  double* const Ex = I.M1;                        // [4][12]: M1 is free between the FK and the Cholesky sweep (M2 is full: At, Kb, Bb)
   bool defer = false;
   if (__ballot(valid && fmask != 0)) {
     bool bad_rank = false;
@@ -3100,14 +3100,15 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // delivers z2 = q̇ of leg DoF l2 and row lane l2 delivers q̇ of base DoF c*.
   int dofA = dof0, dofB = dof1;            // DoF whose velocity lane s delivers as reduced variable / as eliminated-leg row
   if (__ballot(valid && fmask != 0 && !defer)) {
-    unsigned swapped = 0;
 #pragma unroll 1
     for (int f = 0; f < 4; ++f) {
       const bool on = valid && !defer && ((fmask >> f) & 1u);
       if (!__ballot(on)) continue;
       const double d2 = dpost * dpost;
       const double Ec = (on && s < 6) ? Ex[12 * f + s] : 0.0;
-      const double cand = (on && s < 6 && !((swapped >> s) & 1u)) ? fabs(Ec) : -1.0;
+      // (any of the six slots may be taken, also one that an earlier swap already gave to a leg velocity: the base parts of the
+      //  kept rows all lie in the 3-dimensional row space of B, so a fourth pivoted foot finds its pivot only there)
+      const double cand = (on && s < 6) ? fabs(Ec) : -1.0;
       const double emax = -rmin16(-cand);
       const int cstar_ = __ffs((int)((__ballot(cand == emax && cand >= 0.0) >> rbase) & 0xFFFFull)) - 1;
       const int cstar = cstar_ < 0 ? 0 : cstar_;
@@ -3178,7 +3179,6 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         if (on && s == p_keep + l2) { clb = ol_; cub = ou_; }
         if (on && s == l2) dofB = dA;
       }
-      if (on) swapped |= 1u << cstar;
       WSYNC();
     }
   }

@@ -41,6 +41,23 @@ t_gen = timed()
 ref = out["qdot"].clone()
 print(json.dumps({"path": "general kernel alone (presolve off)", "ms_per_step": t_gen, "M_ticks_per_s": B / t_gen / 1e3}), flush=True)
 bt.set_option("presolve", 1)
+# the packed kernel (four instances per wavefront): pivoted elimination + swap in place, nothing deferred
+counts = {}
+for tol in (7, 5, 3, 0):
+    bt.set_option("presolve_tol_exp", tol)
+    bt.set_option("packed_kernel", 0)
+    bt.set_option("count_pivoted", 1)
+    step()
+    counts[tol] = bt.stat("pivoted_last")
+    bt.set_option("count_pivoted", 0)
+    bt.set_option("packed_kernel", 1)
+    t = timed()
+    assert bt.stat("last_path") == 2 and bt.stat("deferred_last") == 0
+    err = float((out["qdot"] - ref).abs().max().item())
+    print(json.dumps({"path": "packed kernel: pivoted elimination + swap in place", "presolve_tol_exp": tol, "flagged_instances": counts[tol],
+                      "flagged_frac": counts[tol] / B, "ms_per_step": t, "M_ticks_per_s": B / t / 1e3, "vs_general_alone": t / t_gen,
+                      "max_abs_diff_vs_general": err}), flush=True)
+bt.set_option("packed_kernel", 0)
 for defer in (0, 1):
     bt.set_option("dbg_force_defer", defer)
     for tol in (7, 5, 3, 0):
@@ -51,7 +68,7 @@ for defer in (0, 1):
         bt.set_option("count_pivoted", 0)
         t = timed()
         err = float((out["qdot"] - ref).abs().max().item())
-        print(json.dumps({"path": "second pass (general kernel over the compact list)" if defer else "pivoted elimination in the compact kernel",
+        print(json.dumps({"path": "one-instance compact kernel: second pass (general kernel over the compact list)" if defer else "one-instance compact kernel: pivoted elimination",
                           "presolve_tol_exp": tol, "flagged_instances": n, "flagged_frac": n / B, "ms_per_step": t, "M_ticks_per_s": B / t / 1e3,
                           "vs_general_alone": t / t_gen, "max_abs_diff_vs_general": err}), flush=True)
 bt.close()
