@@ -39,8 +39,8 @@ ACTUAL_BYTES_PER_TICK = 216 + 120 + 120 + 32 + 208 + 4 + 4
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak
 ALGO_FLOP_PER_TICK = 5.5e4     # dense count of the n = 26 problem (+ ~1e4 per working-set change)
-REDUCED_FLOP_PER_TICK = 1.4e4  # the problem the sim3 kernel actually solves (n' = 14, no equalities): DESIGN.md §4
-PMC_PROFILE = "r02_pmc_summary.txt"   # committed rocprofv3 PMC passes the static roofline.traffic / roofline.issue fields come from
+REDUCED_FLOP_PER_TICK = 1.1e4  # the problem the sim3 kernels actually solve (n' = 11, no equalities): DESIGN.md §4
+PMC_PROFILE = "r02_pmc_summary_packed.txt"   # committed rocprofv3 PMC passes the static roofline.traffic / roofline.issue fields come from
 DT = 0.002
 QDOT_TOL = 1e-5
 
@@ -64,8 +64,8 @@ def _pmc_lines(kernels):
 def pmc_static():
     """roofline.traffic and roofline.issue from the COMMITTED rocprofv3 PMC passes of this same command (separate --pmc runs,
     tools/gpu_profile.sh): constants of that profile, not measurements of this run — marked "static_from_profile"."""
-    v, path = _pmc_lines(("wbc_tick_sim3_kernel", "wbc_tick_deferred_kernel"))
-    s = v.get("wbc_tick_sim3_kernel")
+    v, path = _pmc_lines(("wbc_tick_sim3p_kernel", "wbc_tick_deferred_kernel"))
+    s = v.get("wbc_tick_sim3p_kernel")
     if not s:
         return None, None
     traffic = 0.0
@@ -249,7 +249,7 @@ def run_rank(args, comm, engine, make_inputs):
                      "fp64_frac_nominal_n26": ALGO_FLOP_PER_TICK * B / (k_med * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                      "fp64_frac_solved_problem": REDUCED_FLOP_PER_TICK * B / (k_med * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                      "issue": issue,
-                     "note": "tiny-dense LDS-resident fp64 work: bound by VALU/LDS issue and dependent-chain latency at 3 waves/SIMD; neither HBM "
+                     "note": "tiny-dense LDS-resident fp64 work: bound by VALU/LDS issue and dependent-chain latency at 2 waves/SIMD (four instances per wave); neither HBM "
                              "nor MFMA is approachable (SURVEY.md §8d). achieved/peak/frac are the HBM figures the contract asks for; "
                              "issue_frac = max(VALU busy, LDS busy) of the committed PMC profile"},
         "solver": {"optimal_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
