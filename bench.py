@@ -73,9 +73,10 @@ def pmc_static():
         traffic += v[kn].get("FETCH_SIZE", 0.0) + v[kn].get("WRITE_SIZE", 0.0)       # KiB per dispatch; 8-byte-per-lane accesses:
     try:                                                                             # the gfx950 x2 correction for 16-byte streams does not apply
         cu_cycles = 256.0 * s["GRBM_GUI_ACTIVE"] / 8.0
+        ticks = 65536.0                      # the profile was taken at the bench batch; the packed kernel runs four ticks per wave
         issue = {"valu_busy": s["SQ_ACTIVE_INST_VALU"] / cu_cycles, "lds_busy": s["SQ_LDS_IDX_ACTIVE"] / cu_cycles,
-                 "valu_insts_per_tick": s["SQ_INSTS_VALU"] / s["SQ_WAVES"], "lds_insts_per_tick": s["SQ_INSTS_LDS"] / s["SQ_WAVES"],
-                 "salu_insts_per_tick": s["SQ_INSTS_SALU"] / s["SQ_WAVES"],
+                 "valu_insts_per_tick": s["SQ_INSTS_VALU"] / ticks, "lds_insts_per_tick": s["SQ_INSTS_LDS"] / ticks,
+                 "salu_insts_per_tick": s["SQ_INSTS_SALU"] / ticks, "ticks_per_wave": ticks / s["SQ_WAVES"],
                  "lds_bank_conflict_rate": s["SQ_LDS_BANK_CONFLICT"] / s["SQ_LDS_IDX_ACTIVE"],
                  "static_from_profile": os.path.relpath(path, ROOT)}
     except KeyError:
