@@ -303,12 +303,33 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
   for (int l = 0; l < 3 * nelim; ++l) if (M.depth[M.col_joint[P->legd[l]]] > need_depth) need_depth = M.depth[M.col_joint[P->legd[l]]];
   if (M.depth[M.frame_joint[WBC_FR_EE0 + 4]] > need_depth) need_depth = M.depth[M.frame_joint[WBC_FR_EE0 + 4]];
   if (need_depth > 6) ok = false;
+  for (int i = 0; i < 32; ++i) P->pk_scq[i] = -1;
   for (int L = 0; L < 5 && ok; ++L) {
     int cnt = 0;
-    for (int i = 0; i < 16; ++i) P->fk_sched[L][i] = -1;
+    for (int i = 0; i < 16; ++i) { memset(&P->pk_fk[L][i], 0, sizeof P->pk_fk[L][i]); P->pk_fk[L][i].joint = -1; }
     for (int j = 2; j < M.njoints; ++j)
-      if (M.depth[j] == L + 2 && M.depth[j] <= need_depth) { if (cnt < 16) P->fk_sched[L][cnt] = j; ++cnt; }
+      if (M.depth[j] == L + 2 && M.depth[j] <= need_depth) {
+        if (cnt < 16) {
+          DevPlan::PkJoint& r = P->pk_fk[L][cnt];
+          const bool rev = M.jtype[j] >= WBC_JT_RX && M.jtype[j] <= WBC_JT_RZ;
+          r.joint = j; r.parent = M.parent[j]; r.a0 = 3 * M.ax0[j]; r.a1 = 3 * M.ax1[j]; r.a2 = 3 * M.ax2[j];
+          r.rev = rev ? 1 : 0; r.q_idx = M.idx_q[j]; r.t0 = M.tp[j][0]; r.t1 = M.tp[j][1]; r.t2 = M.tp[j][2];
+          if (rev && j < 32) P->pk_scq[j] = M.idx_q[j];
+        }
+        ++cnt;
+      }
     if (cnt > 16) ok = false;
+  }
+  for (int i = 0; i < 16; ++i) {
+    memset(&P->pk_var[i], 0, sizeof P->pk_var[i]);
+    memset(&P->pk_leg[i], 0, sizeof P->pk_leg[i]);
+    for (int pass = 0; pass < 2; ++pass) {
+      DevPlan::PkCol& r = pass ? P->pk_leg[i] : P->pk_var[i];
+      const bool on = pass ? (i < 3 * nelim) : (i < n_red);
+      const int d = on ? (pass ? P->legd[i] : P->Fd[i]) : 0;
+      r.dof = d; r.joint = M.col_joint[d]; r.lin = M.col_lin[d]; r.ang = M.col_ang[d];
+      r.dq_idx = c.damper_qidx[d]; r.d_lo = c.damper_lo[d]; r.d_hi = c.damper_hi[d]; r.d_vm = c.damper_vmax[d];
+    }
   }
   P->packed_ok = ok ? 1 : 0;
 }
@@ -578,7 +599,7 @@ static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
     HIP_TRY(hipMemsetAsync(a.pivot_count, 0, sizeof(int32_t), (hipStream_t)stream));
   }
   bool packed = b->packed_kernel && !a.ws_in && !a.ws_out && !a.in.q_con && !a.in.posture_u &&
-                !b->force_defer && !b->count_pivoted && !b->dbg_stop && !b->dbg_alias;
+                !b->force_defer && !b->count_pivoted && !(b->dbg_stop > 0 && b->dbg_stop < 100) && !b->dbg_alias;   // (dbg_stop 101.. cuts the packed kernel)
   for (int i = 0; i < b->n_models && packed; ++i) packed = b->plan_host[i].packed_ok != 0;
   if (packed) {
     b->last_path = 2;

@@ -39,7 +39,12 @@ struct DevPlan {
   int32_t nlock;                     // DoF locked at 0 by the velocity box (>= lock_from, use_bounds): left out of the reduced problem
   int32_t packed_ok;                 // the packed kernel (four instances per wavefront) can run this (model, configuration)
   int32_t pad_[2];
-  int32_t fk_sched[5][16];           // packed kernel: joints of tree depth 2 + L, one per lane-in-instance (-1: none)
+  // packed kernel (wbc_tick_sim3p_kernel): everything a lane needs, one record per role, so that no load depends on another
+  struct PkJoint { int32_t joint, parent, a0, a1, a2, rev, q_idx, pad_; double t0, t1, t2; };   // a*: 3 x column of the axis / its successors in R
+  struct PkCol { int32_t dof, joint, lin, ang, dq_idx, pad_[3]; double d_lo, d_hi, d_vm; };       // Jacobian column + velocity-damper entries of a DoF
+  PkJoint pk_fk[5][16];              // joints of tree depth 2 + L, one per lane-in-instance (joint -1: none)
+  PkCol pk_var[16], pk_leg[16];      // reduced variable s / eliminated leg DoF s
+  int32_t pk_scq[32];                // joint j (>= 2): q index of its angle if it is a revolute joint the FK needs, else -1
   uint32_t elimrows;                 // bit i: constraint row i belongs to an eliminated foot
   uint32_t legrows;                  // bit i: kept constraint row i has support on eliminated leg DoF (needs C Z)
   // qpJointb "MANI"/"HYBRID" when EVERY finite difference is structurally zero (the perturbed joint is not a proper ancestor

@@ -2713,7 +2713,7 @@ __global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, cons
 // The compact kernel above keeps one instance per wave, and its reduced QP (n' = 11 unknowns, <= 16 rows) lights 11-16 of the 64
 // lanes: 3.3 k VALU wave-instructions per tick for ~1.4e4 useful flops. Here lane = 16 r + s: instance r of the wave, s = reduced
 // variable / constraint row / FK slot. Every stage is written for 16 lanes:
-//   FK          level-synchronous over a per-plan schedule (DevPlan.fk_sched: at most five joints per tree level — four legs + the
+//   FK          level-synchronous over a per-plan schedule (DevPlan.pk_fk: at most five joints per tree level — four legs + the
 //               arm chain), sin/cos of the joint angles computed beforehand two per lane;
 //   columns     lane s owns the WORLD Jacobian column of reduced variable s (task rows, trunk-box rows) and of eliminated leg DoF
 //               s < 12 (contact rows -> K_e, velocity bounds);
@@ -2757,6 +2757,11 @@ __device__ __forceinline__ double bperm(double v, int src_lane) {     // v of la
 }
 __device__ __forceinline__ int bpermi(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 
+#ifdef WBC_ABLATE
+#define PSTOP(k, val) do { if (A.dbg_stop == 100 + (k)) { if (valid) { A.out.qdot[(size_t)b * NV + s] = (val); if (s == 0) A.out.status[b] = 0; } return; } } while (0)
+#else
+#define PSTOP(k, val) do { } while (0)
+#endif
 __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                                const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   __shared__ SmemP SP;
@@ -2790,13 +2795,14 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   const bool c_con_trunk = fl & 2u;
   const int c_task_joint = (fl >> 4) & 7u;
   const bool has_grip = (P.task_ee_mask >> 4) & 1u;
-  // columns: pass 0 = reduced variable s, pass 1 = eliminated leg DoF s
-  const int dof0 = (s < n) ? P.Fd[s] : 0, dof1 = (s < nl) ? P.legd[s < 12 ? s : 0] : 0;
-  const int c0_joint = M.col_joint[dof0], c0_lin = M.col_lin[dof0], c0_ang = M.col_ang[dof0];
-  const int c1_joint = M.col_joint[dof1], c1_lin = M.col_lin[dof1], c1_ang = M.col_ang[dof1];
-  const int dq0 = cfg.damper_qidx[dof0], dq1 = cfg.damper_qidx[dof1];
-  const double dlo0 = cfg.damper_lo[dof0], dhi0 = cfg.damper_hi[dof0], dvm0 = cfg.damper_vmax[dof0];
-  const double dlo1 = cfg.damper_lo[dof1], dhi1 = cfg.damper_hi[dof1], dvm1 = cfg.damper_vmax[dof1];
+  // per-lane records (one load level: nothing waits for an index): reduced variable s, eliminated leg DoF s, first FK level
+  const DevPlan::PkCol cv = P.pk_var[s], cg = P.pk_leg[s];
+  DevPlan::PkJoint fkn = P.pk_fk[0][s];
+  const int scq0 = P.pk_scq[(2 + s) & 31], scq1 = P.pk_scq[(18 + s) & 31];
+  const int dof0 = cv.dof, dof1 = cg.dof;
+  const int c0_joint = cv.joint, c0_lin = cv.lin, c0_ang = cv.ang, c1_joint = cg.joint, c1_lin = cg.lin, c1_ang = cg.ang;
+  const int dq0 = cv.dq_idx, dq1 = cg.dq_idx;
+  const double dlo0 = cv.d_lo, dhi0 = cv.d_hi, dvm0 = cv.d_vm, dlo1 = cg.d_lo, dhi1 = cg.d_hi, dvm1 = cg.d_vm;
   const double dcoef = cfg.damper_coef, dqi = cfg.damper_qi, dqs = cfg.damper_qs;
   const int gj = M.frame_joint[WBC_FR_EE0 + 4];
   const double gp0 = M.frame_p[WBC_FR_EE0 + 4][0], gp1 = M.frame_p[WBC_FR_EE0 + 4][1], gp2 = M.frame_p[WBC_FR_EE0 + 4][2];
@@ -2815,16 +2821,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   double* const oMi = I.M1;                 // [22][12], runs on into M2
   double* const sc = I.M2 + PV * PLD - 48;  // sin / cos table: the tail of M2, free until J is written
   {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int j = 2 + s + 16 * h;
-      if (j < M.njoints) {
-        const int jt = M.jtype[j];
-        const double th = qv[M.idx_q[j]];
-        const SinCos t = sincos_cw((jt >= WBC_JT_RX && jt <= WBC_JT_RZ) ? th : 0.0);
-        sc[2 * j] = t.s; sc[2 * j + 1] = t.c;
-      }
-    }
+    if (scq0 >= 0) { const SinCos t = sincos_cw(qv[scq0]); sc[2 * (2 + s)] = t.s; sc[2 * (2 + s) + 1] = t.c; }
+    if (scq1 >= 0) { const SinCos t = sincos_cw(qv[scq1]); sc[2 * (18 + s)] = t.s; sc[2 * (18 + s) + 1] = t.c; }
     // root free-flyer (joint 1): R from the quaternion exactly as Eigen's toRotationMatrix, p = xyz; R column-major then p
     if (s == 0) {
       double Rt[9];
@@ -2841,15 +2839,15 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // inside the loop (L1-resident tables): kept live for all five levels they cost 60 VGPRs
 #pragma unroll 1
   for (int L = 0; L < 5; ++L) {
-    const int j = P.fk_sched[L][s];
+    const DevPlan::PkJoint fk = fkn;
+    if (L + 1 < 5) fkn = P.pk_fk[L + 1][s];          // next level's record is on its way while this level is computed
+    const int j = fk.joint;
     if (j >= 0) {
-      const int jt = M.jtype[j];
-      const bool rev = jt >= WBC_JT_RX && jt <= WBC_JT_RZ;
-      const int a0 = 3 * M.ax0[j], a1 = 3 * M.ax1[j], a2 = 3 * M.ax2[j];
-      const double t0 = M.tp[j][0], t1 = M.tp[j][1], t2 = M.tp[j][2];
-      const double* Pp = oMi + 12 * M.parent[j];
+      const bool rev = fk.rev != 0;
+      const int a0 = fk.a0, a1 = fk.a1, a2 = fk.a2;
+      const double* Pp = oMi + 12 * fk.parent;
       const double sn = rev ? sc[2 * j] : 0.0, cs = rev ? sc[2 * j + 1] : 1.0;
-      const double pris = rev ? 0.0 : qv[M.idx_q[j]];
+      const double pris = rev ? 0.0 : qv[fk.q_idx];
       double Av[3], Bv[3], Cv[3], Pv[3];
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr) { Av[rr] = Pp[a0 + rr]; Bv[rr] = Pp[a1 + rr]; Cv[rr] = Pp[a2 + rr]; Pv[rr] = Pp[9 + rr]; }
@@ -2859,12 +2857,13 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         Po[a0 + rr] = Av[rr];
         Po[a1 + rr] = cs * Bv[rr] + sn * Cv[rr];
         Po[a2 + rr] = cs * Cv[rr] - sn * Bv[rr];
-        Po[9 + rr] = Pv[rr] + Av[rr] * (t0 + pris) + Bv[rr] * t1 + Cv[rr] * t2;
+        Po[9 + rr] = Pv[rr] + Av[rr] * (fk.t0 + pris) + Bv[rr] * fk.t1 + Cv[rr] * fk.t2;
       }
     }
     WSYNC();
   }
   // ---- P3: Jacobian columns (WORLD): of reduced variable s, and (linear part) of eliminated leg DoF s
+  PSTOP(1, oMi[12 * 4 + (s & 7)]);
   double lin0[3] = {0, 0, 0}, ang0[3] = {0, 0, 0}, lin1[3] = {0, 0, 0};
   if (s < n) {
     const double* Pj = oMi + 12 * c0_joint;
@@ -2949,6 +2948,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
 #pragma unroll
     for (int k = 0; k < PV; ++k) if (k == s) h[k] += (s < n) ? dpost * dpost : 1.0;   // (lanes >= PV carry an all-zero row: harmless)
   }
+  PSTOP(2, h[0] + h[5] + h[11] + g);
 
   // ---- constraint rows that stay: trunk box (trunkConstraint, :707-754) on the base columns; bounds on the row's own lane
   double clb = 0.0, cub = 0.0;
@@ -3183,6 +3183,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     }
   }
   // a row of the batch tail does nothing; an instance with a leg block of rank < 2 is left to the general kernel (compact list)
+  PSTOP(3, h[0] + h[3] + g + clb + cub + lb + ub);
   const bool flagged = defer;
   bool live = valid && !flagged;
   if (valid && flagged && s == 0) {
@@ -3230,6 +3231,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     h[PV - 1] = 0.0;
   }
   if (live && !(pmin > 0.0)) { status = WBC_QP_NUMERICAL; live = false; }
+  PSTOP(4, y[0] + y[11] + h[0]);
   // y = row s of J0 = L^-T.  jf2 = |J0|_F^2 per instance
   double sq = 0.0;
 #pragma unroll
@@ -3263,6 +3265,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     for (int k = 0; k < PV; k += 2) { const double2a v2 = lds2(I.dv + k); xa = fma(y[k], v2.x, xa); xb = fma(y[k + 1], v2.y, xb); }
     x = has_b ? xa + xb : 0.0;
   }
+  PSTOP(5, x + cn2 + jf2);
   // ---- dual active-set iterations (per-row state; loops run until every row of the wave is done)
   bool act_b = false, act_r = false;
   double u = 0.0;

@@ -26,6 +26,7 @@ step = bt.make_tick_call(dev, out, 0.002)
 names = {1: "FK + Jacobian columns", 2: "task rows + targets", 3: "J'J + posture", 4: "constraint rows + damper bounds",
          5: "presolve (G, g', C', H')", 6: "Cholesky + substitutions", 7: "equality phase + x_eq", 0: "inequality phase + x = Z y + output"}
 res, prev = {}, 0.0
+bt.set_option("packed_kernel", 0)
 for k in (1, 2, 3, 4, 5, 6, 7, 0):
     bt.set_option("dbg_stop", k)
     for _ in range(3):
@@ -44,6 +45,31 @@ for k in (1, 2, 3, 4, 5, 6, 7, 0):
     res[names[k]] = {"stop": k, "cumulative_ms": t, "stage_ms": t - prev}
     prev = t
     print("stop %d  %-40s cumulative %.4f ms  stage %.4f ms" % (k, names[k], t, res[names[k]]["stage_ms"]), flush=True)
+# the packed kernel (four instances per wavefront): cuts 101..105
+bt.set_option("packed_kernel", 1)
+pnames = {101: "loads + sin/cos + FK", 102: "columns + task rows + H' rows", 103: "constraint rows + bounds + G + g' + G'G",
+          104: "Cholesky + substitutions", 105: "J store + x0", 0: "dual iterations + x = Z y + output"}
+pres, prev = {}, 0.0
+for k in (101, 102, 103, 104, 105, 0):
+    bt.set_option("dbg_stop", k)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 10)
+    t = float(np.median(ts))
+    pres[pnames[k]] = {"stop": k, "cumulative_ms": t, "stage_ms": t - prev}
+    prev = t
+    print("packed stop %3d  %-42s cumulative %.4f ms  stage %.4f ms" % (k, pnames[k], t, pres[pnames[k]]["stage_ms"]), flush=True)
+assert bt.stat("last_path") == 2
 bt.set_option("dbg_stop", 0)
+res["packed"] = pres
 print(json.dumps({"B": B, "note": "cumulative includes the (small) deferred pass; stage = difference of consecutive cuts", "stages": res}))
 bt.close()
