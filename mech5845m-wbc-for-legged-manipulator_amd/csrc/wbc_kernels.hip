@@ -2734,13 +2734,20 @@ struct __attribute__((aligned(16))) PInst {
   double M2[PV * PLD];                      // ... sin / cos table in its tail during FK; then At [16][6], K / B scratch -> J
   double Cq[PN * 6];                        // reduced constraint rows x base columns (all the reduced rows touch the base only);
                                             // rows p_keep + l are the rows of G (eliminated leg DoF l x base DoF)
+  double pad_[16];
+};
+struct __attribute__((aligned(16))) PVec {
   double in[40];                            // q [27], gripper target [3] @28, previous [3] @31, trunk box centre [4] @34
   double xv[PN], dv[PN], yv[PN], tv[PN];
   double cl[32];                            // row-bound staging -> Cholesky column broadcast (entries 12..31 zero) -> qdot by DoF
   double pad_[8];
 };
-static_assert(sizeof(PInst) == 4608, "PInst: 576 doubles (= 0 mod 32), so that the four instances' rows fall on the same bank pattern; 18 KB per wave");
-struct __attribute__((aligned(16))) SmemP { PInst I[4]; };
+// Bank placement (ds_read_b64 / b128 bank = dword address mod 64; instances r and r + 1 share a lane group): the matrices'
+// "lane = row" b128 reads interleave conflict-free when the instances sit a multiple of 256 B apart; the vectors are read as
+// broadcasts or "lane = element" b64, which collide at that distance and are conflict-free 128 B (mod 256) apart.
+static_assert(sizeof(PInst) % 256 == 0, "matrix blocks: a multiple of the 256-byte bank row apart");
+static_assert(sizeof(PVec) % 256 == 128, "vector blocks: half a bank row apart (mod 256 B)");
+struct __attribute__((aligned(16))) SmemP { PInst I[4]; PVec V[4]; };
 
 __device__ __forceinline__ double rsum16(double v) {     // sum over the lane's 16-lane row, result in every lane of the row
   v += dpp<DPP_XOR1>(v); v += dpp<DPP_XOR2>(v); v += dpp<DPP_HALF_MIRROR>(v); v += dpp<DPP_MIRROR>(v);
@@ -2767,6 +2774,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   __shared__ SmemP SP;
   const int lane = threadIdx.x, r = lane >> 4, s = lane & 15, rbase = lane & 48;
   PInst& I = SP.I[r];
+  PVec& V = SP.V[r];
   const int b_raw = 4 * blockIdx.x + r;
   const bool valid = b_raw < A.B;
   const int b = valid ? b_raw : A.B - 1;
@@ -2785,10 +2793,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     if (s < 3) ex = A.in.ee_target ? A.in.ee_target[(size_t)b * 15 + 12 + s] : 0.0;
     else if (s < 6) ex = A.in.prev_ee_target ? A.in.prev_ee_target[(size_t)b * 15 + 12 + (s - 3)] : 0.0;
     else if (s < 10) ex = A.in.trunk_box_center ? A.in.trunk_box_center[(size_t)b * 4 + (s - 6)] : 0.0;
-    I.in[s] = q0;
-    if (16 + s < 28) I.in[16 + s] = q1;
-    if (s < 10) I.in[28 + s] = ex;
-    I.cl[s] = 0.0; I.cl[16 + s] = 0.0;
+    V.in[s] = q0;
+    if (16 + s < 28) V.in[16 + s] = q1;
+    if (s < 10) V.in[28 + s] = ex;
+    V.cl[s] = 0.0; V.cl[16 + s] = 0.0;
   }
   const int nv = M.nv, nq = M.nq, n = P.n_red, nelim = P.nelim, nl = 3 * nelim, p_keep = P.p_keep, p = p_keep + nl;
   const unsigned fl = P.flags;
@@ -2815,7 +2823,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   for (int i = 0; i < 3; ++i) eG[i] = cfg.ee_gain[4][i];
   const double joint_w = cfg.joint_w, tb_z = cfg.trunk_box_z_frac, tb_a = cfg.trunk_box_ang, tb_s = cfg.trunk_box_scale;
   WSYNC();
-  const double* const qv = I.in;
+  const double* const qv = V.in;
 
   // ---- sin / cos of the joint angles: joint j (>= 2) reads q[idx_q[j]]; two joints per lane
   double* const oMi = I.M1;                 // [22][12], runs on into M2
@@ -2907,8 +2915,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       a[rr] = sup ? eW[rr] * ((lin0[rr] + wxp[rr]) * ee_w) : 0.0;
       a[3 + rr] = sup ? eW[3 + rr] * (ang0[rr] * ee_w) : 0.0;
     }
-    const double* xt = I.in + 28;
-    const double* xp = I.in + 31;
+    const double* xt = V.in + 28;
+    const double* xp = V.in + 31;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {          // calcTargetVelEE3 (:1052-1157) with R* == R*_prev; EndEffectorB2 (:907-910)
       const double br = ((xt[i] - xp[i]) * inv_dt + eG[i] * ((xt[i] - pfe[i]) * inv_dt)) * ee_w;
@@ -2933,8 +2941,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   if (s >= n) g = 0.0;
   if (A.post_static && P.post_pert) {     // the state qpJointb leaves behind: bounds and integrate see it
     WSYNC();
-    if (((P.post_pert >> s) & 1u)) I.in[s] = (qv[s] + 0.0002) - (0.0002 * 2);
-    if (16 + s < NQ && ((P.post_pert >> (16 + s)) & 1u)) I.in[16 + s] = (qv[16 + s] + 0.0002) - (0.0002 * 2);
+    if (((P.post_pert >> s) & 1u)) V.in[s] = (qv[s] + 0.0002) - (0.0002 * 2);
+    if (16 + s < NQ && ((P.post_pert >> (16 + s)) & 1u)) V.in[16 + s] = (qv[16 + s] + 0.0002) - (0.0002 * 2);
   }
   WSYNC();
   // row s of H' = sum_r At[s][r] At[k][r] (+ posture): straight into the registers the Cholesky sweep works on
@@ -2959,7 +2967,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     const double ay = (s == 1) ? Rtr[7] : ((s == 2) ? -Rtr[6] : Rtr[3]);
     const double ax = (s == 1) ? Rtr[8] : ((s == 2) ? sqrt(fma(Rtr[7], Rtr[7], Rtr[8] * Rtr[8])) : Rtr[0]);
     const double eul = atan2(ay, ax);        // lanes 1, 2, 3 hold roll, pitch, yaw
-    const double* bc = I.in + 34;
+    const double* bc = V.in + 34;
     if (s < 4) {
       const double cr = (s == 0) ? ptr[2] : eul;
       const double vr = (s == 0) ? bc[0] * tb_z : tb_a;
@@ -3002,18 +3010,18 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
 #pragma unroll
       for (int c = 0; c < 6; ++c) grow[c] = id * (r0 * Bb[4 * c] + r1 * Bb[4 * c + 1] + r2 * Bb[4 * c + 2]);
     }
-    if (s < 12) I.xv[s] = g1;
+    if (s < 12) V.xv[s] = g1;
     // leg-bound rows: row p_keep + l = G_l with the leg DoF's velocity bounds; the bounds move p_keep lanes up through LDS
     if (s < nl) {
 #pragma unroll
       for (int c = 0; c < 6; c += 2) sts2(I.Cq + (p_keep + s) * 6 + c, grow[c], grow[c + 1]);
-      I.cl[p_keep + s] = lb1; I.cl[16 + p_keep + s] = ub1;
+      V.cl[p_keep + s] = lb1; V.cl[16 + p_keep + s] = ub1;
     }
   }
-  if (s < p_keep) { I.cl[s] = clb; I.cl[16 + s] = cub; }
+  if (s < p_keep) { V.cl[s] = clb; V.cl[16 + s] = cub; }
   WSYNC();
-  clb = (s < p) ? I.cl[s] : 0.0;
-  cub = (s < p) ? I.cl[16 + s] : 0.0;
+  clb = (s < p) ? V.cl[s] : 0.0;
+  cub = (s < p) ? V.cl[16 + s] : 0.0;
   // ---- a rank-deficient leg block (rare; whole-wave branch, per-instance predicates): K_f P = Q R by column-pivoted Gram-Schmidt
   // on lane f of the instance (see process_sim3): z0, z1 are eliminated as usual, the third contact row E q̇_base + r22 z2 = 0 and
   // the leg velocity z2 pivoted last are dealt with by the SWAP further down. Ex[f] = E [6], r22, g0x, g1x, l0, l1, l2.
@@ -3086,7 +3094,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       const double2a t0 = lds2(Gr + l * 6), t1 = lds2(Gr + l * 6 + 2), t2 = lds2(Gr + l * 6 + 4);
       gg[0] = fma(gl, t0.x, gg[0]); gg[1] = fma(gl, t0.y, gg[1]); gg[2] = fma(gl, t1.x, gg[2]);
       gg[3] = fma(gl, t1.y, gg[3]); gg[4] = fma(gl, t2.x, gg[4]); gg[5] = fma(gl, t2.y, gg[5]);
-      gs = fma(gl, I.xv[l], gs);
+      gs = fma(gl, V.xv[l], gs);
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) h[c] = fma(d2, gg[c], h[c]);
@@ -3119,19 +3127,19 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       const double us = (s < 6) ? ((s == cstar) ? wz : -Ec / Ecs) : 0.0;
       const double hyz = (s < 6) ? d2 * (I.Cq[(p_keep + l0) * 6 + s] * g0x + I.Cq[(p_keep + l1) * 6 + s] * g1x) : 0.0;
       const double hzz = d2 * (g0x * g0x + g1x * g1x + 1.0);
-      const double gz = g0x * I.xv[l0] + g1x * I.xv[l1] + I.xv[l2];
+      const double gz = g0x * V.xv[l0] + g1x * V.xv[l1] + V.xv[l2];
       WSYNC();
       if (on) {
-        I.yv[s] = us; I.dv[s] = hyz;
+        V.yv[s] = us; V.dv[s] = hyz;
         if (s == cstar) {
 #pragma unroll
-          for (int k = 0; k < PV; ++k) I.tv[k] = h[k];
+          for (int k = 0; k < PV; ++k) V.tv[k] = h[k];
         }
       }
       WSYNC();
       const double gcs = bperm(g, rbase + cstar);
       if (on && s < n) {
-        const double Hcc = I.tv[cstar], hyzc = I.dv[cstar];
+        const double Hcc = V.tv[cstar], hyzc = V.dv[cstar];
         double hic = 0.0;
 #pragma unroll
         for (int j = 0; j < PV; ++j) hic = (j == cstar) ? h[j] : hic;
@@ -3139,14 +3147,14 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         if (s != cstar) {
 #pragma unroll
           for (int j = 0; j < PV; ++j) {
-            const double uj = I.yv[j], Hcj = I.tv[j];
+            const double uj = V.yv[j], Hcj = V.tv[j];
             h[j] = (j == cstar) ? wz * hic + hyz + us * kz : h[j] + us * Hcj + hic * uj + us * uj * Hcc;
           }
           g = fma(us, gcs, g);
         } else {
 #pragma unroll
           for (int j = 0; j < PV; ++j) {
-            const double uj = I.yv[j], Hcj = I.tv[j], hj = I.dv[j];
+            const double uj = V.yv[j], Hcj = V.tv[j], hj = V.dv[j];
             h[j] = (j == cstar) ? wz * wz * Hcc + 2.0 * wz * hyzc + hzz : wz * Hcj + hj + uj * kz;
           }
           g = wz * gcs + gz;
@@ -3159,7 +3167,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         const double crz = (s == p_keep + l0) ? g0x : ((s == p_keep + l1) ? g1x : 0.0);
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-          const double uc = I.yv[c];
+          const double uc = V.yv[c];
           row[c] = (s == p_keep + l2) ? uc : ((c == cstar) ? crc * wz + crz : row[c] + crc * uc);
         }
       }
@@ -3168,7 +3176,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       for (int f2 = f + 1; f2 < 4; ++f2) {
         const double e2 = Ex[12 * f2 + cstar];
         WSYNC();
-        if (on && s < 6) Ex[12 * f2 + s] = (s == cstar) ? e2 * wz : Ex[12 * f2 + s] + e2 * I.yv[s];
+        if (on && s < 6) Ex[12 * f2 + s] = (s == cstar) ? e2 * wz : Ex[12 * f2 + s] + e2 * V.yv[s];
       }
       // bounds: slot c* is leg DoF l2 now, row p_keep + l2 is base DoF c*; and what the two lanes deliver at the end
       {
@@ -3202,9 +3210,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     const unsigned long long nb = __ballot(status != WBC_QP_OPTIMAL);
     if ((nb >> rbase) & 0xFFFFull) { status = WBC_QP_NUMERICAL; live = false; }
   }
-  // ---- Cholesky H' = L L' fused with the substitution L y = e_s (rotating registers; column broadcast through I.cl)
+  // ---- Cholesky H' = L L' fused with the substitution L y = e_s (rotating registers; column broadcast through V.cl)
   WSYNC();
-  I.cl[s] = 0.0; I.cl[16 + s] = 0.0;        // (the row bounds were staged there)
+  V.cl[s] = 0.0; V.cl[16 + s] = 0.0;        // (the row bounds were staged there)
   double y[PV];
 #pragma unroll
   for (int k = 0; k < PV; ++k) y[k] = (k == s) ? 1.0 : 0.0;
@@ -3212,9 +3220,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
 #pragma unroll 1
   for (int j = 0; j < PV; ++j) {
     WSYNC();
-    if (s < PV) I.cl[s] = h[0];
+    if (s < PV) V.cl[s] = h[0];
     WSYNC();
-    const double* cj = I.cl + j;
+    const double* cj = V.cl + j;
     const double pj = cj[0];
     pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;
     const double rinv = rsqrt(pj), ipj = rinv * rinv;
@@ -3244,7 +3252,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
 #pragma unroll
     for (int k = 0; k < PV; k += 2) { sts2(J + s * PLD + k, y[k], y[k + 1]); sts2(T + s * PLD + k, 0.0, 0.0); }
   }
-  I.tv[s] = g;
+  V.tv[s] = g;
   // |C_r|^2 of row s
   double cn2 = 0.0;
   if (has_r) {
@@ -3257,12 +3265,12 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   {
     double t = 0.0;
 #pragma unroll
-    for (int i = 0; i < PV; ++i) t = fma(J[i * PLD + (s < PV ? s : 0)], I.tv[i], t);
-    I.dv[s] = has_b ? -t : 0.0;
+    for (int i = 0; i < PV; ++i) t = fma(J[i * PLD + (s < PV ? s : 0)], V.tv[i], t);
+    V.dv[s] = has_b ? -t : 0.0;
     WSYNC();
     double xa = 0.0, xb = 0.0;
 #pragma unroll
-    for (int k = 0; k < PV; k += 2) { const double2a v2 = lds2(I.dv + k); xa = fma(y[k], v2.x, xa); xb = fma(y[k + 1], v2.y, xb); }
+    for (int k = 0; k < PV; k += 2) { const double2a v2 = lds2(V.dv + k); xa = fma(y[k], v2.x, xa); xb = fma(y[k + 1], v2.y, xb); }
     x = has_b ? xa + xb : 0.0;
   }
   PSTOP(5, x + cn2 + jf2);
@@ -3276,7 +3284,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   for (;;) {
     // most violated inactive inequality of each row
     WSYNC();
-    I.xv[s] = x;
+    V.xv[s] = x;
     WSYNC();
     double best = 0.0; int code = -1;
     if (has_b && !act_b) {
@@ -3285,7 +3293,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     }
     if (has_r && !act_r) {
       const double2a c0 = lds2(I.Cq + s * 6), c1 = lds2(I.Cq + s * 6 + 2), c2 = lds2(I.Cq + s * 6 + 4);
-      const double2a x0 = lds2(I.xv), x1 = lds2(I.xv + 2), x2 = lds2(I.xv + 4);
+      const double2a x0 = lds2(V.xv), x1 = lds2(V.xv + 2), x2 = lds2(V.xv + 4);
       const double v = fma(c0.x, x0.x, fma(c0.y, x0.y, fma(c1.x, x1.x, fma(c1.y, x1.y, fma(c2.x, x2.x, c2.y * x2.y)))));
       if (clb > -QP_INF) { const double sl = v - clb; if (sl < -1e-9 * fmax(1.0, fabs(clb)) && sl < best) { best = sl; code = n + s; } }
       if (cub < QP_INF) { const double sl = cub - v; if (sl < -1e-9 * fmax(1.0, fabs(cub)) && sl < best) { best = sl; code = (n + s) | 256; } }
@@ -3316,9 +3324,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         const int lc = bpermi(a_code, rbase + l) & 255;
         if (dr) { if (lc >= n) { if (s == lc - n) act_r = false; } else { if (s == lc) act_b = false; } }
         WSYNC();
-        I.yv[s] = u; I.tv[s] = (double)a_code;
+        V.yv[s] = u; V.tv[s] = (double)a_code;
         WSYNC();
-        if (dr && s >= l && s < q - 1) { u = I.yv[s + 1]; a_code = (int)I.tv[s + 1]; }
+        if (dr && s >= l && s < q - 1) { u = V.yv[s + 1]; a_code = (int)V.tv[s + 1]; }
         if (dr && s == q - 1) { u = 0.0; a_code = 0; }
         const int sv = s < PV ? s : PV - 1;   // (lanes beyond the variables shadow the last row; they never write)
         const int srow = (sv >= l) ? ((sv + 1 < PV) ? sv + 1 : sv) : sv;
@@ -3359,15 +3367,15 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         }
         WSYNC();
         // slack of the constraint being added, at the current x
-        I.xv[s] = x;
+        V.xv[s] = x;
         WSYNC();
         if (dr) {
           double v;
           if (is_row) {
             const double2a c0 = lds2(I.Cq + rr_ * 6), c1 = lds2(I.Cq + rr_ * 6 + 2), c2 = lds2(I.Cq + rr_ * 6 + 4);
-            const double2a x0 = lds2(I.xv), x1 = lds2(I.xv + 2), x2 = lds2(I.xv + 4);
+            const double2a x0 = lds2(V.xv), x1 = lds2(V.xv + 2), x2 = lds2(V.xv + 4);
             v = fma(c0.x, x0.x, fma(c0.y, x0.y, fma(c1.x, x1.x, fma(c1.y, x1.y, fma(c2.x, x2.x, c2.y * x2.y)))));
-          } else v = I.xv[ip & 15];
+          } else v = V.xv[ip & 15];
           s_ip = sgn * v - b_ip;
           drop_l = -1;
         }
@@ -3382,20 +3390,20 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       } else d = sgn * J[(ip & 15) * PLD + s];
       if (!has_b || !stepping) d = 0.0;      // (lanes >= n read padding: masked here)
       WSYNC();
-      I.dv[s] = d; I.yv[s] = (s >= q) ? d : 0.0;
+      V.dv[s] = d; V.yv[s] = (s >= q) ? d : 0.0;
       WSYNC();
       const double zn = rsum16(s >= q ? d * d : 0.0);
       double z = 0.0, zb = 0.0, rv = 0.0, rvb = 0.0;
       const int srd = s < PV ? s : PV - 1;
 #pragma unroll
       for (int k = 0; k < PV; k += 2) {
-        const double2a j2 = lds2(J + srd * PLD + k); const double2a y2 = lds2(I.yv + k);
+        const double2a j2 = lds2(J + srd * PLD + k); const double2a y2 = lds2(V.yv + k);
         z = fma(j2.x, y2.x, z); zb = fma(j2.y, y2.y, zb);
       }
       z += zb;
 #pragma unroll
       for (int k = 0; k < PV; k += 2) {
-        const double2a t2 = lds2(T + srd * PLD + k); const double2a d2 = lds2(I.dv + k);
+        const double2a t2 = lds2(T + srd * PLD + k); const double2a d2 = lds2(V.dv + k);
         rv = fma(t2.x, d2.x, rv); rvb = fma(t2.y, d2.y, rvb);
       }
       rv += rvb;
@@ -3426,7 +3434,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         if (add && has_b && vv > 0.0) {
 #pragma unroll
           for (int k = 0; k < PV; k += 2) {
-            const double2a j2 = lds2(J + s * PLD + k); const double2a y2 = lds2(I.yv + k);   // yv = d for k >= q, else 0
+            const double2a j2 = lds2(J + s * PLD + k); const double2a y2 = lds2(V.yv + k);   // yv = d for k >= q, else 0
             const double v0 = (k == q) ? y2.x - delta : y2.x;
             const double v1 = (k + 1 == q) ? y2.y - delta : y2.y;
             sts2(J + s * PLD + k, fma(-w, v0, j2.x), fma(-w, v1, j2.y));
@@ -3452,23 +3460,23 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
 
   // ---- x = Z y, q̇ by DoF through LDS, outputs
   WSYNC();
-  I.xv[s] = has_b ? x : 0.0;
-  I.cl[s] = 0.0; I.cl[16 + s] = 0.0;
+  V.xv[s] = has_b ? x : 0.0;
+  V.cl[s] = 0.0; V.cl[16 + s] = 0.0;
   WSYNC();
   double x1 = 0.0;
   if (s < nl) {
-    const double2a v0 = lds2(I.xv), v1 = lds2(I.xv + 2), v2 = lds2(I.xv + 4);
+    const double2a v0 = lds2(V.xv), v1 = lds2(V.xv + 2), v2 = lds2(V.xv + 4);
     const double2a g0 = lds2(I.Cq + (p_keep + s) * 6), g1_ = lds2(I.Cq + (p_keep + s) * 6 + 2), g2 = lds2(I.Cq + (p_keep + s) * 6 + 4);
     x1 = fma(g0.x, v0.x, fma(g0.y, v0.y, fma(g1_.x, v1.x, fma(g1_.y, v1.y, fma(g2.x, v2.x, g2.y * v2.y)))));
-    I.cl[dofB] = x1;
+    V.cl[dofB] = x1;
   }
-  if (s < n) I.cl[dofA] = x;
+  if (s < n) V.cl[dofA] = x;
   WSYNC();
   const bool wr = valid && !flagged;
   if (wr) {
     double* qo = A.out.qdot + (size_t)b * NV;
-    qo[s] = I.cl[s];
-    if (16 + s < NV) qo[16 + s] = I.cl[16 + s];
+    qo[s] = V.cl[s];
+    if (16 + s < NV) qo[16 + s] = V.cl[16 + s];
     if (s == 0) {
       A.out.status[b] = status;
       if (A.out.iters) A.out.iters[b] = iters + nl + P.nlock;
@@ -3477,16 +3485,16 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // ---- jointVelocitiestoConfig (Robot_Wrapper4.py:440-441)
   if (A.out.q_next) {
     WSYNC();
-    I.xv[s] = (s < 6) ? I.cl[s] * dt : 0.0;
+    V.xv[s] = (s < 6) ? V.cl[s] * dt : 0.0;
     WSYNC();
     double* qn = A.out.q_next + (size_t)b * NQ;
     if (wr) {
-      integrate_ff(I, s, qn);
+      integrate_ff(V, s, qn);
       // 1-DoF joints: q + v dt, DoF by DoF (two per lane; a locked DoF's velocity is 0, the padding of a smaller model stays 0)
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int d = 6 + s + 16 * hh;
-        if (d < nv) { const int qi = M.col_q[d]; qn[qi] = qv[qi] + I.cl[d] * dt; }
+        if (d < nv) { const int qi = M.col_q[d]; qn[qi] = qv[qi] + V.cl[d] * dt; }
       }
       if (s < NQ - nq) qn[nq + s] = 0.0;
     }
