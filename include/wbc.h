@@ -297,6 +297,10 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          path), so on the sim3 switch set it costs the structural speed-up.
  *   "presolve"         [1] structural elimination of the stance-foot contact equalities (Robot_Wrapper4.py:757-761) where no
  *                          task touches the stance legs; 0: every QP runs at its full size n = nv.
+ *   "presolve_orth"    [1] the same elimination where tasks DO touch the stance legs (foot / trunk / CoM tasks, e.g. BASELINE
+ *                          configs[1]), through an orthonormal basis of the contact rows' null space (Householder QR per instance):
+ *                          the reduced QP is as well conditioned as the full one; the base and stance-leg velocity bounds become
+ *                          6 + 3 x (stance feet) two-sided rows. 0: those configurations run at full size. Needs "presolve".
  *   "sim3_kernel"      [1] batches whose every model has such an elimination plan, <= 16 constraint rows and no orientation
  *                          references run on the compact wbc_tick_sim3_kernel (+ a second pass of the general kernel over the
  *                          instances whose leg blocks it could not eliminate); 0: the general kernel does the elimination.
@@ -324,7 +328,8 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
 int wbc_batch_set_option(WbcBatch* b, const char* name, int value);
 
 /* Read-only statistics of a handle: "last_path" (kernel the last tick ran on: 0 general, 1 compact sim3 + second pass, 2 packed
- * compact sim3 — four instances per wavefront — + second pass),
+ * compact sim3 — four instances per wavefront — + second pass), "last_orth" (1: that general-kernel tick ran the variant with the
+ * orthonormal contact presolve, option "presolve_orth"),
  * "deferred_last" (instances the last sim3-kernel tick left to the second pass; waits for `stream`), "pivoted_last" (instances
  * that took the pivoted elimination, with option "count_pivoted"),
  * "sim3_lds_bytes" / "tick_lds_bytes" (LDS per instance of the two tick kernels). */

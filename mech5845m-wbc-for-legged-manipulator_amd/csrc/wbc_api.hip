@@ -41,7 +41,7 @@ struct WbcBatch {
   size_t ws_bytes;
   int mrows, prows, mcart;
   int jtj_mfma;
-  int presolve;
+  int presolve, presolve_orth;
   double sing_tol;
   int sim3_kernel;       // 1 (default): batches that qualify run on wbc_tick_sim3_kernel (compact LDS) + a deferred pass
   int32_t* d_status;     // status buffer of our own when the caller passes none (the deferred pass needs one)
@@ -50,6 +50,7 @@ struct WbcBatch {
   int packed_kernel;     // 1 (default): eligible batches run four instances per wavefront (wbc_tick_sim3p_kernel)
   int warm_start;        // 1: wbc_rollout carries each instance's working set from tick to tick (default 0: measured slower)
   int32_t* d_defer;      // [1 + max_batch]: count + compact list of the instances the sim3 kernel deferred (lazy)
+  int last_orth;         // the last general-kernel tick ran the variant with the orthonormal contact presolve
   int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass)
   int max_nj, max_nf;    // FK output strides: the largest model's joint / frame counts
   unsigned long long* d_prof;
@@ -145,7 +146,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   WbcBatch* b = new (std::nothrow) WbcBatch;
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
-  b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
+  b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->presolve_orth = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
   b->jtj_mfma = -1; b->warm_start = 0; b->packed_kernel = 1;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
@@ -207,6 +208,11 @@ static int rows_con(const WbcConfig& c) {
   return p;
 }
 
+static int any_orth_plan(const WbcBatch* b) {
+  for (int i = 0; i < b->n_models; ++i) if (b->plan_host[i].orth) return 1;
+  return 0;
+}
+
 // Which stance feet's contact equalities the tick kernel eliminates structurally (contact_presolve in wbc_kernels.hip).
 // Enabled only when (1) every contact foot's rows are supported by the 6 base DoF + 3 own leg DoF, the leg sets disjoint,
 // (2) NO active task touches an eliminated leg DoF (then H_ll = d^2 I, H_lf = 0 and the reduction costs no accuracy),
@@ -262,9 +268,12 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
     for (int d = 0; d < M.nv; ++d) if ((legs >> d) & 1u) { P->lidx[d] = l; P->legd[l++] = d; }
     prow += 3;
   }
-  if (!nelim || !c.task_joint || c.task_com) return;
-  for (int e = 0; e < WBC_NEE; ++e) if (c.task_ee[e] && (M.frame_support[WBC_FR_EE0 + e] & legmask)) return;
-  if (c.task_trunk && (M.frame_support[WBC_FR_TRUNK] & legmask)) return;
+  if (!nelim || !c.task_joint) return;
+  // `clean`: no task touches the stance legs (H_ll = d^2 I, H_lf = 0): the explicit G = -K^-1 B costs no accuracy (contact_presolve,
+  // the sim3 kernels). Otherwise the elimination goes through an orthonormal null-space basis (contact_presolve_orth).
+  bool clean = !c.task_com;
+  for (int e = 0; e < WBC_NEE; ++e) if (c.task_ee[e] && (M.frame_support[WBC_FR_EE0 + e] & legmask)) clean = false;
+  if (c.task_trunk && (M.frame_support[WBC_FR_TRUNK] & legmask)) clean = false;
   // DoF the velocity box locks at 0 (lb = ub = 0 from lock_from on, Robot_Wrapper4.py:627-630) are known: they leave the reduced
   // problem altogether (their q̇ is 0, they contribute to nothing else) — which also leaves room in qp_core<16> for the
   // extra unknown a rank-deficient stance-leg block keeps (pivoted elimination in wbc_tick_sim3_kernel)
@@ -273,7 +282,7 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
   // (exact whatever rows touch them: a column that multiplies a velocity fixed at 0 contributes to nothing)
   const int nlock = __builtin_popcount(lockmask);
   const int n_red = M.nv - 3 * nelim - nlock, p_keep = prows - 3 * nelim;
-  if (n_red > WBC_PLAN_NR || n_red < 6 || p_keep + (c.use_bounds ? 3 * nelim : 0) > WBC_MAX_P) return;
+  if (n_red > WBC_PLAN_NR || n_red < 6 || p_keep + (c.use_bounds ? 3 * nelim + (clean ? 0 : 6) : 0) > WBC_MAX_P) return;
   int cnt = 0;
   for (int d = 0; d < M.nv; ++d) if (!(((legmask | lockmask) >> d) & 1u)) { P->pos[d] = cnt; P->Fd[cnt++] = d; }
   P->nlock = nlock;
@@ -291,7 +300,9 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
       r += 3;
     }
   }
-  P->nelim = nelim; P->n_red = n_red; P->p_keep = p_keep; P->enabled = 1;
+  P->nelim = nelim; P->n_red = n_red; P->p_keep = p_keep;
+  if (!clean) { P->orth = 1; return; }
+  P->enabled = 1;
   // ---- the packed kernel (wbc_tick_sim3p_kernel) covers the sim3 switch-set family only: Grip task or none, no trunk / CoM
   // task, the kept rows = the trunk box (base support only), velocity bounds on, a posture mode it can form itself, every
   // joint it needs within tree depth 6 and at most 16 joints per level
@@ -368,6 +379,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!b || !name) return fail(WBC_E_ARG, "wbc_batch_set_option: null");
   if (!strcmp(name, "jtj_mfma")) { b->jtj_mfma = value < 0 ? -1 : (value ? 1 : 0); return WBC_OK; }
   if (!strcmp(name, "presolve")) { b->presolve = value; return WBC_OK; }
+  if (!strcmp(name, "presolve_orth")) { b->presolve_orth = value; return WBC_OK; }
   if (!strcmp(name, "presolve_tol_exp")) { double t = 1.0; for (int i = 0; i < value; ++i) t *= 0.1; b->sing_tol = t; return WBC_OK; }
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
   if (!strcmp(name, "packed_kernel")) { b->packed_kernel = value; return WBC_OK; }
@@ -390,6 +402,7 @@ extern "C" int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, i
   if (!b || !name || !out) return fail(WBC_E_ARG, "wbc_batch_get_stat: null");
   HIP_TRY(hipSetDevice(b->device_id));
   if (!strcmp(name, "last_path")) { *out = b->last_path; return WBC_OK; }
+  if (!strcmp(name, "last_orth")) { *out = b->last_path == 0 ? b->last_orth : 0; return WBC_OK; }
   if (!strcmp(name, "deferred_last")) {      // waits for `stream`
     *out = 0;
     if (!b->d_defer || !b->last_path) return WBC_OK;
@@ -557,7 +570,7 @@ static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
   a.models = b->d_models; a.cfgs = b->d_cfgs; a.plans = b->d_plans; a.n_models = b->n_models;
   // J'J on the matrix cores: forced (1), off (0) or, by default (-1), for wide Cartesian stacks only — measured on MI355X
   // (profiles/r02_mfma_evidence.txt): +9 % ticks/s at 33 and 45 Cartesian rows (config 2, "everything"), a wash at 6 (config 3)
-  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma < 0 ? (b->mcart >= WBC_MFMA_AUTO_ROWS) : b->jtj_mfma; a.presolve = b->presolve; a.sing_tol = b->sing_tol; a.dbg_alias = b->dbg_alias; a.dt = dt;
+  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma < 0 ? (b->mcart >= WBC_MFMA_AUTO_ROWS) : b->jtj_mfma; a.presolve = b->presolve; a.presolve_orth = b->presolve_orth ? 1 + any_orth_plan(b) : 0; a.sing_tol = b->sing_tol; a.dbg_alias = b->dbg_alias; a.dt = dt;
   a.prof = b->d_prof; a.dbg_stop = b->dbg_stop;
   a.fk_nj = b->max_nj; a.fk_nf = b->max_nf;
 }
@@ -579,6 +592,7 @@ static bool sim3_eligible(const WbcBatch* b, const KernelArgs& a) {
 static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
   if (!sim3_eligible(b, a)) {
     b->last_path = 0;
+    b->last_orth = a.presolve && a.presolve_orth == 2 && !(a.ws_in || a.ws_out);
     if (int e = launch_tick(a, MODE_TICK, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return WBC_OK;
   }

@@ -38,7 +38,8 @@ struct DevPlan {
   int32_t enabled, nelim, n_red, p_keep;
   int32_t nlock;                     // DoF locked at 0 by the velocity box (>= lock_from, use_bounds): left out of the reduced problem
   int32_t packed_ok;                 // the packed kernel (four instances per wavefront) can run this (model, configuration)
-  int32_t pad_[2];
+  int32_t orth;                      // tasks touch the stance legs: contact elimination through an orthonormal null-space basis (contact_presolve_orth)
+  int32_t pad_[1];
   // packed kernel (wbc_tick_sim3p_kernel): everything a lane needs, one record per role, so that no load depends on another
   struct PkJoint { int32_t joint, parent, a0, a1, a2, rev, q_idx, pad_; double t0, t1, t2; };   // a*: 3 x column of the axis / its successors in R
   struct PkCol { int32_t dof, joint, lin, ang, dq_idx, pad_[3]; double d_lo, d_hi, d_vm; };       // Jacobian column + velocity-damper entries of a DoF
@@ -79,7 +80,8 @@ struct KernelArgs {
   int32_t fk_nj, fk_nf;             // oMi / oMf output strides = max njoints / nframes over the handle's models
   int32_t* defer;                   // [1 + max_batch]: count, then the instances wbc_tick_sim3_kernel left to the general path
   int32_t* pivot_count;             // diagnostic (option "count_pivoted"): instances that took the pivoted elimination; else null
-  int32_t dbg_force_defer, pad2_;   // diagnostic: every instance with a flagged leg block is deferred instead of pivoted
+  int32_t dbg_force_defer;          // diagnostic: every instance with a flagged leg block is deferred instead of pivoted
+  int32_t presolve_orth;            // the orthonormal contact presolve where DevPlan.orth: 0 off, 1 on, 2 on and a plan of this batch has DevPlan.orth (host)
   // warm start: the final working set of the previous tick, [B][2] words in FULL-problem indexing whatever
   // kernel wrote them: word 0 = velocity bounds (bit d: DoF d at its lower bound, bit 32 + d: at its upper bound), word 1 =
   // constraint rows of findConstraints' order (bit i / 32 + i). Either may be null (cold start / nothing carried); they may alias.

@@ -1285,10 +1285,269 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// The contact presolve for configurations whose tasks DO touch the stance legs (foot / trunk / CoM tasks: DevPlan.orth; BASELINE
+// configs[1] is one): the explicit G = -K^-1 B of contact_presolve makes Z'HZ up to 10^8 x worse conditioned than H there, so the
+// contact equalities E [qd_base; qd_legs] = 0 (E = [B K], 3 rows per stance foot) are eliminated through an ORTHONORMAL basis of
+// their null space instead: Householder QR of E' (18 x 12), Z = the last six columns of Q, [qd_base; qd_legs] = Z y~. Then
+// cond(Z'HZ) <= cond(H), a rank-deficient K is no special case (E keeps full row rank through B), and the reduced problem has
+// n' = 6 + (free DoF outside base and stance legs) unknowns:
+//     H' = Z'HZ  (6 x 6 block and 6 x rest strip recomputed, the rest of H kept),   g' = Z'g,
+//     kept rows C' = C Z;  the velocity bounds of the base and stance-leg DoF become the 6 + 3 nelim rows of Z (two-sided),
+//     the other DoF keep their simple bounds;  qd = Z y.
+// Same minimiser as the full problem (tests compare against the oracle's full solve). Returns false (general path) only when two
+// contact rows are numerically dependent.  LDS: Householder broadcast RB[0..32), T = H(:, bl) Z at RB[32..188), Z'T at RB[188..224),
+// Z at RB[16 LDJ ..)
+// (rows >= 16 of RB are never touched by qp_core<16>).
+// ------------------------------------------------------------------------------------------------
+#ifdef ORTH_CUT   // timing cuts (variant builds only: make variant VFLAGS=-DORTH_CUT=k): the presolve returns after stage k with garbage
+#define OCUT(k, val) do { if (ORTH_CUT == (k)) { res.x = (val); res.status = 0; res.iters = 0; res.ws_b = res.ws_r = 0; return true; } } while (0)
+#else
+#define OCUT(k, val) do { } while (0)
+#endif
+__device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
+                                                      const DevPlan& P, const double g, const double lb, const double ub,
+                                                      const double clb, const double cub, const int lane,
+                                                      unsigned long long* ts, QpResult& res) {
+  if (!A.presolve || !A.presolve_orth || !P.orth) return false;
+  const int nv = M.nv, p = A.prows;
+  const int nelim = P.nelim, n_red = P.n_red, nl = 3 * nelim;
+  constexpr int NB = 18;                         // base + stance-leg coordinates: j < 6 base DoF j, 6 + l eliminated leg DoF l
+  double* const Vm = S.RB;                       // Householder vector broadcast (two slots of 10)
+  double* const Tm = S.RB + 32;                  // [26][6]  H(:, bl) Z
+  double* const Bm = S.RB + 32 + NV * 6;         // [6][6]   Z'H(bl, bl) Z, the base block of H'
+  double* const Zm = S.RB + NR * LDJ;            // [NB][6]
+  double* const Cm = S.RC;
+  int legd[12], Fd[NR], rowstart[4];
+#pragma unroll
+  for (int l = 0; l < 12; ++l) legd[l] = P.legd[l];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) Fd[k] = P.Fd[k];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) rowstart[f] = P.rowstart[f];
+  const unsigned elimrows = P.elimrows, legrows = P.legrows;
+#pragma unroll
+  for (int l = 0; l < 12; ++l) asm volatile("" : "+s"(legd[l]));
+#pragma unroll
+  for (int k = 0; k < NR; ++k) asm volatile("" : "+s"(Fd[k]));
+#pragma unroll
+  for (int f = 0; f < 4; ++f) asm volatile("" : "+s"(rowstart[f]));
+  int fj = 0, my_pos = -1, my_l = -1;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) { fj = (lane == k) ? Fd[k] : fj; my_pos = (lane == Fd[k] && k < n_red) ? k : my_pos; }
+#pragma unroll
+  for (int l = 0; l < 12; ++l) my_l = (lane == legd[l] && l < nl) ? l : my_l;
+  if (lane < 32) { S.npv[lane] = (lane < nv) ? g : 0.0; S.xv[lane] = lb; S.yv[lane] = ub; }
+  OCUT(0, g + lb + ub + clb + cub);
+
+  // ---- Householder QR of E' with the coordinates ordered [leg 0, leg 1, .., base]: the reflector of column k = 3 f + r then has
+  // support on leg f's coordinates r..2 and the base only, and what it leaves in the other legs' coordinates of a later column
+  // is part of R (never read again). So every vector is carried as base[6] + cur[3] (its entries at the current leg's
+  // coordinates) whatever its length: lane j < nl = column j of E' (contact row j), lanes 16..33 = the unit vectors, which end up
+  // as the rows of Q — their base part is the row of Z (u_i = Q'e_i, Z = Q[:, nl..nl+5]).
+  double base[6], kown[3];
+  int own_f;
+  {
+    const int f = (lane < 12) ? lane / 3 : 0, rr = (lane < 12) ? lane - 3 * f : 0;
+    int rs = rowstart[0], d0 = legd[0], d1 = legd[1], d2 = legd[2];
+#pragma unroll
+    for (int t = 1; t < 4; ++t) { const bool m = f == t; rs = m ? rowstart[t] : rs; d0 = m ? legd[3 * t] : d0; d1 = m ? legd[3 * t + 1] : d1; d2 = m ? legd[3 * t + 2] : d2; }
+    const double* row = Cm + (rs + rr) * LDJ;
+    const bool col = lane < nl;
+    const int ui = lane - 16;                    // unit vector index (0..5 base, 6 + l leg coordinate l)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) base[i] = col ? row[i] : ((ui == i) ? 1.0 : 0.0);
+    kown[0] = col ? row[d0] : 0.0; kown[1] = col ? row[d1] : 0.0; kown[2] = col ? row[d2] : 0.0;
+    own_f = col ? f : -1;
+    if (ui >= 6 && ui < NB) {
+      const int l = ui - 6, lf = l / 3, lt = l - 3 * lf;
+      own_f = lf; kown[0] = (lt == 0) ? 1.0 : 0.0; kown[1] = (lt == 1) ? 1.0 : 0.0; kown[2] = (lt == 2) ? 1.0 : 0.0;
+    }
+  }
+  double c0 = fma(kown[0], kown[0], fma(kown[1], kown[1], kown[2] * kown[2]));
+#pragma unroll
+  for (int i = 0; i < 6; ++i) c0 = fma(base[i], base[i], c0);
+  bool dependent = false;
+#pragma unroll 1
+  for (int f = 0; f < nelim; ++f) {
+    double cur[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) cur[t] = (own_f == f) ? kown[t] : 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double* const Vb = Vm + ((r & 1) ? 16 : 0);  // two slots: the next step's store does not wait for this step's reads
+      // |x|^2 of the column from its pivot entry down, in three partial sums (the chain through the 12 steps is what this costs)
+      double sa = base[0] * base[0], sb_ = base[1] * base[1], sc_ = base[2] * base[2];
+      sa = fma(base[3], base[3], sa); sb_ = fma(base[4], base[4], sb_); sc_ = fma(base[5], base[5], sc_);
+      if (r <= 0) sa = fma(cur[0], cur[0], sa);
+      if (r <= 1) sb_ = fma(cur[1], cur[1], sb_);
+      sc_ = fma(cur[2], cur[2], sc_);
+      const double sig = (sa + sb_) + sc_;
+      const double ek = cur[r];
+      // sqrt and 1 / den from the hardware estimates + Newton steps (v_rsq_f64 / v_rcp_f64 are good to ~2^-24; the IEEE sqrt and
+      // division sequences are three times as long, and only this lane's reflector depends on them: any beta within a few ulp
+      // leaves Q orthogonal to working precision)
+      double rs = __builtin_amdgcn_rsq(sig);
+      rs = rs * fma(-0.5 * sig * rs, rs, 1.5); rs = rs * fma(-0.5 * sig * rs, rs, 1.5);
+      const double nrm = (sig > 0.0) ? sig * rs : 0.0;
+      const double alpha = (ek > 0.0) ? -nrm : nrm;
+      const double den = fma(-alpha, ek, sig);   // v'v / 2
+      double rd = __builtin_amdgcn_rcp(den);
+      rd = rd * fma(-den, rd, 2.0); rd = rd * fma(-den, rd, 2.0);
+      if (lane == 3 * f + r) {
+        dependent = dependent || !(sig > A.sing_tol * A.sing_tol * c0);
+        sts2(Vb + 0, base[0], base[1]); sts2(Vb + 2, base[2], base[3]); sts2(Vb + 4, base[4], base[5]);
+        sts2(Vb + 6, (r == 0) ? ek - alpha : 0.0, (r == 1) ? ek - alpha : ((r < 1) ? cur[1] : 0.0));
+        sts2(Vb + 8, (r == 2) ? ek - alpha : cur[2], (den > 0.0) ? rd : 0.0);
+      }
+      WSYNC();
+      const double2a v01 = lds2(Vb + 0), v23 = lds2(Vb + 2), v45 = lds2(Vb + 4), l01 = lds2(Vb + 6), l2b = lds2(Vb + 8);
+      const double vb[6] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y}, vl[3] = {l01.x, l01.y, l2b.x};
+      double wa = vb[0] * base[0], wb = vb[1] * base[1], wc = vb[2] * base[2];
+      wa = fma(vb[3], base[3], wa); wb = fma(vb[4], base[4], wb); wc = fma(vb[5], base[5], wc);
+      if (r <= 0) wa = fma(vl[0], cur[0], wa);
+      if (r <= 1) wb = fma(vl[1], cur[1], wb);
+      wc = fma(vl[2], cur[2], wc);
+      const double w = ((wa + wb) + wc) * l2b.y;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) base[i] = fma(-w, vb[i], base[i]);
+#pragma unroll
+      for (int t = r; t < 3; ++t) cur[t] = fma(-w, vl[t], cur[t]);
+    }
+  }
+  if (__ballot(dependent)) return false;
+  if (lane >= 16 && lane < 16 + NB) {
+#pragma unroll
+    for (int c = 0; c < 6; c += 2) sts2(Zm + (lane - 16) * 6 + c, base[c], base[c + 1]);
+  }
+  WSYNC();
+  STAMP(ts, T_P1);
+  OCUT(1, base[0] + base[5]);
+  // ---- T = H(:, bl) Z: lane d + 32 h carries T[d][3 h .. 3 h + 2]
+  {
+    const int d = lane & 31, h = lane >> 5, dd = (d < NV) ? d : NV - 1;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int dj = (j < 6) ? j : legd[j - 6];  // (rows of Z beyond 6 + nl are zero: whatever H entry they meet)
+      const double hv = S.RA[dd * LDJ + dj];
+      const double* zr = Zm + j * 6 + 3 * h;
+      t0 = fma(hv, zr[0], t0); t1 = fma(hv, zr[1], t1); t2 = fma(hv, zr[2], t2);
+      if (j % 6 == 5) __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler hoists every LDS read of the unrolled loop: 250+ VGPRs)
+    }
+    if (d < NV) { double* o = Tm + d * 6 + 3 * h; o[0] = t0; o[1] = t1; o[2] = t2; }
+  }
+  WSYNC();
+  // base block of H' = Z'T(bl, :): one entry per lane (36 lanes; on the six base lanes alone the 108 FMAs + their LDS reads cost
+  // the variant 90 spilled VGPRs)
+  if (lane < 36) {
+    const int c = lane / 6, k = lane - 6 * c;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; j += 2) {
+      a0 = fma(Zm[j * 6 + c], Tm[((j < 6) ? j : legd[j - 6]) * 6 + k], a0);
+      a1 = fma(Zm[(j + 1) * 6 + c], Tm[((j + 1 < 6) ? j + 1 : legd[j - 5]) * 6 + k], a1);
+    }
+    Bm[lane] = a0 + a1;
+  }
+  // per-lane column of Z (lanes >= 6: zero), kept for g' and C'
+  double zcol[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) zcol[j] = (lane < 6) ? Zm[j * 6 + lane] : 0.0;
+  // g' = Z'g
+  double g_red = (lane >= 6 && lane < n_red) ? S.npv[fj] : 0.0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) g_red = fma(zcol[j], S.npv[(j < 6) ? j : legd[j - 6]], g_red);
+  STAMP(ts, T_P2);
+  OCUT(2, g_red + zcol[3]);
+  // ---- C' = C Z for the rows that stay (in their order), then the base / stance-leg velocity bounds as the rows of Z
+  double nclb = 0.0, ncub = 0.0;
+  int i2 = 0;
+#pragma unroll 1
+  for (int i = 0; i < p; ++i) {
+    if ((elimrows >> i) & 1u) continue;
+    double v = (lane >= 6 && lane < n_red) ? Cm[i * LDJ + fj] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v = fma(zcol[j], Cm[i * LDJ + j], v);
+    if ((legrows >> i) & 1u) {
+#pragma unroll
+      for (int l = 0; l < 12; ++l) v = fma(zcol[6 + l], Cm[i * LDJ + legd[l]], v);
+    }
+    const double bl = rdl(clb, i), bu = rdl(cub, i);
+    WSYNC();
+    if (lane < NV) Cm[i2 * LDJ + lane] = v;
+    if (lane == i2) { nclb = bl; ncub = bu; }
+    WSYNC();
+    ++i2;
+  }
+  if (cfg.use_bounds) {
+    const int nb = 6 + nl;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (j < nb) { if (lane < NV) Cm[(i2 + j) * LDJ + lane] = zcol[j]; }
+    }
+    const int jj = lane - i2;
+    if (jj >= 0 && jj < nb) {
+      int dj = jj;
+#pragma unroll
+      for (int l = 0; l < 12; ++l) dj = (jj == 6 + l) ? legd[l] : dj;
+      nclb = S.xv[dj]; ncub = S.yv[dj];
+    }
+    i2 += nb;
+  }
+  const double lb_red = (lane < 6) ? -1e30 : ((lane < n_red) ? S.xv[fj] : 0.0);
+  const double ub_red = (lane < 6) ? 1e30 : ((lane < n_red) ? S.yv[fj] : 0.0);
+  WSYNC();
+  STAMP(ts, T_P3);
+  OCUT(3, g_red + lb_red + ub_red + nclb + ncub);
+  // ---- row `lane` of H' (lanes < n_red), identity padding up to NR
+  double hr[NR];
+  {
+    // (every lane reads through ONE address per entry, chosen by selects: with the loads inside per-lane branches the 16 entries
+    //  became 40 serialized LDS round trips)
+    const int fjc = (lane < n_red) ? fj : 0;
+    const double* const trow = (lane < 6) ? (Bm + lane * 6) : (Tm + fjc * 6);
+    const double2a ta = lds2(trow), tb = lds2(trow + 2), tc = lds2(trow + 4);
+    const double tk[6] = {ta.x, ta.y, tb.x, tb.y, tc.x, tc.y};
+    const double* const src = (lane < 6) ? (Tm + lane) : (S.RA + fjc * LDJ);
+    const int mul = (lane < 6) ? 6 : 1;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const double v = (k < 6) ? tk[k] : src[Fd[k] * mul];
+      hr[k] = (lane < n_red && k < n_red) ? v : ((k == lane) ? 1.0 : 0.0);
+    }
+  }
+  OCUT(4, hr[0] + hr[3] + hr[7] + hr[15] + g_red + lb_red + ub_red + nclb + ncub);
+  WSYNC();
+  for (int k = lane; k < NV * LDJ; k += 64) S.RA[k] = 0.0;
+  WSYNC();
+  if (lane < NR) {
+#pragma unroll
+    for (int k = 0; k < NR; k += 2) sts2(S.RA + lane * LDJ + k, hr[k], hr[k + 1]);
+  }
+  WSYNC();
+  STAMP(ts, T_PRE);
+  OCUT(5, g_red + lb_red + ub_red + nclb + ncub);
+  res = qp_core<NR>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
+  res.iters += nl + P.nlock;
+  // ---- qd = Z y
+  WSYNC();
+  if (lane < 32) S.xv[lane] = (lane < n_red) ? res.x : 0.0;
+  WSYNC();
+  double x = 0.0;
+  if (lane < 6 || my_l >= 0) {
+    const double* zr = Zm + ((lane < 6) ? lane : 6 + my_l) * 6;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) x = fma(zr[c], S.xv[c], x);
+  } else if (my_pos >= 0) x = S.xv[my_pos];
+  res.x = (lane < nv) ? x : 0.0;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // One instance: FK -> Jacobians -> task stack -> H, g, C, bounds [-> QP -> qdot -> q_next]
 // (inputs already staged in S.in)
 // ------------------------------------------------------------------------------------------------
-template <int MODE, bool WARM = false>
+template <int MODE, bool WARM = false, bool ORTH = false>
 __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
                                                  const DevPlan& P, const LaneConst& lc, const InRegs& inr, const int b,
                                                  const int lane, const unsigned long long t_entry = 0) {
@@ -1631,7 +1890,8 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
 #ifdef WBC_PROFILE
   ts[T_PRE] = 0;
 #endif
-  if (!contact_presolve(S, A, M, cfg, P, dpost, g, lb, ub, clb, cub, lane, ts, res)) {
+  if (!contact_presolve(S, A, M, cfg, P, dpost, g, lb, ub, clb, cub, lane, ts, res) &&
+      !(ORTH && contact_presolve_orth(S, A, M, cfg, P, g, lb, ub, clb, cub, lane, ts, res))) {
     // warm start in the problem's own indexing: lane d <-> bound of DoF d, lane i <-> constraint row i
     const unsigned long long w0 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b] : 0ull, w1 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b + 1] : 0ull;
     const int sb = (lane < 32) ? (int)(((w0 >> lane) & 1ull) | (((w0 >> (32 + lane)) & 1ull) << 1)) : 0;
@@ -1685,7 +1945,9 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
 // grid-stride loop whose exit, b >= B, every wave reaches).
 // ------------------------------------------------------------------------------------------------
 // WARM: the variant that reads / writes working sets (warm start, KernelArgs.ws_in / ws_out); the cold variant carries none of it
-template <int MODE, bool WARM = false>
+// ORTH: the variant that carries contact_presolve_orth (chosen by launch_tick when a plan of the batch asks for it: the other
+// variants keep their register allocation — with the extra code inlined the general kernel went from 198 VGPRs to 256 + spills)
+template <int MODE, bool WARM = false, bool ORTH = false>
 __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                          const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   // models / cfgs are separate __restrict__ const parameters so that the compiler may read them with scalar loads
@@ -1712,7 +1974,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
   const LaneConst lc = load_lane_const(models[mid], cfgs[mid], lane);   // L1/L2-resident 3 KB table
   stage_inputs(S, cur, lane, has2, has3);
   WSYNC();
-  process_instance<MODE, WARM>(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane, t_entry);
+  process_instance<MODE, WARM, ORTH>(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane, t_entry);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3510,6 +3772,7 @@ static int check_launch(const char* what) {
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (mode == MODE_TICK && (a.ws_in || a.ws_out)) hipLaunchKernelGGL((wbc_tick_kernel<MODE_TICK, true>), dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
+  else if (mode == MODE_TICK && a.presolve && a.presolve_orth == 2) hipLaunchKernelGGL((wbc_tick_kernel<MODE_TICK, false, true>), dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
   else if (mode == MODE_TICK) hipLaunchKernelGGL(wbc_tick_kernel<MODE_TICK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
   else if (mode == MODE_ASSEMBLE) hipLaunchKernelGGL(wbc_tick_kernel<MODE_ASSEMBLE>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
   else hipLaunchKernelGGL(wbc_tick_kernel<MODE_FK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);

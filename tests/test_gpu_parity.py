@@ -277,6 +277,43 @@ def test_contact_presolve_and_general_path_agree(wx200, px100, cfg_name):
     bt.close()
 
 
+@pytest.mark.parametrize("cfg_name,with_rot", [("c2", False), ("everything", True), ("c2_three_feet", False)])
+def test_orthonormal_contact_presolve_matches_the_oracle(wx200, px100, cfg_name, with_rot):
+    """Configurations whose tasks touch the stance legs (BASELINE configs[1], "everything"): the contact equalities are eliminated
+    through an orthonormal null-space basis (option presolve_orth, default on) — same status and q̇ as the oracle's
+    full-size solve, same as the general path, on both morphologies; `iters` keeps counting the eliminated equalities."""
+    B = 1024
+    models = [wx200, px100]
+    base = "c2" if cfg_name == "c2_three_feet" else cfg_name
+    cfgs = [common.config(base, m) for m in models]
+    if cfg_name == "c2_three_feet":          # RR in swing: its contact rows and its foot task go, its leg stays a free variable
+        for c in cfgs:
+            c.con_ee[2] = 0
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=81 + i, with_rot=with_rot) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    got = bt.tick(d, DT, want_q_next=True)
+    assert bt.stat("last_path") == 0 and bt.stat("last_orth") == 1
+    bt.set_option("presolve_orth", 0)
+    gen = bt.tick(d, DT, want_q_next=True)
+    assert bt.stat("last_orth") == 0
+    ok = ref["status"] == 0
+    assert ok.mean() > 0.9
+    assert (got["status"] == ref["status"]).all() and (gen["status"] == ref["status"]).all()
+    e_o, e_g = np.abs(got["qdot"] - ref["qdot"])[ok].max(), np.abs(gen["qdot"] - ref["qdot"])[ok].max()
+    print("%s: orthonormal presolve err %.3e (iters %.2f), general path err %.3e (iters %.2f), oracle iters %.2f" % (
+        cfg_name, e_o, got["iters"][ok].mean(), e_g, gen["iters"][ok].mean(), ref["iters"][ok].mean()))
+    assert e_o < QDOT_TOL and e_g < QDOT_TOL
+    assert np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    assert abs(got["iters"][ok].mean() - ref["iters"][ok].mean()) < 1.01      # (the oracle counts the px100's padded DoF as one more fixed bound)
+    bt.close()
+
+
 def _leg_block_ratio(a):
     """min over the four stance feet of |det K| / (sum |K_ij|)^3 per instance, K = the foot's 3 x 3 leg block of its WORLD-frame
     contact rows (constraint rows 4.. of the sim3 switch set; FR, FL, RR, RL own DoF 9-11, 6-8, 15-17, 12-14)."""

@@ -13,14 +13,18 @@ from wbc_batch import WbcBatch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 mfma = len(sys.argv) > 2 and sys.argv[2] == "mfma"
 model = wbc_model.load_model("a1_wx200")
-cfg = wbc_model.sim3_config(model)
+cfg = {"c2": wbc_model.equality_only_config, "sim3": wbc_model.sim3_config}[os.environ.get("WBC_CFG", "sim3")](model)   # WBC_CFG=c2: BASELINE configs[1]
 bt = WbcBatch(model, B)
 assert b"PROFILE" in bt.lib.wbc_version(), "set WBC_HIP_LIB to the profile build"
 bt.configure(cfg)
 bt.set_option("jtj_mfma", int(mfma))
-if os.environ.get("WBC_PRESOLVE") is not None:
-    bt.set_option("presolve", int(os.environ["WBC_PRESOLVE"]))
-fk = lambda q: bt.fk(q, want=("oMf",))["oMf"]
+for opt in ("presolve", "presolve_orth", "sim3_kernel"):
+    if os.environ.get("WBC_" + opt.upper()) is not None:
+        bt.set_option(opt, int(os.environ["WBC_" + opt.upper()]))
+class _Fk:
+    def __call__(self, q): return bt.fk(q, want=("oMf",))["oMf"]
+    def com(self, q): return bt.fk(q, want=("com",))["com"]
+fk = _Fk()
 d = wbc_workload.make_tick_inputs(model, cfg, B, 0, fk)
 dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d.items()}
 bt.debug_cycles()          # arm + reset

@@ -8,8 +8,11 @@ import numpy as np, torch, common, wbc_model
 from wbc_batch import WbcBatch
 wx, px = common.models()
 dev = torch.device("cuda", 0)
+only = sys.argv[1:]          # optional: configuration names to time (default: all)
 for name, B, mixed in (("c2", 1024, False), ("c2", 4096, False), ("c2", 65536, False), ("c3", 1024, False), ("c3", 4096, False), ("c3", 65536, False),
                        ("c3", 65536, True), ("everything", 65536, False), ("full", 65536, False), ("hybrid_grip_com", 65536, False)):
+    if only and name not in only:
+        continue
     models = [wx, px] if mixed else [wx]
     cfgs = [common.config(name, m) for m in models]
     bt = WbcBatch(models, B)
