@@ -1295,7 +1295,7 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
 //     kept rows C' = C Z;  the velocity bounds of the base and stance-leg DoF become the 6 + 3 nelim rows of Z (two-sided),
 //     the other DoF keep their simple bounds;  qd = Z y.
 // Same minimiser as the full problem (tests compare against the oracle's full solve). Returns false (general path) only when two
-// contact rows are numerically dependent.  LDS: Householder broadcast RB[0..32), T = H(:, bl) Z at RB[32..188), Z'T at RB[188..224),
+// contact rows are numerically dependent.  LDS: T = H(:, bl) Z at RB[32..188), Z'T at RB[188..224),
 // Z at RB[16 LDJ ..)
 // (rows >= 16 of RB are never touched by qp_core<16>).
 // ------------------------------------------------------------------------------------------------
@@ -1312,7 +1312,6 @@ __device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs&
   const int nv = M.nv, p = A.prows;
   const int nelim = P.nelim, n_red = P.n_red, nl = 3 * nelim;
   constexpr int NB = 18;                         // base + stance-leg coordinates: j < 6 base DoF j, 6 + l eliminated leg DoF l
-  double* const Vm = S.RB;                       // Householder vector broadcast (two slots of 10)
   double* const Tm = S.RB + 32;                  // [26][6]  H(:, bl) Z
   double* const Bm = S.RB + 32 + NV * 6;         // [6][6]   Z'H(bl, bl) Z, the base block of H'
   double* const Zm = S.RB + NR * LDJ;            // [NB][6]
@@ -1374,40 +1373,40 @@ __device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs&
     for (int t = 0; t < 3; ++t) cur[t] = (own_f == f) ? kown[t] : 0.0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      double* const Vb = Vm + ((r & 1) ? 16 : 0);  // two slots: the next step's store does not wait for this step's reads
-      // |x|^2 of the column from its pivot entry down, in three partial sums (the chain through the 12 steps is what this costs)
+      // every lane forms "its" reflector (branch-free); the pivot lane's is the one that counts and is read out of its registers
+      // with v_readlane (the pivot lane index is wave-uniform) — no LDS round trip inside the 12-step chain (measured against the
+      // LDS broadcast: 2 % of the C2 tick)
+      const int pl = 3 * f + r;
       double sa = base[0] * base[0], sb_ = base[1] * base[1], sc_ = base[2] * base[2];
       sa = fma(base[3], base[3], sa); sb_ = fma(base[4], base[4], sb_); sc_ = fma(base[5], base[5], sc_);
       if (r <= 0) sa = fma(cur[0], cur[0], sa);
       if (r <= 1) sb_ = fma(cur[1], cur[1], sb_);
       sc_ = fma(cur[2], cur[2], sc_);
-      const double sig = (sa + sb_) + sc_;
+      const double sig = (sa + sb_) + sc_;       // |x|^2 of the column from its pivot entry down
       const double ek = cur[r];
-      // sqrt and 1 / den from the hardware estimates + Newton steps (v_rsq_f64 / v_rcp_f64 are good to ~2^-24; the IEEE sqrt and
-      // division sequences are three times as long, and only this lane's reflector depends on them: any beta within a few ulp
-      // leaves Q orthogonal to working precision)
+      // v_rsq_f64 / v_rcp_f64 are good to ~2^-24: one Newton step each leaves beta within ~1e-14 of 2 / v'v and Q orthogonal to
+      // that (the IEEE sqrt and division sequences are four times as long)
       double rs = __builtin_amdgcn_rsq(sig);
-      rs = rs * fma(-0.5 * sig * rs, rs, 1.5); rs = rs * fma(-0.5 * sig * rs, rs, 1.5);
+      rs = rs * fma(-0.5 * sig * rs, rs, 1.5);
       const double nrm = (sig > 0.0) ? sig * rs : 0.0;
       const double alpha = (ek > 0.0) ? -nrm : nrm;
       const double den = fma(-alpha, ek, sig);   // v'v / 2
       double rd = __builtin_amdgcn_rcp(den);
-      rd = rd * fma(-den, rd, 2.0); rd = rd * fma(-den, rd, 2.0);
-      if (lane == 3 * f + r) {
-        dependent = dependent || !(sig > A.sing_tol * A.sing_tol * c0);
-        sts2(Vb + 0, base[0], base[1]); sts2(Vb + 2, base[2], base[3]); sts2(Vb + 4, base[4], base[5]);
-        sts2(Vb + 6, (r == 0) ? ek - alpha : 0.0, (r == 1) ? ek - alpha : ((r < 1) ? cur[1] : 0.0));
-        sts2(Vb + 8, (r == 2) ? ek - alpha : cur[2], (den > 0.0) ? rd : 0.0);
-      }
-      WSYNC();
-      const double2a v01 = lds2(Vb + 0), v23 = lds2(Vb + 2), v45 = lds2(Vb + 4), l01 = lds2(Vb + 6), l2b = lds2(Vb + 8);
-      const double vb[6] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y}, vl[3] = {l01.x, l01.y, l2b.x};
+      rd = rd * fma(-den, rd, 2.0);
+      if (lane == pl) dependent = dependent || !(sig > A.sing_tol * A.sing_tol * c0);
+      double vb[6], vl[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < 6; ++i) vb[i] = rdl(base[i], pl);
+      vl[r] = rdl(ek - alpha, pl);
+#pragma unroll
+      for (int t = r + 1; t < 3; ++t) vl[t] = rdl(cur[t], pl);
+      const double beta = rdl((den > 0.0) ? rd : 0.0, pl);
       double wa = vb[0] * base[0], wb = vb[1] * base[1], wc = vb[2] * base[2];
       wa = fma(vb[3], base[3], wa); wb = fma(vb[4], base[4], wb); wc = fma(vb[5], base[5], wc);
       if (r <= 0) wa = fma(vl[0], cur[0], wa);
       if (r <= 1) wb = fma(vl[1], cur[1], wb);
       wc = fma(vl[2], cur[2], wc);
-      const double w = ((wa + wb) + wc) * l2b.y;
+      const double w = ((wa + wb) + wc) * beta;
 #pragma unroll
       for (int i = 0; i < 6; ++i) base[i] = fma(-w, vb[i], base[i]);
 #pragma unroll
@@ -1518,8 +1517,7 @@ __device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs&
   }
   OCUT(4, hr[0] + hr[3] + hr[7] + hr[15] + g_red + lb_red + ub_red + nclb + ncub);
   WSYNC();
-  for (int k = lane; k < NV * LDJ; k += 64) S.RA[k] = 0.0;
-  WSYNC();
+  // H' into RA rows / columns < NR — all qp_core<NR> reads of H; what is left of the 26-wide H beside it is finite and never read
   if (lane < NR) {
 #pragma unroll
     for (int k = 0; k < NR; k += 2) sts2(S.RA + lane * LDJ + k, hr[k], hr[k + 1]);
