@@ -787,24 +787,44 @@ def test_rollouts_are_deterministic_and_survive_unsolvable_ticks(wx200):
     bt.close()
 
 
-def test_gpu_solution_against_the_exact_optimum(wx200):
-    """The device's q̇ against the EXACT (rational-arithmetic) optimum of the double-precision QP data it assembled itself:
-    no oracle in between. Both kernels (compact sim3 kernel / general path) must be as close to the truth as the oracle is."""
-    cfg = common.config("c3", wx200)
-    B = 3
-    d = common.tick_inputs(wx200, cfg, B, seed=71)
-    bt = WbcBatch(wx200, B)
+@pytest.mark.parametrize("cfg_name,with_rot,model_name", [("c3", False, "wx200"), ("c3", False, "px100"), ("c2", False, "wx200"),
+                                                          ("everything", True, "wx200"), ("hybrid_grip_com", False, "wx200")])
+def test_gpu_solution_against_the_exact_optimum(wx200, px100, cfg_name, with_rot, model_name):
+    """The device's q̇ against the EXACT (rational-arithmetic) optimum of the double-precision QP data it assembled itself: no oracle
+    in between (tests/common.py exact_optimum: Gaussian elimination in fractions on the active set the answer shows, optimality
+    conditions asserted). Every kernel path the configuration can take — packed / one-instance compact / general with the explicit or
+    the orthonormal contact presolve / general at full size — must be as close to the truth as the oracle is."""
+    model = wx200 if model_name == "wx200" else px100
+    cfg = common.config(cfg_name, model)
+    B = 24
+    d = common.tick_inputs(model, cfg, B, seed=71, with_rot=with_rot)
+    bt = WbcBatch(model, B)
     bt.configure(cfg)
     a = bt.assemble(d, DT)
-    for sim3 in (1, 0):
-        bt.set_option("sim3_kernel", sim3)
-        bt.set_option("presolve", sim3)
+    nv = model.nv
+    exact, worst = {}, {}
+    # (presolve, presolve_orth, sim3_kernel, packed_kernel)
+    for key in ((1, 1, 1, 1), (1, 1, 1, 0), (1, 1, 0, 0), (1, 0, 0, 0), (0, 0, 0, 0)):
+        for name, v in zip(("presolve", "presolve_orth", "sim3_kernel", "packed_kernel"), key):
+            bt.set_option(name, v)
         got = bt.tick(d, DT)
+        path = (bt.stat("last_path"), bt.stat("last_orth"))
         for b in range(B):
-            assert got["status"][b] == 0
-            x = common.exact_optimum(a["H"][b], a["g"][b], a["C"][b], a["lb"][b], a["ub"][b], a["Clb"][b], a["Cub"][b], got["qdot"][b])
-            err = np.abs(got["qdot"][b] - x).max()
-            assert err < 2e-6, (sim3, b, err)
+            if got["status"][b] != 0:
+                continue
+            if b not in exact:
+                exact[b] = common.exact_optimum(a["H"][b][:nv, :nv], a["g"][b][:nv], a["C"][b][:, :nv], a["lb"][b][:nv], a["ub"][b][:nv],
+                                                a["Clb"][b], a["Cub"][b], got["qdot"][b][:nv])
+            err = np.abs(got["qdot"][b][:nv] - exact[b]).max()
+            worst[(key, path)] = max(worst.get((key, path), 0.0), err)
+    print(cfg_name, model_name, {k: "%.2e" % v for k, v in worst.items()}, "%d instances" % len(exact))
+    assert len(exact) >= B - 4
+    assert max(worst.values()) < 5e-6
+    paths = {k[1] for k in worst}
+    if cfg_name == "c3":
+        assert {(2, 0), (1, 0), (0, 0)} <= paths          # packed, one-instance compact, general
+    if cfg_name in ("c2", "everything"):
+        assert {(0, 1), (0, 0)} <= paths                  # orthonormal presolve, full size
     bt.close()
 
 
