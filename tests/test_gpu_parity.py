@@ -669,11 +669,13 @@ def test_rollout_equals_tick_plus_update_state(wx200):
     bt.close()
 
 
-def test_full_size_properties(wx200):
-    """BASELINE's full single-GPU size (B = 65536, config 3): size-independent certificates on every instance
-    (contact rows satisfied, bounds and box rows respected) + oracle parity on a random subsample."""
+@pytest.mark.parametrize("cfg_name", ["c3", "c2"])
+def test_full_size_properties(wx200, cfg_name):
+    """BASELINE's full single-GPU size (B = 65536; config 3 on the packed kernel, config 2's switch set on the general kernel with
+    the orthonormal contact presolve): size-independent certificates on every instance (contact rows satisfied, bounds and box rows
+    respected) + oracle parity on a random subsample."""
     B = 65536
-    cfg = common.config("c3", wx200)
+    cfg = common.config(cfg_name, wx200)
     d = common.tick_inputs(wx200, cfg, B, seed=41)
     bt = WbcBatch(wx200, B)
     bt.configure(cfg)
@@ -684,7 +686,9 @@ def test_full_size_properties(wx200):
     x = got["qdot"]
     Cx = np.einsum("bpn,bn->bp", a["C"], x)
     scale = 1 + np.abs(x).max(axis=1, keepdims=True)
-    assert (np.abs(Cx[:, 4:])[ok] / scale[ok]).max() < 1e-8                     # 12 contact equalities
+    c0 = 4 if cfg_name == "c3" else 0                                            # (config 2 has no trunk box in front of the contact rows)
+    assert (np.abs(Cx[:, c0:])[ok] / scale[ok]).max() < 1e-8                     # 12 contact equalities
+    assert bt.stat("last_path") == (2 if cfg_name == "c3" else 0) and bt.stat("last_orth") == (0 if cfg_name == "c3" else 1)
     assert ((a["Clb"] - Cx)[ok] / scale[ok]).max() < 1e-8 and ((Cx - a["Cub"])[ok] / scale[ok]).max() < 1e-8
     assert ((a["lb"] - x)[ok]).max() < 1e-8 and ((x - a["ub"])[ok]).max() < 1e-8
     rng = np.random.default_rng(0)
