@@ -305,7 +305,7 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          references run on the compact wbc_tick_sim3_kernel (+ a second pass of the general kernel over the
  *                          instances whose leg blocks it could not eliminate); 0: the general kernel does the elimination.
  *   "packed_kernel"    [1] batches of the sim3 switch-set family itself (Grip task or none, trunk box + foot contacts, velocity
- *                          bounds, posture PREV / Tikhonov / static HYBRID; no warm start, no orientation references) run FOUR
+ *                          bounds, posture PREV / Tikhonov / static HYBRID; no warm start; the gripper's orientation reference is honoured) run FOUR
  *                          instances per wavefront (wbc_tick_sim3p_kernel); 0: one instance per wavefront (wbc_tick_sim3_kernel).
  *   "presolve_tol_exp" [7] a stance-leg 3 x 3 block K with |det K| <= 10^-value (sum |K_ij|)^3 is treated as rank deficient: the
  *                          compact kernel eliminates it with column pivoting and keeps one leg velocity + one contact equality

@@ -578,10 +578,17 @@ static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
 // The fused tick on the best kernel for the batch: wbc_tick_sim3_kernel (compact LDS, reduced QP only) when every
 // model's plan is enabled and the problem fits its layout, followed by wbc_tick_deferred_kernel (general path) over
 // the instances it deferred (singular leg block); otherwise the general kernel alone. `a` holds device pointers.
+static bool packed_eligible(const WbcBatch* b, const KernelArgs& a) {
+  bool packed = b->packed_kernel && !a.ws_in && !a.ws_out && !a.in.q_con && !a.in.posture_u &&
+                !b->force_defer && !b->count_pivoted && !(b->dbg_stop > 0 && b->dbg_stop < 100) && !b->dbg_alias;   // (dbg_stop 101.. cuts the packed kernel)
+  for (int i = 0; i < b->n_models && packed; ++i) packed = b->plan_host[i].packed_ok != 0;
+  return packed;
+}
 static bool sim3_eligible(const WbcBatch* b, const KernelArgs& a) {
   if (!b->sim3_kernel || !b->presolve || b->n_models < 1) return false;
   if (b->jtj_mfma > 0) return false;   // forced: the compact kernel has no matrix-core contraction, the option selects the general kernel
-  if (a.in.ee_ref_rot || a.in.com_target || a.in.com_target_vel) return false;
+  if (a.in.com_target || a.in.com_target_vel) return false;
+  if (a.in.ee_ref_rot && !packed_eligible(b, a)) return false;   // orientation references: the packed kernel honours the gripper's, the one-instance compact kernel none
   if (b->prows > WBC_SIM3_MAXP || b->mcart > 12) return false;
   for (int i = 0; i < b->n_models; ++i) {
     const DevPlan& P = b->plan_host[i];
@@ -612,10 +619,7 @@ static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
     a.pivot_count = b->d_defer + 1 + b->max_batch;
     HIP_TRY(hipMemsetAsync(a.pivot_count, 0, sizeof(int32_t), (hipStream_t)stream));
   }
-  bool packed = b->packed_kernel && !a.ws_in && !a.ws_out && !a.in.q_con && !a.in.posture_u &&
-                !b->force_defer && !b->count_pivoted && !(b->dbg_stop > 0 && b->dbg_stop < 100) && !b->dbg_alias;   // (dbg_stop 101.. cuts the packed kernel)
-  for (int i = 0; i < b->n_models && packed; ++i) packed = b->plan_host[i].packed_ok != 0;
-  if (packed) {
+  if (packed_eligible(b, a)) {
     b->last_path = 2;
     if (int e = launch_tick_sim3p(a, stream)) return fail(WBC_E_HIP, "packed sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   } else if (int e = launch_tick_sim3(a, B, stream)) return fail(WBC_E_HIP, "sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));

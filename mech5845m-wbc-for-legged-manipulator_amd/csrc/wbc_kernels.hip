@@ -2982,7 +2982,7 @@ __global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, cons
 //               at a row-dependent lane comes through ds_bpermute, the Cholesky column is broadcast through a per-instance LDS
 //               vector, control flow is per-row predication with the loops running to the slowest of the four instances.
 // Applies to the sim3 switch-set family only (launch_tick_auto): Grip task or none, posture PREV / Tikhonov / static HYBRID, trunk
-// box + foot contacts, velocity bounds on, no CoM rows, no orientation references, nothing warm. Instances with a rank-deficient
+// box + foot contacts, velocity bounds on, no CoM rows, nothing warm (the gripper's orientation reference is honoured). Instances with a rank-deficient
 // leg block go to the compact list and are redone by the one-instance kernels. Same arithmetic per instance as process_sim3.
 // ================================================================================================
 constexpr int PLD = 14;                     // row stride of the matrices (even: rows are 16-byte aligned for ds_read_b128; 7 s mod 16 is a
@@ -3057,6 +3057,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     if (16 + s < 28) V.in[16 + s] = q1;
     if (s < 10) V.in[28 + s] = ex;
     V.cl[s] = 0.0; V.cl[16 + s] = 0.0;
+    if (A.in.ee_ref_rot) {                // the gripper's orientation reference and its previous value (free vectors until the QP)
+      if (s < 9) { V.dv[s] = A.in.ee_ref_rot[(size_t)b * 45 + 36 + s]; V.yv[s] = A.in.ee_prev_rot[(size_t)b * 45 + 36 + s]; }
+    }
   }
   const int nv = M.nv, nq = M.nq, n = P.n_red, nelim = P.nelim, nl = 3 * nelim, p_keep = P.p_keep, p = p_keep + nl;
   const unsigned fl = P.flags;
@@ -3178,9 +3181,20 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     const double* xt = V.in + 28;
     const double* xp = V.in + 31;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {          // calcTargetVelEE3 (:1052-1157) with R* == R*_prev; EndEffectorB2 (:907-910)
+    for (int i = 0; i < 3; ++i) {          // calcTargetVelEE3 (:1052-1157); EndEffectorB2 (:907-910)
       const double br = ((xt[i] - xp[i]) * inv_dt + eG[i] * ((xt[i] - pfe[i]) * inv_dt)) * ee_w;
       g = fma(-a[i], br, g);
+    }
+    if (A.in.ee_ref_rot) {                 // omega = vee(((R* - R*_prev)/dt) R*^T)  (:1125-1128, 1133); zero when the reference rests
+      const double* Rs = V.dv;
+      const double* Rp = V.yv;
+      double D[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) D[i] = (Rs[i] - Rp[i]) * inv_dt;
+      const double w3 = D[6] * Rs[3] + D[7] * Rs[4] + D[8] * Rs[5];   // S[2][1]
+      const double w4 = D[0] * Rs[6] + D[1] * Rs[7] + D[2] * Rs[8];   // S[0][2]
+      const double w5 = D[3] * Rs[0] + D[4] * Rs[1] + D[5] * Rs[2];   // S[1][0]
+      g = fma(-a[3], w3 * ee_w, g); g = fma(-a[4], w4 * ee_w, g); g = fma(-a[5], w5 * ee_w, g);
     }
   }
 #pragma unroll

@@ -277,6 +277,39 @@ def test_contact_presolve_and_general_path_agree(wx200, px100, cfg_name):
     bt.close()
 
 
+def test_packed_kernel_honours_the_grippers_orientation_reference(wx200, px100):
+    """The reference's calcTargetVelEE3 always carries orientation references (RW4:1125-1133) and the RobotModel mirror passes them
+    on every tick: with a MOVING gripper reference (omega != 0) the sim3 switch set still runs on the packed kernel and matches the
+    oracle and the general kernel; the other end effectors' references are ignored (their tasks are off)."""
+    B = 2048
+    models = [wx200, px100]
+    cfgs = [common.config("c3", m) for m in models]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=91 + i, with_rot=True) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
+    still = dict(d)
+    still["ee_prev_rot"] = d["ee_ref_rot"]                       # resting reference: omega = 0
+    ref_still = oracle.tick(models, cfgs, still, DT, B, nthreads=8)
+    ok = ref["status"] == 0
+    assert np.abs(ref["qdot"] - ref_still["qdot"])[ok].max() > 1e-3   # the moving reference does change the answer
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    got = bt.tick(d, DT, want_q_next=True)
+    assert bt.stat("last_path") == 2
+    bt.set_option("sim3_kernel", 0)
+    gen = bt.tick(d, DT, want_q_next=True)
+    assert bt.stat("last_path") == 0
+    assert (got["status"] == ref["status"]).all() and (gen["status"] == ref["status"]).all()
+    e_p, e_g = np.abs(got["qdot"] - ref["qdot"])[ok].max(), np.abs(gen["qdot"] - ref["qdot"])[ok].max()
+    print("gripper orientation reference: packed err %.3e, general err %.3e" % (e_p, e_g))
+    assert e_p < QDOT_TOL and e_g < QDOT_TOL
+    assert np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    bt.close()
+
+
 @pytest.mark.parametrize("cfg_name,with_rot", [("c2", False), ("everything", True), ("c2_three_feet", False)])
 def test_orthonormal_contact_presolve_matches_the_oracle(wx200, px100, cfg_name, with_rot):
     """Configurations whose tasks touch the stance legs (BASELINE configs[1], "everything"): the contact equalities are eliminated
