@@ -307,6 +307,8 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *   "packed_kernel"    [1] batches of the sim3 switch-set family itself (Grip task or none, trunk box + foot contacts, velocity
  *                          bounds, posture PREV / Tikhonov / static HYBRID; no warm start; the gripper's orientation reference is honoured) run FOUR
  *                          instances per wavefront (wbc_tick_sim3p_kernel); 0: one instance per wavefront (wbc_tick_sim3_kernel).
+ *   "packed_update"    [1] wbc_update_state / the roll-out's state update run four instances per wavefront where every model's
+ *                          configuration is of the packed kernel's family (statistic "last_update_packed"); 0: one per wavefront.
  *   "presolve_tol_exp" [7] a stance-leg 3 x 3 block K with |det K| <= 10^-value (sum |K_ij|)^3 is treated as rank deficient: the
  *                          compact kernel eliminates it with column pivoting and keeps one leg velocity + one contact equality
  *                          in the reduced QP (the general kernel's in-kernel presolve falls back to the full problem).
@@ -329,7 +331,7 @@ int wbc_batch_set_option(WbcBatch* b, const char* name, int value);
 
 /* Read-only statistics of a handle: "last_path" (kernel the last tick ran on: 0 general, 1 compact sim3 + second pass, 2 packed
  * compact sim3 — four instances per wavefront — + second pass), "last_orth" (1: that general-kernel tick ran the variant with the
- * orthonormal contact presolve, option "presolve_orth"),
+ * orthonormal contact presolve, option "presolve_orth"), "last_update_packed" (1: the last state update ran on the packed kernel),
  * "deferred_last" (instances the last sim3-kernel tick left to the second pass; waits for `stream`), "pivoted_last" (instances
  * that took the pivoted elimination, with option "count_pivoted"),
  * "sim3_lds_bytes" / "tick_lds_bytes" (LDS per instance of the two tick kernels). */

@@ -50,6 +50,7 @@ struct WbcBatch {
   int packed_kernel;     // 1 (default): eligible batches run four instances per wavefront (wbc_tick_sim3p_kernel)
   int warm_start;        // 1: wbc_rollout carries each instance's working set from tick to tick (default 0: measured slower)
   int32_t* d_defer;      // [1 + max_batch]: count + compact list of the instances the sim3 kernel deferred (lazy)
+  int packed_update, last_update_packed;   // option: wbc_update_packed_kernel where every plan allows it [1]; what the last update ran on
   int last_orth;         // the last general-kernel tick ran the variant with the orthonormal contact presolve
   int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass)
   int max_nj, max_nf;    // FK output strides: the largest model's joint / frame counts
@@ -146,7 +147,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   WbcBatch* b = new (std::nothrow) WbcBatch;
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
-  b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->presolve_orth = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
+  b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->presolve_orth = 1; b->packed_update = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
   b->jtj_mfma = -1; b->warm_start = 0; b->packed_kernel = 1;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
@@ -343,6 +344,10 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
     }
   }
   P->packed_ok = ok ? 1 : 0;
+  bool upd = ok;
+  for (int e = 0; e < 5; ++e) if (M.depth[M.frame_joint[WBC_FR_EE0 + e]] > need_depth) upd = false;
+  if (M.depth[M.frame_joint[WBC_FR_TRUNK]] > need_depth) upd = false;
+  P->pk_update_ok = upd ? 1 : 0;
 }
 
 extern "C" int wbc_batch_configure(WbcBatch* b, int mi, const WbcConfig* cfg) {
@@ -380,6 +385,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!strcmp(name, "jtj_mfma")) { b->jtj_mfma = value < 0 ? -1 : (value ? 1 : 0); return WBC_OK; }
   if (!strcmp(name, "presolve")) { b->presolve = value; return WBC_OK; }
   if (!strcmp(name, "presolve_orth")) { b->presolve_orth = value; return WBC_OK; }
+  if (!strcmp(name, "packed_update")) { b->packed_update = value; return WBC_OK; }
   if (!strcmp(name, "presolve_tol_exp")) { double t = 1.0; for (int i = 0; i < value; ++i) t *= 0.1; b->sing_tol = t; return WBC_OK; }
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
   if (!strcmp(name, "packed_kernel")) { b->packed_kernel = value; return WBC_OK; }
@@ -402,6 +408,7 @@ extern "C" int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, i
   if (!b || !name || !out) return fail(WBC_E_ARG, "wbc_batch_get_stat: null");
   HIP_TRY(hipSetDevice(b->device_id));
   if (!strcmp(name, "last_path")) { *out = b->last_path; return WBC_OK; }
+  if (!strcmp(name, "last_update_packed")) { *out = b->last_update_packed; return WBC_OK; }
   if (!strcmp(name, "last_orth")) { *out = b->last_path == 0 ? b->last_orth : 0; return WBC_OK; }
   if (!strcmp(name, "deferred_last")) {      // waits for `stream`
     *out = 0;
@@ -578,6 +585,13 @@ static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
 // The fused tick on the best kernel for the batch: wbc_tick_sim3_kernel (compact LDS, reduced QP only) when every
 // model's plan is enabled and the problem fits its layout, followed by wbc_tick_deferred_kernel (general path) over
 // the instances it deferred (singular leg block); otherwise the general kernel alone. `a` holds device pointers.
+static int launch_update_auto(WbcBatch* b, UpdateArgs& u, int B, void* stream) {
+  bool packed = b->packed_update != 0;
+  for (int i = 0; i < b->n_models && packed; ++i) packed = b->configured[i] && b->plan_host[i].pk_update_ok != 0;
+  u.plans = b->d_plans;
+  b->last_update_packed = packed;
+  return packed ? launch_update_packed(u, stream) : launch_update(u, B, stream);
+}
 static bool packed_eligible(const WbcBatch* b, const KernelArgs& a) {
   bool packed = b->packed_kernel && !a.ws_in && !a.ws_out && !a.in.q_con && !a.in.posture_u &&
                 !b->force_defer && !b->count_pivoted && !(b->dbg_stop > 0 && b->dbg_stop < 100) && !b->dbg_alias;   // (dbg_stop 101.. cuts the packed kernel)
@@ -729,7 +743,7 @@ extern "C" int wbc_update_state(WbcBatch* b, int B, const double* q_cur, const d
   st.out(&a.q_new, n * WBC_Q_STRIDE);
   if ((rc = st.stage())) return rc;
   (void)alias;
-  if (int e = launch_update(a, B, stream)) return fail(WBC_E_HIP, "update kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (int e = launch_update_auto(b, a, B, stream)) return fail(WBC_E_HIP, "update kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return st.finish();
 }
 
@@ -804,7 +818,7 @@ extern "C" int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, 
     if ((rc = auto_posture(b, a, B, stream))) return rc;
     if ((rc = launch_tick_auto(b, a, B, stream))) return rc;
     u.grip_trace = ro.grip_trace ? ro.grip_trace + (size_t)k * n * 3 : nullptr;
-    if (int e = launch_update(u, B, stream)) return fail(WBC_E_HIP, "update kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (int e = launch_update_auto(b, u, B, stream)) return fail(WBC_E_HIP, "update kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   }
   if (ro.q_final) HIP_TRY(hipMemcpyAsync(ro.q_final, blk(O_Q), n * 27 * sizeof(double), hipMemcpyDeviceToDevice, s));
   if (ro.qdot_last) HIP_TRY(hipMemcpyAsync(ro.qdot_last, blk(O_QD), n * 26 * sizeof(double), hipMemcpyDeviceToDevice, s));

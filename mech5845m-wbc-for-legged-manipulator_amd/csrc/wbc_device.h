@@ -39,7 +39,7 @@ struct DevPlan {
   int32_t nlock;                     // DoF locked at 0 by the velocity box (>= lock_from, use_bounds): left out of the reduced problem
   int32_t packed_ok;                 // the packed kernel (four instances per wavefront) can run this (model, configuration)
   int32_t orth;                      // tasks touch the stance legs: contact elimination through an orthonormal null-space basis (contact_presolve_orth)
-  int32_t pad_[1];
+  int32_t pk_update_ok;              // the packed FK schedule reaches every frame wbc_update_packed_kernel reads, and no trunk task is on
   // packed kernel (wbc_tick_sim3p_kernel): everything a lane needs, one record per role, so that no load depends on another
   struct PkJoint { int32_t joint, parent, a0, a1, a2, rev, q_idx, pad_; double t0, t1, t2; };   // a*: 3 x column of the axis / its successors in R
   struct PkCol { int32_t dof, joint, lin, ang, dq_idx, pad_[3]; double d_lo, d_hi, d_vm; };       // Jacobian column + velocity-damper entries of a DoF
@@ -127,6 +127,7 @@ struct PostureArgs {
 struct UpdateArgs {
   const DevModel* models;
   const WbcConfig* cfgs;
+  const DevPlan* plans;
   int32_t B, n_models;
   int32_t mode, pad_;                  // WBC_ROLLOUT_RUNNING: IMU fed back + trunkWorldPos; WBC_ROLLOUT_WARMUP: q_new = q_next as it is
   const double *q_cur, *q_next, *imu, *foot_targets;
@@ -150,6 +151,7 @@ int launch_qp(const QpArgs& a, int grid, void* stream);
 int launch_integrate(const IntegrateArgs& a, int grid, void* stream);
 int launch_posture(const PostureArgs& a, int grid, void* stream);
 int launch_update(const UpdateArgs& a, int grid, void* stream);
+int launch_update_packed(const UpdateArgs& a, void* stream);   // four instances per wavefront (every plan pk_update_ok)
 int tick_lds_bytes();
 
 }  // namespace wbc

@@ -3775,6 +3775,157 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wbc_update_kernel for four instances per wavefront (same lane layout and FK records as the packed tick kernel): the one-instance
+// kernel spends a whole wave's instruction stream on one 22-joint FK; in a roll-out that was a third of the closed-loop tick.
+// Used when every plan of the batch is DevPlan.pk_update_ok (the packed FK schedule reaches every frame the estimator reads).
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) UInst {
+  double oMi[24 * 12];
+  double q[32];
+  double sc[64];
+  double pf[6 * 4];                         // feet 0..3, trunk, gripper: world positions
+  double ft[16];
+};
+struct __attribute__((aligned(16))) USmemP { UInst I[4]; };
+__global__ void __launch_bounds__(64) wbc_update_packed_kernel(const UpdateArgs A, const DevModel* __restrict__ models,
+                                                               const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
+  __shared__ USmemP UP;
+  const int lane = threadIdx.x, r = lane >> 4, s = lane & 15;
+  UInst& U = UP.I[r];
+  const int b_raw = 4 * blockIdx.x + r;
+  const bool valid = b_raw < A.B;
+  const size_t b = valid ? b_raw : A.B - 1;
+  int mid = 0;
+  if (A.model_id) { mid = A.model_id[b]; mid = mid < 0 ? 0 : (mid >= A.n_models ? A.n_models - 1 : mid); }
+  const DevModel& M = models[mid];
+  const WbcConfig& cfg = cfgs[mid];
+  const DevPlan& P = plans[mid];
+  const int nq = M.nq;
+  const bool warm = A.mode == WBC_ROLLOUT_WARMUP;
+  // ---- every global read first. config = [current base xyz, base_config (IMU quaternion), new joint angles]  (:388-389)
+  double c0, c1 = 0.0;
+  if (warm) c0 = A.q_next[b * NQ + s];
+  else if (s < 3) c0 = A.q_cur[b * NQ + s];
+  else if (s < 7) c0 = A.imu ? A.imu[b * 4 + (s - 3)] : A.q_next[b * NQ + s];
+  else c0 = A.q_next[b * NQ + s];
+  if (16 + s < nq) c1 = A.q_next[b * NQ + 16 + s];
+  const double ft = (s < 12) ? A.foot_targets[b * 15 + s] : 0.0;
+  const double eet = (A.ee_target && s < 15) ? A.ee_target[b * 15 + s] : 0.0;
+  const double ees = (A.ee_target && A.ee_step && s < 15) ? A.ee_step[b * 15 + s] : 0.0;
+  double rref[3] = {0.0, 0.0, 0.0};
+  if (A.ee_prev_rot && A.ee_ref_rot) {
+#pragma unroll
+    for (int h = 0; h < 3; ++h) if (16 * h + s < 45) rref[h] = A.ee_ref_rot[b * 45 + 16 * h + s];
+  }
+  const double tt = (A.trunk_target && s < 3) ? A.trunk_target[b * 3 + s] : 0.0;
+  const double tts = (A.trunk_target && A.trunk_step && s < 3) ? A.trunk_step[b * 3 + s] : 0.0;
+  int st = 0, stm = 0, it = 0, its = 0;
+  if (s == 0) {
+    if (A.status_max) { st = A.status[b]; stm = A.status_max[b]; }
+    if (A.iters_sum) { it = A.iters[b]; its = A.iters_sum[b]; }
+  }
+  DevPlan::PkJoint fkn = P.pk_fk[0][s];
+  const int scq0 = P.pk_scq[(2 + s) & 31], scq1 = P.pk_scq[(18 + s) & 31];
+  // frame of this lane: feet 0..3, trunk, gripper
+  const int fr = (s < 4) ? WBC_FR_EE0 + s : ((s == 4) ? WBC_FR_TRUNK : WBC_FR_EE0 + 4);
+  const int fjoint = M.frame_joint[fr];
+  const double f0 = M.frame_p[fr][0], f1 = M.frame_p[fr][1], f2 = M.frame_p[fr][2];
+  const int tjoint = M.frame_joint[WBC_FR_TRUNK];
+  U.q[s] = c0; U.q[16 + s] = c1;
+  if (s < 12) U.ft[s] = ft;
+  WSYNC();
+  const double* const qv = U.q;
+  double* const oMi = U.oMi;
+  if (scq0 >= 0) { const SinCos t = sincos_cw(qv[scq0]); U.sc[2 * (2 + s)] = t.s; U.sc[2 * (2 + s) + 1] = t.c; }
+  if (scq1 >= 0) { const SinCos t = sincos_cw(qv[scq1]); U.sc[2 * (18 + s)] = t.s; U.sc[2 * (18 + s) + 1] = t.c; }
+  if (s == 0) {
+    double Rt[9];
+    quat_to_R(qv + 3, Rt);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) oMi[12 + 3 * c + rr] = Rt[3 * rr + c];
+    oMi[12 + 9] = qv[0]; oMi[12 + 10] = qv[1]; oMi[12 + 11] = qv[2];
+  }
+  WSYNC();
+#pragma unroll 1
+  for (int L = 0; L < 5; ++L) {             // the packed tick kernel's FK, record for record
+    const DevPlan::PkJoint fk = fkn;
+    if (L + 1 < 5) fkn = P.pk_fk[L + 1][s];
+    const int j = fk.joint;
+    if (j >= 0) {
+      const bool rev = fk.rev != 0;
+      const int a0 = fk.a0, a1 = fk.a1, a2 = fk.a2;
+      const double* Pp = oMi + 12 * fk.parent;
+      const double sn = rev ? U.sc[2 * j] : 0.0, cs = rev ? U.sc[2 * j + 1] : 1.0;
+      const double pris = rev ? 0.0 : qv[fk.q_idx];
+      double Av[3], Bv[3], Cv[3], Pv[3];
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) { Av[rr] = Pp[a0 + rr]; Bv[rr] = Pp[a1 + rr]; Cv[rr] = Pp[a2 + rr]; Pv[rr] = Pp[9 + rr]; }
+      double* Po = oMi + 12 * j;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        Po[a0 + rr] = Av[rr];
+        Po[a1 + rr] = cs * Bv[rr] + sn * Cv[rr];
+        Po[a2 + rr] = cs * Cv[rr] - sn * Bv[rr];
+        Po[9 + rr] = Pv[rr] + Av[rr] * (fk.t0 + pris) + Bv[rr] * fk.t1 + Cv[rr] * fk.t2;
+      }
+    }
+    WSYNC();
+  }
+  if (s < 6) {
+    const double* Pj = oMi + 12 * fjoint;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) U.pf[4 * s + rr] = Pj[9 + rr] + Pj[rr] * f0 + Pj[3 + rr] * f1 + Pj[6 + rr] * f2;
+  }
+  WSYNC();
+  // trunkWorldPos: trunk_pos = WPA - WRB . BPA  (:1321-1325), evaluated by every lane of the instance
+  const double* Pt = oMi + 12 * tjoint;     // R column-major
+  double WPA[3], BPA[3], base[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double t = U.pf[4 * 4 + i];
+    WPA[i] = (U.ft[i] + U.ft[3 + i] + U.ft[6 + i] + U.ft[9 + i]) / 4;
+    BPA[i] = ((U.pf[i] - t) + (U.pf[4 + i] - t) + (U.pf[8 + i] - t) + (U.pf[12 + i] - t)) / 4;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr) base[rr] = WPA[rr] - (Pt[rr] * BPA[0] + Pt[3 + rr] * BPA[1] + Pt[6 + rr] * BPA[2]);
+  if (warm) { base[0] = qv[0]; base[1] = qv[1]; base[2] = qv[2]; }   // no estimator while warming up (running == False, :414)
+  if (!valid) return;
+  {
+    double* qo = A.q_new + b * NQ;
+    qo[s] = (s == 0) ? base[0] : (s == 1) ? base[1] : (s == 2) ? base[2] : c0;
+    if (16 + s < NQ) qo[16 + s] = (16 + s < nq) ? c1 : 0.0;
+  }
+  if (A.grip_trace && s < 3) {
+    const double d = (s == 0) ? base[0] - qv[0] : (s == 1) ? base[1] - qv[1] : base[2] - qv[2];
+    A.grip_trace[b * 3 + s] = U.pf[4 * 5 + s] + d;
+  }
+  if (s == 0) {
+    if (A.status_max && st > stm) A.status_max[b] = st;
+    if (A.iters_sum) A.iters_sum[b] = its + it;
+  }
+  // ---- side effects of qpb() on the reference state, then the targets move on (as wbc_update_kernel)
+  if (A.ee_target && s < 15) {
+    const int e = s / 3;
+    if (cfg.task_ee[e] && A.prev_ee_target) A.prev_ee_target[b * 15 + s] = eet;       // prev_EE_pos[i] = target (:1151)
+    if (A.ee_step) A.ee_target[b * 15 + s] = eet + ees;
+  }
+  if (A.ee_prev_rot && A.ee_ref_rot) {
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+      const int i = 16 * h + s;
+      if (i < 45 && cfg.task_ee[i / 9]) A.ee_prev_rot[b * 45 + i] = rref[h];          // prev_EE_CoM_rot[i] = R* (:1152)
+    }
+  }
+  if (A.trunk_target && s < 3) {
+    if (cfg.task_trunk && A.prev_trunk_target) A.prev_trunk_target[b * 3 + s] = tt;   // prev_trunk_ref = target (:995)
+    if (A.trunk_step) A.trunk_target[b * 3 + s] = tt + tts;
+  }
+  // (old_ref_trunk_rot_matrix, :996, only moves with the trunk task on — which pk_update_ok excludes)
+}
+
 static int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   (void)what;
@@ -3789,6 +3940,10 @@ int launch_tick(const KernelArgs& a, int mode, int grid, void* stream) {
   else if (mode == MODE_ASSEMBLE) hipLaunchKernelGGL(wbc_tick_kernel<MODE_ASSEMBLE>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
   else hipLaunchKernelGGL(wbc_tick_kernel<MODE_FK>, dim3(grid), dim3(64), 0, s, a, a.models, a.cfgs, a.plans);
   return check_launch("tick");
+}
+int launch_update_packed(const UpdateArgs& a, void* stream) {
+  hipLaunchKernelGGL(wbc_update_packed_kernel, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  return check_launch("update_packed");
 }
 int launch_tick_sim3(const KernelArgs& a, int grid, void* stream) {
   if (a.ws_in || a.ws_out) hipLaunchKernelGGL(wbc_tick_sim3_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);

@@ -625,11 +625,14 @@ def test_update_state_parity(wx200, px100):
     bt = WbcBatch(models, B)
     for i, m in enumerate(models):
         bt.configure(common.config("c3", m), i)
-    for im in (imu, None):
-        ref = oracle.update_state(models, q_cur, q_next, targets, im, mid)
-        got = bt.update_state(q_cur, q_next, targets, im, mid)
-        assert np.abs(got - ref).max() < 1e-13
-        assert (got[:, 3:] == ref[:, 3:]).all()
+    for packed in (1, 0):                    # four instances per wavefront (the sim3 family's plans allow it) / one per wavefront
+        bt.set_option("packed_update", packed)
+        for im in (imu, None):
+            ref = oracle.update_state(models, q_cur, q_next, targets, im, mid)
+            got = bt.update_state(q_cur, q_next, targets, im, mid)
+            assert bt.stat("last_update_packed") == packed
+            assert np.abs(got - ref).max() < 1e-13
+            assert (got[:, 3:] == ref[:, 3:]).all()
     bt.close()
 
 
