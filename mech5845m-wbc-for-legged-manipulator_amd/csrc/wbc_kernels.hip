@@ -3087,6 +3087,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   const double joint_w = cfg.joint_w, tb_z = cfg.trunk_box_z_frac, tb_a = cfg.trunk_box_ang, tb_s = cfg.trunk_box_scale;
   WSYNC();
   const double* const qv = V.in;
+  PSTOP(6, qv[s] + dlo0 + dlo1 + eW[0] + (double)(fkn.joint + scq0 + scq1));
 
   // ---- sin / cos of the joint angles: joint j (>= 2) reads q[idx_q[j]]; two joints per lane
   double* const oMi = I.M1;                 // [22][12], runs on into M2
@@ -3106,6 +3107,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     }
   }
   WSYNC();
+  PSTOP(7, oMi[12 + s] + sc[4 + s]);
   // ---- P1: pin.forwardKinematics, level by level (Robot_Wrapper4.py:400). The level's joint and its constants are fetched
   // inside the loop (L1-resident tables): kept live for all five levels they cost 60 VGPRs
 #pragma unroll 1

@@ -45,12 +45,12 @@ for k in (1, 2, 3, 4, 5, 6, 7, 0):
     res[names[k]] = {"stop": k, "cumulative_ms": t, "stage_ms": t - prev}
     prev = t
     print("stop %d  %-40s cumulative %.4f ms  stage %.4f ms" % (k, names[k], t, res[names[k]]["stage_ms"]), flush=True)
-# the packed kernel (four instances per wavefront): cuts 101..105
+# the packed kernel (four instances per wavefront): cuts 106, 107, 101..105
 bt.set_option("packed_kernel", 1)
-pnames = {101: "loads + sin/cos + FK", 102: "columns + task rows + H' rows", 103: "constraint rows + bounds + G + g' + G'G",
+pnames = {106: "inputs + plan records staged", 107: "sin/cos + root placement", 101: "FK levels", 102: "columns + task rows + H' rows", 103: "constraint rows + bounds + G + g' + G'G",
           104: "Cholesky + substitutions", 105: "J store + x0", 0: "dual iterations + x = Z y + output"}
 pres, prev = {}, 0.0
-for k in (101, 102, 103, 104, 105, 0):
+for k in (106, 107, 101, 102, 103, 104, 105, 0):
     bt.set_option("dbg_stop", k)
     for _ in range(3):
         step()
