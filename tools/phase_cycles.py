@@ -13,7 +13,13 @@ from wbc_batch import WbcBatch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 mfma = len(sys.argv) > 2 and sys.argv[2] == "mfma"
 model = wbc_model.load_model("a1_wx200")
-cfg = {"c2": wbc_model.equality_only_config, "sim3": wbc_model.sim3_config}[os.environ.get("WBC_CFG", "sim3")](model)   # WBC_CFG=c2: BASELINE configs[1]
+_name = os.environ.get("WBC_CFG", "sim3")          # WBC_CFG=c2: BASELINE configs[1]; full / everything / ...: tests/common.py's named configurations
+if _name in ("sim3", "c2"):
+    cfg = {"c2": wbc_model.equality_only_config, "sim3": wbc_model.sim3_config}[_name](model)
+else:
+    sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+    import common
+    cfg = common.config(_name, model)
 bt = WbcBatch(model, B)
 assert b"PROFILE" in bt.lib.wbc_version(), "set WBC_HIP_LIB to the profile build"
 bt.configure(cfg)
@@ -25,7 +31,10 @@ class _Fk:
     def __call__(self, q): return bt.fk(q, want=("oMf",))["oMf"]
     def com(self, q): return bt.fk(q, want=("com",))["com"]
 fk = _Fk()
-d = wbc_workload.make_tick_inputs(model, cfg, B, 0, fk)
+if _name in ("full", "everything"):
+    d = common.tick_inputs(model, cfg, B, 0, with_rot=True)
+else:
+    d = wbc_workload.make_tick_inputs(model, cfg, B, 0, fk)
 dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d.items()}
 bt.debug_cycles()          # arm + reset
 for _ in range(3):
