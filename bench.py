@@ -191,6 +191,46 @@ class GpuEngine:
                 "worst_status_histogram": {name: int((st == code).sum()) for code, name in enumerate(("optimal", "max_iter", "infeasible", "numerical"))},
                 "optimal_frac": float((st == 0).mean()), "iters_per_tick": float(ro["iters"].double().mean().item()) / ticks}
 
+    def other_configs(self):
+        """Context for the headline (not bench lines): BASELINE configs[1] (five EE tasks + CoM task, contact equalities, no
+        velocity box) at its own batch 1024 and at 65536, on the general kernel with the orthonormal contact presolve."""
+        import wbc_model
+        import wbc_workload
+        from wbc_batch import WbcBatch
+        t = self.torch
+        out = {}
+        cfg = wbc_model.equality_only_config(self.model)
+        for B in (1024, 65536):
+            bt = WbcBatch(self.model, B, device_id=self.dev.index)
+            bt.configure(cfg)
+
+            class FK:
+                def __call__(_, q):
+                    return bt.fk(q, want=("oMf",))["oMf"]
+
+                def com(_, q):
+                    return bt.fk(q, want=("com",))["com"]
+            d = wbc_workload.make_tick_inputs(self.model, cfg, B, 5, FK())
+            dev_in = {k: t.from_numpy(np.ascontiguousarray(v)).to(self.dev) for k, v in d.items()}
+            dev_out = dict(qdot=t.zeros((B, 26), dtype=t.float64, device=self.dev), status=t.zeros(B, dtype=t.int32, device=self.dev),
+                           iters=t.zeros(B, dtype=t.int32, device=self.dev))
+            step = bt.make_tick_call(dev_in, dev_out, DT)
+            for _ in range(3):
+                step()
+            self.sync()
+            ev0, ev1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(10):
+                step()
+            ev1.record()
+            self.sync()
+            ms = ev0.elapsed_time(ev1) / 10
+            out["c2_B%d" % B] = {"ticks_per_s": B / ms * 1e3, "ms_per_step": ms, "task_rows": bt.task_rows, "constraint_rows": bt.constraint_rows,
+                                 "optimal_frac": float((dev_out["status"] == 0).double().mean().item()),
+                                 "kernel_path": "wbc_tick_kernel<MODE_TICK, ORTH>" if bt.stat("last_orth") else "wbc_tick_kernel<MODE_TICK>"}
+            bt.close()
+        return out
+
     def close(self):
         self.bt.close()
 
@@ -335,6 +375,8 @@ def main(argv=None):
             line["closed_loop_unstressed"] = dict(engine.closed_loop(make_inputs(engine, args.batch, seed=rank, stress=False), args.rollout_ticks),
                                                   unit="closed-loop ticks/s per GPU", ticks=args.rollout_ticks,
                                                   inputs="same distribution without the stress recipe")
+        if args.rollout_ticks > 0 and world == 1:
+            line["configs"] = engine.other_configs()
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             ok = cpu_baseline_and_accuracy(line, engine, engine.host_in, res, args)
         print(json.dumps(line), flush=True)
