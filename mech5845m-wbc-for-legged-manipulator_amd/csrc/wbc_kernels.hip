@@ -3677,12 +3677,14 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         z = fma(j2.x, y2.x, z); zb = fma(j2.y, y2.y, zb);
       }
       z += zb;
+      if (__ballot(stepping && q > 0)) {      // r = T d1: nothing to do while no row of the wave holds an active inequality
 #pragma unroll
-      for (int k = 0; k < PV; k += 2) {
-        const double2a t2 = lds2(T + srd * PLD + k); const double2a d2 = lds2(V.dv + k);
-        rv = fma(t2.x, d2.x, rv); rvb = fma(t2.y, d2.y, rvb);
+        for (int k = 0; k < PV; k += 2) {
+          const double2a t2 = lds2(T + srd * PLD + k); const double2a d2 = lds2(V.dv + k);
+          rv = fma(t2.x, d2.x, rv); rvb = fma(t2.y, d2.y, rvb);
+        }
+        rv += rvb;
       }
-      rv += rvb;
       if (s >= q) rv = 0.0;
       if (!has_b) z = 0.0;
       const bool have_step = zn > 100.0 * n * EPS2 * jf2 * np2;
