@@ -223,3 +223,84 @@ def test_warm_started_variant_reaches_the_same_optimum():
         assert s4 == 0 and np.abs(x4 - xr).max() < 1e-8 and sorted(ws4) == sorted(ws0)
     assert cold_it > 0
     print("working-set changes: cold %d, seeded with the own set %d, with the previous tick's set %+d vs cold" % (cold_it, warm_it, warm_prev_it))
+
+
+def _householder_null_basis_leg_first(E_base, K_blocks):
+    """The device's construction (contact_presolve_orth) restated: Householder QR of E' with the coordinates ordered
+    [leg 0, .., leg f-1, base]; every vector carried as (its entries at the CURRENT leg's coordinates, its base part) only — what a
+    reflector leaves in other legs' coordinates of a later column is part of R and never read again. Returns Z [(6 + 3 f) x 6] in the
+    order [base; leg 0; ..] whose columns span null([B K])."""
+    nf = len(K_blocks)
+    # vectors: the 3 nf columns of E' (contact rows), then the 6 + 3 nf unit vectors (-> rows of Q)
+    vecs = []
+    for f in range(nf):
+        for r in range(3):
+            vecs.append(dict(base=E_base[f][r].astype(float).copy(), own=f, kown=K_blocks[f][r].astype(float).copy()))
+    for i in range(6):
+        vecs.append(dict(base=np.eye(6)[i].copy(), own=-1, kown=np.zeros(3)))
+    for f in range(nf):
+        for t in range(3):
+            vecs.append(dict(base=np.zeros(6), own=f, kown=np.eye(3)[t].copy()))
+    for f in range(nf):
+        cur = [v["kown"].copy() if v["own"] == f else np.zeros(3) for v in vecs]
+        for r in range(3):
+            piv = 3 * f + r
+            x = np.concatenate([vecs[piv]["base"], cur[piv][r:]])
+            sig = x @ x
+            ek = cur[piv][r]
+            alpha = -np.sqrt(sig) if ek > 0 else np.sqrt(sig)
+            vb, vl = vecs[piv]["base"].copy(), np.zeros(3)
+            vl[r] = ek - alpha
+            vl[r + 1:] = cur[piv][r + 1:]
+            beta = 1.0 / (sig - alpha * ek)
+            for j, v in enumerate(vecs):
+                w = beta * (vb @ v["base"] + vl[r:] @ cur[j][r:])
+                v["base"] = v["base"] - w * vb
+                cur[j][r:] = cur[j][r:] - w * vl[r:]
+    return np.array([v["base"] for v in vecs[3 * nf:]])
+
+
+def test_orthonormal_contact_presolve_restated_in_numpy():
+    """Host-side statement of what wbc_tick_kernel<.., ORTH> does for configurations whose tasks touch the stance legs (BASELINE
+    configs[1], "everything"): Z from the leg-first Householder QR is an orthonormal basis of the contact rows' null space, the
+    reduced QP (H' = Z'HZ, bound rows = rows of Z) has cond(H') <= cond(H) and the same minimiser as the full problem — while the
+    explicit basis [I; -K^-1 B] the sim3 presolve uses is orders of magnitude worse conditioned here."""
+    wx, _ = common.models()
+    for name, B, rot in (("c2", 24, False), ("everything", 12, True)):
+        cfg = common.config(name, wx)
+        d = common.tick_inputs(wx, cfg, B, seed=5, with_rot=rot)
+        qp = oracle.assemble([wx], [cfg], d, DT, B)
+        x_ref, st, it = oracle.qp_solve(qp["H"], qp["g"], qp["C"], qp["lb"], qp["ub"], qp["Clb"], qp["Cub"])
+        worse = []
+        for b in np.nonzero(st == 0)[0]:
+            H, g, Cm, lb, ub, cl, cu = (qp[k][b] for k in ("H", "g", "C", "lb", "ub", "Clb", "Cub"))
+            eq = [i for i in range(Cm.shape[0]) if cl[i] == cu[i] == 0.0 and np.any(Cm[i, 6:18] != 0)]
+            assert len(eq) == 12
+            feet = [eq[3 * f:3 * f + 3] for f in range(4)]
+            legd = [[j for j in range(6, 18) if Cm[rows[0], j] != 0 or Cm[rows[1], j] != 0 or Cm[rows[2], j] != 0] for rows in feet]
+            assert all(len(l) == 3 for l in legd)
+            Zbl = _householder_null_basis_leg_first([Cm[rows][:, :6] for rows in feet], [Cm[np.ix_(rows, l)] for rows, l in zip(feet, legd)])
+            bl = list(range(6)) + [j for l in legd for j in l]
+            E = Cm[np.ix_(eq, bl)]
+            assert np.abs(E @ Zbl).max() < 1e-12 * np.abs(E).max() * 10 and np.abs(Zbl.T @ Zbl - np.eye(6)).max() < 1e-13
+            locked = [j for j in range(26) if lb[j] == ub[j] == 0.0]
+            rest = [j for j in range(26) if j not in bl and j not in locked]
+            Z = np.zeros((26, 6 + len(rest)))
+            Z[np.ix_(bl, range(6))] = Zbl
+            for k, j in enumerate(rest):
+                Z[j, 6 + k] = 1.0
+            keep = [i for i in range(Cm.shape[0]) if i not in eq]
+            Hr = Z.T @ H @ Z
+            y, s2, _ = oracle.qp_solve(Hr, Z.T @ g, np.vstack([Cm[keep] @ Z, Z[bl]]),
+                                       np.concatenate([np.full(6, -1e30), lb[rest]]), np.concatenate([np.full(6, 1e30), ub[rest]]),
+                                       np.concatenate([cl[keep], lb[bl]]), np.concatenate([cu[keep], ub[bl]]))
+            assert s2 == 0
+            assert np.abs(Z @ y - x_ref[b]).max() < 1e-6
+            Hfree = H[np.ix_([j for j in range(26) if j not in locked], [j for j in range(26) if j not in locked])]
+            assert np.linalg.cond(Hr) <= 1.0001 * np.linalg.cond(Hfree)
+            # the explicit basis, for the record
+            G = np.vstack([-np.linalg.solve(Cm[np.ix_(rows, l)], Cm[rows][:, :6]) for rows, l in zip(feet, legd)])
+            Ze = Z.copy()
+            Ze[np.ix_(bl, range(6))] = np.vstack([np.eye(6), G])
+            worse.append(np.linalg.cond(Ze.T @ H @ Ze) / np.linalg.cond(Hr))
+        assert np.median(worse) > 30, np.median(worse)
