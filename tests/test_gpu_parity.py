@@ -608,11 +608,12 @@ def test_integrate_parity(wx200):
     bt.close()
 
 
-def test_update_state_parity(wx200, px100):
-    """The tail of runWBC: updateState(running=True) + trunkWorldPos (Robot_Wrapper4.py:387-428, 1297-1327)."""
+@pytest.mark.parametrize("B", [512, 5, 63])
+def test_update_state_parity(wx200, px100, B):
+    """The tail of runWBC: updateState(running=True) + trunkWorldPos (Robot_Wrapper4.py:387-428, 1297-1327); batch sizes that do
+    not fill the last wavefront of the four-instances-per-wave kernel included."""
     import wbc_workload
     rng = np.random.default_rng(13)
-    B = 512
     models = [wx200, px100]
     mid = (np.arange(B) % 2).astype(np.int32)
     qa = [wbc_workload.sample_q(m, B, rng) for m in models]
