@@ -1299,45 +1299,13 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
 // Z at RB[16 LDJ ..)
 // (rows >= 16 of RB are never touched by qp_core<16>).
 // ------------------------------------------------------------------------------------------------
-#ifdef ORTH_CUT   // timing cuts (variant builds only: make variant VFLAGS=-DORTH_CUT=k): the presolve returns after stage k with garbage
-#define OCUT(k, val) do { if (ORTH_CUT == (k)) { res.x = (val); res.status = 0; res.iters = 0; res.ws_b = res.ws_r = 0; return true; } } while (0)
-#else
-#define OCUT(k, val) do { } while (0)
-#endif
-__device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
-                                                      const DevPlan& P, const double g, const double lb, const double ub,
-                                                      const double clb, const double cub, const int lane,
-                                                      unsigned long long* ts, QpResult& res) {
-  if (!A.presolve || !A.presolve_orth || !P.orth) return false;
-  const int nv = M.nv, p = A.prows;
-  const int nelim = P.nelim, n_red = P.n_red, nl = 3 * nelim;
-  constexpr int NB = 18;                         // base + stance-leg coordinates: j < 6 base DoF j, 6 + l eliminated leg DoF l
-  double* const Tm = S.RB + 32;                  // [26][6]  H(:, bl) Z
-  double* const Bm = S.RB + 32 + NV * 6;         // [6][6]   Z'H(bl, bl) Z, the base block of H'
-  double* const Zm = S.RB + NR * LDJ;            // [NB][6]
-  double* const Cm = S.RC;
-  int legd[12], Fd[NR], rowstart[4];
-#pragma unroll
-  for (int l = 0; l < 12; ++l) legd[l] = P.legd[l];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) Fd[k] = P.Fd[k];
-#pragma unroll
-  for (int f = 0; f < 4; ++f) rowstart[f] = P.rowstart[f];
-  const unsigned elimrows = P.elimrows, legrows = P.legrows;
-#pragma unroll
-  for (int l = 0; l < 12; ++l) asm volatile("" : "+s"(legd[l]));
-#pragma unroll
-  for (int k = 0; k < NR; ++k) asm volatile("" : "+s"(Fd[k]));
-#pragma unroll
-  for (int f = 0; f < 4; ++f) asm volatile("" : "+s"(rowstart[f]));
-  int fj = 0, my_pos = -1, my_l = -1;
-#pragma unroll
-  for (int k = 0; k < NR; ++k) { fj = (lane == k) ? Fd[k] : fj; my_pos = (lane == Fd[k] && k < n_red) ? k : my_pos; }
-#pragma unroll
-  for (int l = 0; l < 12; ++l) my_l = (lane == legd[l] && l < nl) ? l : my_l;
-  if (lane < 32) { S.npv[lane] = (lane < nv) ? g : 0.0; S.xv[lane] = lb; S.yv[lane] = ub; }
-  OCUT(0, g + lb + ub + clb + cub);
-
+// Householder QR of E' (the stance feet's contact rows over [base; stance legs]) -> Z, an orthonormal basis of their null space, one row
+// per lane 16 .. 33 written to Zm [18][6] (rows: base DoF 0..5, then eliminated leg DoF l). `rows` + rs[f] * LDJ is the first of
+// foot f's three rows (26-wide, as the constraint stage writes them). Returns false when two rows are numerically dependent.
+__device__ __forceinline__ bool orth_qr_z(const double* const rows, const int (&rowstart)[4], const int (&legd)[12], const int nelim,
+                                          const int nl, const int lane, const double sing_tol, double* const Zm) {
+  constexpr int NB = 18;
+  const double* const Cm = rows;
   // ---- Householder QR of E' with the coordinates ordered [leg 0, leg 1, .., base]: the reflector of column k = 3 f + r then has
   // support on leg f's coordinates r..2 and the base only, and what it leaves in the other legs' coordinates of a later column
   // is part of R (never read again). So every vector is carried as base[6] + cur[3] (its entries at the current leg's
@@ -1393,7 +1361,7 @@ __device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs&
       const double den = fma(-alpha, ek, sig);   // v'v / 2
       double rd = __builtin_amdgcn_rcp(den);
       rd = rd * fma(-den, rd, 2.0);
-      if (lane == pl) dependent = dependent || !(sig > A.sing_tol * A.sing_tol * c0);
+      if (lane == pl) dependent = dependent || !(sig > sing_tol * sing_tol * c0);
       double vb[6], vl[3] = {0.0, 0.0, 0.0};
 #pragma unroll
       for (int i = 0; i < 6; ++i) vb[i] = rdl(base[i], pl);
@@ -1419,10 +1387,54 @@ __device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs&
     for (int c = 0; c < 6; c += 2) sts2(Zm + (lane - 16) * 6 + c, base[c], base[c + 1]);
   }
   WSYNC();
+  return true;
+}
+
+#ifdef ORTH_CUT   // timing cuts (variant builds only: make variant VFLAGS=-DORTH_CUT=k): the presolve returns after stage k with garbage
+#define OCUT(k, val) do { if (ORTH_CUT == (k)) { res.x = (val); res.status = 0; res.iters = 0; res.ws_b = res.ws_r = 0; return true; } } while (0)
+#else
+#define OCUT(k, val) do { } while (0)
+#endif
+__device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
+                                                      const DevPlan& P, const double g, const double lb, const double ub,
+                                                      const double clb, const double cub, const int lane,
+                                                      unsigned long long* ts, QpResult& res, const bool have_h = false) {
+  // have_h: orth_direct_assemble has been there: Z and H' are in place (no 26-wide H exists)
+  if (!have_h && (!A.presolve || !A.presolve_orth || !P.orth)) return false;
+  const int nv = M.nv, p = A.prows;
+  const int nelim = P.nelim, n_red = P.n_red, nl = 3 * nelim;
+  constexpr int NB = 18;                         // base + stance-leg coordinates: j < 6 base DoF j, 6 + l eliminated leg DoF l
+  double* const Tm = S.RB + 32;                  // [26][6]  H(:, bl) Z
+  double* const Bm = S.RB + 32 + NV * 6;         // [6][6]   Z'H(bl, bl) Z, the base block of H'
+  double* const Zm = S.RB + NR * LDJ;            // [NB][6]
+  double* const Cm = S.RC;
+  int legd[12], Fd[NR], rowstart[4];
+#pragma unroll
+  for (int l = 0; l < 12; ++l) legd[l] = P.legd[l];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) Fd[k] = P.Fd[k];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) rowstart[f] = P.rowstart[f];
+  const unsigned elimrows = P.elimrows, legrows = P.legrows;
+#pragma unroll
+  for (int l = 0; l < 12; ++l) asm volatile("" : "+s"(legd[l]));
+#pragma unroll
+  for (int k = 0; k < NR; ++k) asm volatile("" : "+s"(Fd[k]));
+#pragma unroll
+  for (int f = 0; f < 4; ++f) asm volatile("" : "+s"(rowstart[f]));
+  int fj = 0, my_pos = -1, my_l = -1;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) { fj = (lane == k) ? Fd[k] : fj; my_pos = (lane == Fd[k] && k < n_red) ? k : my_pos; }
+#pragma unroll
+  for (int l = 0; l < 12; ++l) my_l = (lane == legd[l] && l < nl) ? l : my_l;
+  if (lane < 32) { S.npv[lane] = (lane < nv) ? g : 0.0; S.xv[lane] = lb; S.yv[lane] = ub; }
+  OCUT(0, g + lb + ub + clb + cub);
+
+  if (!have_h && !orth_qr_z(Cm, rowstart, legd, nelim, nl, lane, A.sing_tol, Zm)) return false;
   STAMP(ts, T_P1);
-  OCUT(1, base[0] + base[5]);
+  OCUT(1, Zm[lane & 63]);
   // ---- T = H(:, bl) Z: lane d + 32 h carries T[d][3 h .. 3 h + 2]
-  {
+  if (!have_h) {
     const int d = lane & 31, h = lane >> 5, dd = (d < NV) ? d : NV - 1;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
 #pragma unroll
@@ -1438,7 +1450,7 @@ __device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs&
   WSYNC();
   // base block of H' = Z'T(bl, :): one entry per lane (36 lanes; on the six base lanes alone the 108 FMAs + their LDS reads cost
   // the variant 90 spilled VGPRs)
-  if (lane < 36) {
+  if (!have_h && lane < 36) {
     const int c = lane / 6, k = lane - 6 * c;
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -1499,6 +1511,7 @@ __device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs&
   STAMP(ts, T_P3);
   OCUT(3, g_red + lb_red + ub_red + nclb + ncub);
   // ---- row `lane` of H' (lanes < n_red), identity padding up to NR
+  if (!have_h) {
   double hr[NR];
   {
     // (every lane reads through ONE address per entry, chosen by selects: with the loads inside per-lane branches the 16 entries
@@ -1523,6 +1536,7 @@ __device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs&
     for (int k = 0; k < NR; k += 2) sts2(S.RA + lane * LDJ + k, hr[k], hr[k + 1]);
   }
   WSYNC();
+  }
   STAMP(ts, T_PRE);
   OCUT(5, g_red + lb_red + ub_red + nclb + ncub);
   res = qp_core<NR>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
@@ -1538,6 +1552,118 @@ __device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs&
     for (int c = 0; c < 6; ++c) x = fma(zr[c], S.xv[c], x);
   } else if (my_pos >= 0) x = S.xv[my_pos];
   res.x = (lane < nv) ? x : 0.0;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The orthonormal presolve without the 26-wide H: right after the task pass (At = the Cartesian task stack by DoF in LDS) the contact
+// rows go through orth_qr_z, A Z is formed for the base block (one Cartesian row per lane), and H' = (A Z)'(A Z) + posture comes out of
+// ONE 16 x 16 tile of the fp64 matrix cores (the full J'J is three tiles and was then reduced by Z'(H Z): 0.15 ms of the C2 step).
+// Leaves H' in RA rows / columns < NR and Z at RB[16 LDJ ..) for contact_presolve_orth(.., have_h = true), which runs after the
+// constraint stage. Only where the constraints are evaluated at the same state as the tasks (no second FK pass). Returns false —
+// RA zeroed again for the general path — when two contact rows are numerically dependent.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool orth_direct_assemble(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
+                                                     const DevPlan& P, const double* const At, const int mtp,
+                                                     const double (&lin)[3], const int lane) {
+  const int nv = M.nv, nelim = P.nelim, nl = 3 * nelim, n_red = P.n_red, mc = A.mcart;
+  constexpr int NB = 18;
+  double* const Esc = S.RA;                      // [12][LDJ] contact rows (dead once the QR has loaded them)
+  double* const AZt = S.RA;                      // [6][mtp]  (A Z)' by reduced base variable (6 mtp <= 300)
+  double* const Zd = S.RA + 12 * LDJ;            // [26][6]   Z by DoF, for the A Z loop
+  double* const Zs = S.RA + 12 * LDJ + NV * 6;   // [18][6]   Z by [base; stance-leg] row until At is dead
+  double* const Zm = S.RB + NR * LDJ;            // ... then where contact_presolve_orth expects it
+  int legd[12], Fd[NR];
+#pragma unroll
+  for (int l = 0; l < 12; ++l) legd[l] = P.legd[l];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) Fd[k] = P.Fd[k];
+#pragma unroll
+  for (int l = 0; l < 12; ++l) asm volatile("" : "+s"(legd[l]));
+#pragma unroll
+  for (int k = 0; k < NR; ++k) asm volatile("" : "+s"(Fd[k]));
+  // ---- the stance feet's contact rows (EEConstraint, Robot_Wrapper4.py:757-761), as the constraint stage writes them later
+  {
+    int fi = 0;
+#pragma unroll 1
+    for (unsigned cm_ = P.con_ee_mask & 15u; cm_; cm_ &= cm_ - 1) {
+      const int e = __ffs((int)cm_) - 1;
+      const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_EE0 + e] >> lane) & 1u);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) if (lane < NV) Esc[(3 * fi + r) * LDJ + lane] = sup ? lin[r] : 0.0;
+      ++fi;
+    }
+  }
+  WSYNC();
+  const int rs4[4] = {0, 3, 6, 9};
+  if (!orth_qr_z(Esc, rs4, legd, nelim, nl, lane, A.sing_tol, Zs)) {
+    WSYNC();
+    if (lane < NV) {
+#pragma unroll 1
+      for (int k = 0; k < NV; k += 2) sts2(S.RA + lane * LDJ + k, 0.0, 0.0);
+    }
+    WSYNC();
+    return false;
+  }
+  // ---- Z by DoF (zero rows for the DoF outside base and stance legs): the A Z loop then walks At and Z with plain strides — unrolled over
+  // the [base; legs] index list its 6 accumulators x 18 terms cost the variant 150 spilled VGPRs
+  {
+    int zj = (lane < 6) ? lane : -1;
+#pragma unroll
+    for (int l = 0; l < 12; ++l) zj = (lane == legd[l] && l < nl) ? 6 + l : zj;
+    if (lane < NV) {
+      const double* zr = Zs + ((zj >= 0) ? zj : 0) * 6;
+      const double2a z0 = lds2(zr), z1 = lds2(zr + 2), z2 = lds2(zr + 4);
+      const bool on = zj >= 0;
+      sts2(Zd + lane * 6, on ? z0.x : 0.0, on ? z0.y : 0.0); sts2(Zd + lane * 6 + 2, on ? z1.x : 0.0, on ? z1.y : 0.0);
+      sts2(Zd + lane * 6 + 4, on ? z2.x : 0.0, on ? z2.y : 0.0);
+    }
+  }
+  WSYNC();
+  // ---- (A Z)[r][c] for the six base variables: lane = Cartesian task row r
+  {
+    const double* ap = At + ((lane < mc) ? lane : 0);
+    const double* zp = Zd;
+    double az[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+    for (int d = 0; d < NV; ++d) {
+      const double a = *ap;
+      const double2a z0 = lds2(zp), z1 = lds2(zp + 2), z2 = lds2(zp + 4);
+      az[0] = fma(a, z0.x, az[0]); az[1] = fma(a, z0.y, az[1]); az[2] = fma(a, z1.x, az[2]);
+      az[3] = fma(a, z1.y, az[3]); az[4] = fma(a, z2.x, az[4]); az[5] = fma(a, z2.y, az[5]);
+      ap += mtp; zp += 6;
+    }
+    if (lane < mc) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) AZt[c * mtp + lane] = az[c];
+    }
+  }
+  WSYNC();
+  // ---- H' = A_red'A_red on the matrix cores, one tile: column c0 of A_red is (A Z)[:, c0] for c0 < 6, else the column of DoF Fd[c0]
+  const int kq = lane >> 4, c0 = lane & 15;
+  int fdc = 0;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) fdc = (c0 == k) ? Fd[k] : fdc;
+  const double* const colp = (c0 < 6) ? (AZt + c0 * mtp) : (At + fdc * mtp);
+  const bool colon = c0 < n_red;
+  v4f64 acc = {0, 0, 0, 0};
+#pragma unroll 1
+  for (int s4 = 0; s4 < mc; s4 += 4) {
+    const int r = s4 + kq;
+    const double a0 = (colon && r < mc) ? colp[r] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc, 0, 0, 0);
+  }
+  WSYNC();                                       // every read of A Z and of At is done: RA rows < NR become H', RB rows >= NR take Z
+  const double dp = cfg.task_joint ? (1.0 / nv) * cfg.joint_w : 0.0;   // posture rows: Z'(d^2 I)Z = d^2 I on the reduced variables
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = kq + 4 * r;
+    double v = acc[r];
+    if (row == c0) v = (row < n_red) ? fma(dp, dp, v) : 1.0;
+    S.RA[row * LDJ + c0] = v;
+  }
+  if (lane < (NB * 6) / 2) sts2(Zm + 2 * lane, Zs[2 * lane], Zs[2 * lane + 1]);
+  WSYNC();
   return true;
 }
 
@@ -1729,8 +1855,13 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
   }
   WSYNC();
   STAMP(ts, T_A1);
-  // pass 2: H[lane][i] = sum_r At[i][r] At[lane][r]
-  if (A.jtj_mfma) {
+  // pass 2: H[lane][i] = sum_r At[i][r] At[lane][r] — or, where the orthonormal contact presolve applies and the constraints are
+  // evaluated at this same state, the reduced H' directly (orth_direct_assemble)
+  bool direct = false;
+  if (ORTH && MODE == MODE_TICK && A.presolve && A.presolve_orth && P.orth && !A.in.q_con && !(A.post_static && P.post_pert))
+    direct = orth_direct_assemble(S, A, M, cfg, P, At, mtp, lin, lane);
+  if (direct) {
+  } else if (A.jtj_mfma) {
     // dense contraction on the fp64 matrix cores (the operand comes straight from the At image in LDS)
     const int mc = A.mcart;
     jtj_mfma(S, lane, mc, [&](int r, int c) -> double { return (r < mc && c < NV) ? At[c * mtp + r] : 0.0; });
@@ -1758,7 +1889,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     if (lane < nv) g = fma(-dpost, bj, g);
     upost = bj;
   }
-  if (lane < NV) S.RA[lane * LDJ + lane] += (lane < nv) ? dpost * dpost : 1.0;   // padded DoF: H_dd = 1
+  if (lane < NV && !direct) S.RA[lane * LDJ + lane] += (lane < nv) ? dpost * dpost : 1.0;   // padded DoF: H_dd = 1
   if (lane >= nv) g = 0.0;
   WSYNC();
 
@@ -1889,7 +2020,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
   ts[T_PRE] = 0;
 #endif
   if (!contact_presolve(S, A, M, cfg, P, dpost, g, lb, ub, clb, cub, lane, ts, res) &&
-      !(ORTH && contact_presolve_orth(S, A, M, cfg, P, g, lb, ub, clb, cub, lane, ts, res))) {
+      !(ORTH && contact_presolve_orth(S, A, M, cfg, P, g, lb, ub, clb, cub, lane, ts, res, direct))) {
     // warm start in the problem's own indexing: lane d <-> bound of DoF d, lane i <-> constraint row i
     const unsigned long long w0 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b] : 0ull, w1 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b + 1] : 0ull;
     const int sb = (lane < 32) ? (int)(((w0 >> lane) & 1ull) | (((w0 >> (32 + lane)) & 1ull) << 1)) : 0;
