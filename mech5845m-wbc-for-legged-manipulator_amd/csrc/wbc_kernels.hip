@@ -1268,7 +1268,8 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
   }
   WSYNC();
   STAMP(ts, T_PRE);
-  res = qp_core<NR>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
+  if (n_red <= 12) res = qp_core<12>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);   // (qp_core's sweeps cost ~NM^2)
+  else res = qp_core<NR>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
   res.iters += nl + P.nlock;                         // the eliminated equalities and the locked DoF, so that `iters` keeps its meaning
   // ---- x = Z y
   WSYNC();
@@ -1539,7 +1540,10 @@ __device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs&
   }
   STAMP(ts, T_PRE);
   OCUT(5, g_red + lb_red + ub_red + nclb + ncub);
-  res = qp_core<NR>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
+  // the reduced problem at its own compiled size (the sweeps of qp_core cost ~NM^2: n' = 11 on a 16-wide core wastes half of them)
+  if (n_red <= 12) res = qp_core<12>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
+  else if (n_red <= 14) res = qp_core<14>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
+  else res = qp_core<NR>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
   res.iters += nl + P.nlock;
   // ---- qd = Z y
   WSYNC();
@@ -2661,8 +2665,11 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
     if (my_orig >= 0) sd_r = (int)(((ws1 >> my_orig) & 1ull) | (((ws1 >> (32 + my_orig)) & 1ull) << 1));
     else if (c_use_bounds && lane >= p_keep && lane < p_keep + nl) sd_r = (int)(((ws0 >> my_legd) & 1ull) | (((ws0 >> (32 + my_legd)) & 1ull) << 1));
   }
-  QpResult res = qp_core<NR, SmemC, CSC, WARM>(S, g_red, lb_red, ub_red, nclb, ncub, n_eff, i2, lane, ts, DBG_STOP_ARG,
-                                               sd_b == 3 ? 0 : sd_b, sd_r == 3 ? 0 : sd_r);
+  QpResult res;
+  if (n_eff <= 12) res = qp_core<12, SmemC, CSC, WARM>(S, g_red, lb_red, ub_red, nclb, ncub, n_eff, i2, lane, ts, DBG_STOP_ARG,
+                                                       sd_b == 3 ? 0 : sd_b, sd_r == 3 ? 0 : sd_r);   // (no pivoted foot: n' = 11 / 10)
+  else res = qp_core<NR, SmemC, CSC, WARM>(S, g_red, lb_red, ub_red, nclb, ncub, n_eff, i2, lane, ts, DBG_STOP_ARG,
+                                           sd_b == 3 ? 0 : sd_b, sd_r == 3 ? 0 : sd_r);
   res.iters += nl - nsing + P.nlock;   // the eliminated equalities and the locked DoF, so that `iters` keeps its meaning
   // ---- x = Z y
   WSYNC();
