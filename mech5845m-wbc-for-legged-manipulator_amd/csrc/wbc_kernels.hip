@@ -2029,6 +2029,23 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     const unsigned long long w0 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b] : 0ull, w1 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b + 1] : 0ull;
     const int sb = (lane < 32) ? (int)(((w0 >> lane) & 1ull) | (((w0 >> (32 + lane)) & 1ull) << 1)) : 0;
     const int sr = (lane < 32) ? (int)(((w1 >> lane) & 1ull) | (((w1 >> (32 + lane)) & 1ull) << 1)) : 0;
+    // The DoF the velocity box locks at 0 (>= lock_from, Robot_Wrapper4.py:627-630) are the LAST ones: they leave the problem (x = 0
+    // contributes to nothing) and the solve runs on a 24-wide core where that fits — the sweeps of qp_core cost ~NM^2. Counted as
+    // working-set changes so that `iters` keeps its meaning.
+    const int ntail = (!WARM && cfg.use_bounds && cfg.lock_from >= 6 && cfg.lock_from < nv) ? nv - cfg.lock_from : 0;
+    const int n_eff = nv - ntail;
+    if (ntail > 0 && n_eff <= 24) {
+      WSYNC();
+#pragma unroll 1
+      for (int k = n_eff; k < 24; ++k) {           // identity padding of H, zero columns of C
+        if (lane < 24) { S.RA[lane * LDJ + k] = (lane == k) ? 1.0 : 0.0; if (lane != k) S.RA[k * LDJ + lane] = 0.0; }
+        if (lane < A.prows) S.RC[lane * LDJ + k] = 0.0;
+      }
+      WSYNC();
+      res = qp_core<24>(S, (lane < n_eff) ? g : 0.0, lb, ub, clb, cub, n_eff, A.prows, lane, ts);
+      res.iters += ntail;
+      if (lane >= n_eff) res.x = 0.0;
+    } else
     res = qp_core<NV, Smem, LDJ, WARM>(S, g, lb, ub, clb, cub, nv, A.prows, lane, ts, 0, sb == 3 ? 0 : sb, sr == 3 ? 0 : sr);
   }
   if (WARM && A.ws_out) {   // (the in-kernel presolve path runs cold and carries nothing: res.ws_* = 0 there)
