@@ -301,6 +301,9 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          configs[1]), through an orthonormal basis of the contact rows' null space (Householder QR per instance):
  *                          the reduced QP is as well conditioned as the full one; the base and stance-leg velocity bounds become
  *                          6 + 3 x (stance feet) two-sided rows. 0: those configurations run at full size. Needs "presolve".
+ *   "orth_qr"          [0] diagnostic: that basis always by the Householder QR of the contact rows; by default only instances with a
+ *                          nearly rank-deficient stance-leg block take it, the others orthonormalise [I; -K^-1 B] through a 6 x 6
+ *                          Cholesky factor (same null space, a quarter of the instructions).
  *   "sim3_kernel"      [1] batches whose every model has such an elimination plan, <= 16 constraint rows and no orientation
  *                          references run on the compact wbc_tick_sim3_kernel (+ a second pass of the general kernel over the
  *                          instances whose leg blocks it could not eliminate); 0: the general kernel does the elimination.

@@ -41,7 +41,7 @@ struct WbcBatch {
   size_t ws_bytes;
   int mrows, prows, mcart;
   int jtj_mfma;
-  int presolve, presolve_orth;
+  int presolve, presolve_orth, orth_qr;
   double sing_tol;
   int sim3_kernel;       // 1 (default): batches that qualify run on wbc_tick_sim3_kernel (compact LDS) + a deferred pass
   int32_t* d_status;     // status buffer of our own when the caller passes none (the deferred pass needs one)
@@ -385,6 +385,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!strcmp(name, "jtj_mfma")) { b->jtj_mfma = value < 0 ? -1 : (value ? 1 : 0); return WBC_OK; }
   if (!strcmp(name, "presolve")) { b->presolve = value; return WBC_OK; }
   if (!strcmp(name, "presolve_orth")) { b->presolve_orth = value; return WBC_OK; }
+  if (!strcmp(name, "orth_qr")) { b->orth_qr = value; return WBC_OK; }
   if (!strcmp(name, "packed_update")) { b->packed_update = value; return WBC_OK; }
   if (!strcmp(name, "presolve_tol_exp")) { double t = 1.0; for (int i = 0; i < value; ++i) t *= 0.1; b->sing_tol = t; return WBC_OK; }
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
@@ -577,7 +578,7 @@ static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
   a.models = b->d_models; a.cfgs = b->d_cfgs; a.plans = b->d_plans; a.n_models = b->n_models;
   // J'J on the matrix cores: forced (1), off (0) or, by default (-1), for wide Cartesian stacks only — measured on MI355X
   // (profiles/r02_mfma_evidence.txt): +9 % ticks/s at 33 and 45 Cartesian rows (config 2, "everything"), a wash at 6 (config 3)
-  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma < 0 ? (b->mcart >= WBC_MFMA_AUTO_ROWS) : b->jtj_mfma; a.presolve = b->presolve; a.presolve_orth = b->presolve_orth ? 1 + any_orth_plan(b) : 0; a.sing_tol = b->sing_tol; a.dbg_alias = b->dbg_alias; a.dt = dt;
+  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma < 0 ? (b->mcart >= WBC_MFMA_AUTO_ROWS) : b->jtj_mfma; a.presolve = b->presolve; a.presolve_orth = b->presolve_orth ? 1 + any_orth_plan(b) : 0; a.orth_qr = b->orth_qr; a.sing_tol = b->sing_tol; a.dbg_alias = b->dbg_alias; a.dt = dt;
   a.prof = b->d_prof; a.dbg_stop = b->dbg_stop;
   a.fk_nj = b->max_nj; a.fk_nf = b->max_nf;
 }

@@ -82,6 +82,7 @@ struct KernelArgs {
   int32_t* pivot_count;             // diagnostic (option "count_pivoted"): instances that took the pivoted elimination; else null
   int32_t dbg_force_defer;          // diagnostic: every instance with a flagged leg block is deferred instead of pivoted
   int32_t presolve_orth;            // the orthonormal contact presolve where DevPlan.orth: 0 off, 1 on, 2 on and a plan of this batch has DevPlan.orth (host)
+  int32_t orth_qr, pad3_;           // diagnostic: the null-space basis always through the Householder QR (else only for flagged leg blocks)
   // warm start: the final working set of the previous tick, [B][2] words in FULL-problem indexing whatever
   // kernel wrote them: word 0 = velocity bounds (bit d: DoF d at its lower bound, bit 32 + d: at its upper bound), word 1 =
   // constraint rows of findConstraints' order (bit i / 32 + i). Either may be null (cold start / nothing carried); they may alias.

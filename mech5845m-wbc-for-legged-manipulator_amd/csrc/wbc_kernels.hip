@@ -1391,6 +1391,122 @@ __device__ __forceinline__ bool orth_qr_z(const double* const rows, const int (&
   return true;
 }
 
+// The same null-space basis without the 12-step QR, for the (usual) stance whose leg blocks are well conditioned: G = -K^-1 B by the
+// adjugate (all feet at once), then Z = [I; G] S with S = L^-T, L L' = I + G'G — the columns of [I; G] orthonormalised through a 6 x 6
+// Cholesky factor instead of through the 18 x 12 Householder sweep (~250 wave-instructions instead of ~1000). What went wrong with the
+// explicit G in round 1 was the missing S (cond(Z'HZ) ~ |G|^2 cond(H)), not G itself: with |G| up to 10^4 the orthogonality error is
+// 4e-9 and the reduced solve is as accurate as the QR's (tests; tools note in DESIGN.md §3.9). Any leg block with
+// |det K| <= 1e-6 (sum |K_ij|)^3 sends the instance to orth_qr_z, for which a rank-deficient K is no special case.
+__device__ __forceinline__ bool orth_null_basis(const double* const rows, const int (&rowstart)[4], const int (&legd)[12], const int nelim,
+                                                const int nl, const int lane, const double sing_tol, double* const Zm, const bool force_qr) {
+  // ---- G (rows 6 + l of Zm for now)
+  bool flagged;
+  {
+    const int f = (lane < 24) ? lane / 6 : 0, c = (lane < 24) ? lane - 6 * f : 0;
+    int d0 = legd[0], d1 = legd[1], d2 = legd[2], rs = rowstart[0];
+#pragma unroll
+    for (int t = 1; t < 4; ++t) { const bool m = f == t; d0 = m ? legd[3 * t] : d0; d1 = m ? legd[3 * t + 1] : d1; d2 = m ? legd[3 * t + 2] : d2; rs = m ? rowstart[t] : rs; }
+    const double* r0 = rows + rs * LDJ; const double* r1 = r0 + LDJ; const double* r2 = r1 + LDJ;
+    const double k00 = r0[d0], k01 = r0[d1], k02 = r0[d2], k10 = r1[d0], k11 = r1[d1], k12 = r1[d2],
+                 k20 = r2[d0], k21 = r2[d1], k22 = r2[d2];
+    const double b0 = r0[c], b1 = r1[c], b2 = r2[c];
+    const double a00 = k11 * k22 - k12 * k21, a01 = k02 * k21 - k01 * k22, a02 = k01 * k12 - k02 * k11;
+    const double a10 = k12 * k20 - k10 * k22, a11 = k00 * k22 - k02 * k20, a12 = k02 * k10 - k00 * k12;
+    const double a20 = k10 * k21 - k11 * k20, a21 = k01 * k20 - k00 * k21, a22 = k00 * k11 - k01 * k10;
+    const double det = k00 * a00 + k01 * a10 + k02 * a20;
+    const double sc = fabs(k00) + fabs(k01) + fabs(k02) + fabs(k10) + fabs(k11) + fabs(k12) + fabs(k20) + fabs(k21) + fabs(k22);
+    const bool live = lane < 6 * nelim;
+    flagged = force_qr || __ballot(live && !(fabs(det) > fmax(1e-6, sing_tol) * sc * sc * sc)) != 0;
+    const double id = -1.0 / det;
+    if (lane < 24) {
+      Zm[(6 + 3 * f + 0) * 6 + c] = live ? id * (a00 * b0 + a01 * b1 + a02 * b2) : 0.0;
+      Zm[(6 + 3 * f + 1) * 6 + c] = live ? id * (a10 * b0 + a11 * b1 + a12 * b2) : 0.0;
+      Zm[(6 + 3 * f + 2) * 6 + c] = live ? id * (a20 * b0 + a21 * b1 + a22 * b2) : 0.0;
+    }
+  }
+  if (flagged) { WSYNC(); return orth_qr_z(rows, rowstart, legd, nelim, nl, lane, sing_tol, Zm); }
+  WSYNC();
+  // ---- M = I + G'G, one entry per lane (rows 0..5 of Zm for now)
+  if (lane < 36) {
+    const int c = lane / 6, k = lane - 6 * c;
+    double m0 = (c == k) ? 1.0 : 0.0, m1 = 0.0;
+#pragma unroll
+    for (int l = 0; l < 12; l += 2) {
+      m0 = fma(Zm[(6 + l) * 6 + c], Zm[(6 + l) * 6 + k], m0);
+      m1 = fma(Zm[(7 + l) * 6 + c], Zm[(7 + l) * 6 + k], m1);
+    }
+    Zm[lane] = m0 + m1;
+  }
+  WSYNC();
+  // ---- L L' = M and Li = L^-1 in registers, the same on every lane (M >= I: no pivot can fail)
+  double Lm[6][6], Li[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double2a a = lds2(Zm + 6 * i), b = lds2(Zm + 6 * i + 2), c = lds2(Zm + 6 * i + 4);
+    Lm[i][0] = a.x; Lm[i][1] = a.y; Lm[i][2] = b.x; Lm[i][3] = b.y; Lm[i][4] = c.x; Lm[i][5] = c.y;
+  }
+  double dinv[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double v = Lm[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) v = fma(-Lm[j][k], Lm[j][k], v);
+    double rs = __builtin_amdgcn_rsq(v);
+    rs = rs * fma(-0.5 * v * rs, rs, 1.5); rs = rs * fma(-0.5 * v * rs, rs, 1.5);
+    dinv[j] = rs;
+    Lm[j][j] = v * rs;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double w = Lm[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) w = fma(-Lm[i][k], Lm[j][k], w);
+      Lm[i][j] = w * rs;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {             // column c of L^-1: L x = e_c
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i < c) Li[i][c] = 0.0;
+      else {
+        double w = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = c; k < i; ++k) w = fma(-Lm[i][k], Li[k][c], w);
+        Li[i][c] = w * dinv[i];
+      }
+    }
+  }
+  WSYNC();                                   // every lane has M: rows 0..5 become S = Li'
+  // ---- Z = [S; G S], S[c][k] = Li[k][c]
+  if (lane < 6) {
+    double srow[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      double v = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v = (lane == c) ? Li[k][c] : v;
+      srow[k] = v;
+    }
+    sts2(Zm + lane * 6, srow[0], srow[1]); sts2(Zm + lane * 6 + 2, srow[2], srow[3]); sts2(Zm + lane * 6 + 4, srow[4], srow[5]);
+  }
+  if (lane >= 16 && lane < 28) {
+    double* zr = Zm + (6 + lane - 16) * 6;
+    const double2a a = lds2(zr), b = lds2(zr + 2), c = lds2(zr + 4);
+    const double gl[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+    double o[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      double v = 0.0;
+#pragma unroll
+      for (int c2 = 0; c2 <= k; ++c2) v = fma(gl[c2], Li[k][c2], v);
+      o[k] = v;
+    }
+    sts2(zr, o[0], o[1]); sts2(zr + 2, o[2], o[3]); sts2(zr + 4, o[4], o[5]);
+  }
+  WSYNC();
+  return true;
+}
+
 #ifdef ORTH_CUT   // timing cuts (variant builds only: make variant VFLAGS=-DORTH_CUT=k): the presolve returns after stage k with garbage
 #define OCUT(k, val) do { if (ORTH_CUT == (k)) { res.x = (val); res.status = 0; res.iters = 0; res.ws_b = res.ws_r = 0; return true; } } while (0)
 #else
@@ -1431,7 +1547,7 @@ __device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs&
   if (lane < 32) { S.npv[lane] = (lane < nv) ? g : 0.0; S.xv[lane] = lb; S.yv[lane] = ub; }
   OCUT(0, g + lb + ub + clb + cub);
 
-  if (!have_h && !orth_qr_z(Cm, rowstart, legd, nelim, nl, lane, A.sing_tol, Zm)) return false;
+  if (!have_h && !orth_null_basis(Cm, rowstart, legd, nelim, nl, lane, A.sing_tol, Zm, A.orth_qr != 0)) return false;
   STAMP(ts, T_P1);
   OCUT(1, Zm[lane & 63]);
   // ---- T = H(:, bl) Z: lane d + 32 h carries T[d][3 h .. 3 h + 2]
@@ -1600,7 +1716,7 @@ __device__ __forceinline__ bool orth_direct_assemble(Smem& S, const KernelArgs& 
   }
   WSYNC();
   const int rs4[4] = {0, 3, 6, 9};
-  if (!orth_qr_z(Esc, rs4, legd, nelim, nl, lane, A.sing_tol, Zs)) {
+  if (!orth_null_basis(Esc, rs4, legd, nelim, nl, lane, A.sing_tol, Zs, A.orth_qr != 0)) {
     WSYNC();
     if (lane < NV) {
 #pragma unroll 1

@@ -332,10 +332,17 @@ def test_orthonormal_contact_presolve_matches_the_oracle(wx200, px100, cfg_name,
         bt.configure(c, i)
     got = bt.tick(d, DT, want_q_next=True)
     assert bt.stat("last_path") == 0 and bt.stat("last_orth") == 1
+    bt.set_option("orth_qr", 1)              # the basis through the Householder QR for every instance (by default: flagged leg blocks only)
+    qr = bt.tick(d, DT, want_q_next=True)
+    bt.set_option("orth_qr", 0)
     bt.set_option("presolve_orth", 0)
     gen = bt.tick(d, DT, want_q_next=True)
     assert bt.stat("last_orth") == 0
     ok = ref["status"] == 0
+    assert (qr["status"] == ref["status"]).all()
+    e_q = np.abs(qr["qdot"] - ref["qdot"])[ok].max()
+    print("%s: basis by QR err %.3e" % (cfg_name, e_q))
+    assert e_q < QDOT_TOL and np.abs(qr["qdot"] - got["qdot"])[ok].max() < 1e-6
     assert ok.mean() > 0.9
     assert (got["status"] == ref["status"]).all() and (gen["status"] == ref["status"]).all()
     e_o, e_g = np.abs(got["qdot"] - ref["qdot"])[ok].max(), np.abs(gen["qdot"] - ref["qdot"])[ok].max()
