@@ -300,6 +300,12 @@ def test_orthonormal_contact_presolve_restated_in_numpy():
             assert np.linalg.cond(Hr) <= 1.0001 * np.linalg.cond(Hfree)
             # the explicit basis, for the record
             G = np.vstack([-np.linalg.solve(Cm[np.ix_(rows, l)], Cm[rows][:, :6]) for rows, l in zip(feet, legd)])
+            # ... and normalised through the 6 x 6 Cholesky factor of I + G'G (what the device does for well-conditioned leg blocks,
+            # orth_null_basis): the same null space, orthonormal to ~eps |G|^2
+            S = np.linalg.inv(np.linalg.cholesky(np.eye(6) + G.T @ G)).T
+            Zf = np.vstack([S, G @ S])
+            assert np.abs(E @ Zf).max() < 1e-9 * np.abs(E).max() and np.abs(Zf.T @ Zf - np.eye(6)).max() < 1e-7
+            assert np.abs(Zbl @ (Zbl.T @ Zf) - Zf).max() < 1e-9
             Ze = Z.copy()
             Ze[np.ix_(bl, range(6))] = np.vstack([np.eye(6), G])
             worse.append(np.linalg.cond(Ze.T @ H @ Ze) / np.linalg.cond(Hr))
