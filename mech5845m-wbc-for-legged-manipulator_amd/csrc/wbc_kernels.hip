@@ -2914,6 +2914,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_deferred_kernel(const KernelAr
 }
 
 // Stand-alone QP (QP_Wrapper.QP.solveQP): H, g (or A, b) and constraints straight from HBM.
+// NM: compiled size of the dual active-set core (launch_qp picks the smallest of 12 / 16 / 24 / 26 that holds n: its sweeps cost ~NM^2)
+template <int NM>
 __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
   __shared__ Smem S;
   S.cl[threadIdx.x] = 0.0;
@@ -2989,7 +2991,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
     WSYNC();
     unsigned long long ts[T_NN];
     (void)ts;
-    const QpResult res = qp_core<NV>(S, g, lb, ub, clb, cub, n, p, lane, ts);
+    const QpResult res = qp_core<NM>(S, g, lb, ub, clb, cub, n, p, lane, ts);
     if (lane < n) A.x[(size_t)b * n + lane] = res.x;
     if (lane == 0) {
       if (A.status) A.status[b] = res.status;
@@ -4237,7 +4239,11 @@ int launch_tick_sim3p(const KernelArgs& a, void* stream) {
 int sim3_lds_bytes() { return (int)sizeof(SmemC); }
 int sim3p_lds_bytes() { return (int)sizeof(SmemP); }
 int launch_qp(const QpArgs& a, int grid, void* stream) {
-  hipLaunchKernelGGL(wbc_qp_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a);
+  hipStream_t s = (hipStream_t)stream;
+  if (a.n <= 12) hipLaunchKernelGGL(wbc_qp_kernel<12>, dim3(grid), dim3(64), 0, s, a);
+  else if (a.n <= 16) hipLaunchKernelGGL(wbc_qp_kernel<16>, dim3(grid), dim3(64), 0, s, a);
+  else if (a.n <= 24) hipLaunchKernelGGL(wbc_qp_kernel<24>, dim3(grid), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(wbc_qp_kernel<NV>, dim3(grid), dim3(64), 0, s, a);
   return check_launch("qp");
 }
 int launch_integrate(const IntegrateArgs& a, int grid, void* stream) {

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Throughput of the stand-alone batched QP (wbc_qp_solve, the QP.solveQP mirror) by problem size: the kernel is compiled for cores of
+12 / 16 / 24 / 26 unknowns and launch_qp picks the smallest that holds n (random strictly convex QPs with boxes and rows)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "mech5845m-wbc-for-legged-manipulator_amd")]
+import numpy as np, torch
+from wbc_batch import WbcBatch
+rng=np.random.default_rng(0)
+B=32768
+for n,p in ((8,4),(14,8),(20,8),(26,12)):
+    A=rng.normal(size=(B,n+4,n)); H=np.einsum("bmi,bmj->bij",A,A)+1e-3*np.eye(n); g=rng.normal(size=(B,n))
+    C=rng.normal(size=(B,p,n)); lb=-np.ones((B,n))*0.5; ub=-lb; cl=-np.ones((B,p)); cu=-cl
+    import wbc_model
+    bt=WbcBatch(wbc_model.load_model("a1_wx200"),B)
+    d=[torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (H,g,C,lb,ub,cl,cu)]
+    for _ in range(3): r=bt.qp_solve(*d)
+    r=dict(zip(("x","status","iters"), r))
+    torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(10): bt.qp_solve(*d)
+    torch.cuda.synchronize(); dt=(time.perf_counter()-t)/10
+    print("n=%d p=%d: %.3f ms  %.1f M QPs/s  optimal %.3f iters %.2f"%(n,p,dt*1e3,B/dt/1e6,(r["status"]==0).double().mean().item(), r["iters"].double().mean().item()))
+    bt.close()
