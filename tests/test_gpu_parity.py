@@ -941,11 +941,13 @@ def test_tick_can_be_captured_into_a_graph(wx200):
 
 
 @pytest.mark.timeout(120)
-def test_non_finite_inputs_are_contained(wx200):
+@pytest.mark.parametrize("cfg_name", ["c3", "c2"])
+def test_non_finite_inputs_are_contained(wx200, cfg_name):
     """NaN / Inf / absurd magnitudes in some instances' inputs: every wave still terminates (all solver loops are capped),
-    the poisoned instances come back flagged with q̇ = 0, and their neighbours are solved as if nothing had happened."""
+    the poisoned instances come back flagged with q̇ = 0, and their neighbours are solved as if nothing had happened — on the packed /
+    compact sim3 kernels (c3) and through the orthonormal contact presolve of the general kernel (c2)."""
     B = 512
-    cfg = common.config("c3", wx200)
+    cfg = common.config(cfg_name, wx200)
     d = common.tick_inputs(wx200, cfg, B, seed=33)
     clean = {k: v.copy() for k, v in d.items()}
     d["q"][5, 10] = np.nan
@@ -953,7 +955,9 @@ def test_non_finite_inputs_are_contained(wx200):
     d["q"][40, 3:7] = 0.0                      # zero quaternion
     d["ee_target"][63, 4, 1] = np.nan
     d["ee_target"][64, 4, 0] = 1e200
-    d["trunk_box_center"][100, 0] = -np.inf
+    d["trunk_box_center"][100, 0] = -np.inf if cfg_name == "c3" else d["trunk_box_center"][100, 0]
+    if cfg_name == "c2":
+        d["com_target"][100, 1] = np.inf
     d["q"][200, 20] = 1e30                     # an angle no range reduction survives
     poisoned = [5, 17, 40, 63, 64, 100, 200]
     bt = WbcBatch(wx200, B)
