@@ -3762,30 +3762,44 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // ---- Cholesky H' = L L' fused with the substitution L y = e_s (rotating registers; column broadcast through V.cl)
   WSYNC();
   V.cl[s] = 0.0; V.cl[16 + s] = 0.0;        // (the row bounds were staged there)
+  V.yv[s] = 0.0; V.tv[s] = 0.0;             // second column vector of the blocked sweep: yv | tv, 32 contiguous entries, zero tail
   double y[PV];
 #pragma unroll
   for (int k = 0; k < PV; ++k) y[k] = (k == s) ? 1.0 : 0.0;
   double pmin = 1.0;
+  // Two columns per trip: the raw columns j and j + 1 of every row go through LDS together and each lane redoes, for the rows below, the
+  // one update that column j + 1 receives from step j — the same operations in the same order as two single steps (bit-identical), one LDS
+  // round trip instead of two in the 12-step chain.
 #pragma unroll 1
-  for (int j = 0; j < PV; ++j) {
+  for (int j = 0; j < PV; j += 2) {
     WSYNC();
-    if (s < PV) V.cl[s] = h[0];
+    if (s < PV) { V.cl[s] = h[0]; V.yv[s] = h[1]; }
     WSYNC();
-    const double* cj = V.cl + j;
-    const double pj = cj[0];
+    const double* c0 = V.cl + j;
+    const double* c1 = V.yv + j;
+    const double pj = c0[0];
     pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;
     const double rinv = rsqrt(pj), ipj = rinv * rinv;
-    double cm[PV];
+    double cm0[PV], cm1[PV];
 #pragma unroll
-    for (int rr = 1; rr < PV; ++rr) cm[rr] = cj[rr];
+    for (int rr = 1; rr < PV; ++rr) { cm0[rr] = c0[rr]; cm1[rr] = c1[rr]; }
+    // step j on this row
     const double th = h[0] * ipj, ty = y[0] * ipj, yk = y[0] * rinv;
+    const double h1 = fma(-th, cm0[1], h[1]), y1 = fma(-ty, cm0[1], y[1]);
+    // step j as it acts on column j + 1 of the rows below (what their own lanes compute for themselves)
+    const double a = cm0[1];
 #pragma unroll
-    for (int rr = 1; rr < PV; ++rr) h[rr - 1] = fma(-th, cm[rr], h[rr]);
+    for (int rr = 1; rr < PV; ++rr) cm1[rr] = fma(-(cm0[rr] * ipj), a, cm1[rr]);
+    const double pj2 = cm1[1];
+    pmin = (pj2 > 0.0) ? fmin(pmin, pj2) : -1.0;
+    const double rinv2 = rsqrt(pj2), ipj2 = rinv2 * rinv2;
+    const double th2 = h1 * ipj2, ty2 = y1 * ipj2, yk2 = y1 * rinv2;
 #pragma unroll
-    for (int rr = 1; rr < PV; ++rr) y[rr - 1] = fma(-ty, cm[rr], y[rr]);
-    y[PV - 1] = yk;
-    LDS_THEN_VALU(PV, 2 * PV + 2);
-    h[PV - 1] = 0.0;
+    for (int rr = 2; rr < PV; ++rr) h[rr - 2] = fma(-th2, cm1[rr], fma(-th, cm0[rr], h[rr]));
+#pragma unroll
+    for (int rr = 2; rr < PV; ++rr) y[rr - 2] = fma(-ty2, cm1[rr], fma(-ty, cm0[rr], y[rr]));
+    y[PV - 2] = fma(-ty2, 0.0, yk); y[PV - 1] = yk2;
+    h[PV - 2] = 0.0; h[PV - 1] = 0.0;
   }
   if (live && !(pmin > 0.0)) { status = WBC_QP_NUMERICAL; live = false; }
   PSTOP(4, y[0] + y[11] + h[0]);
