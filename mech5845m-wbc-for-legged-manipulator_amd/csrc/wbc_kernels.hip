@@ -3850,29 +3850,30 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     V.xv[s] = x;
     WSYNC();
     double best = 0.0; int code = -1;
+    double cand_b = 0.0, cand_n2 = 1.0;    // bound value (signed by side) and |normal|^2 of this lane's candidate: fetched with its code in ONE round
     if (has_b && !act_b) {
-      if (lb > -QP_INF) { const double sl = x - lb; if (sl < -1e-9 * fmax(1.0, fabs(lb)) && sl < best) { best = sl; code = s; } }
-      if (ub < QP_INF) { const double sl = ub - x; if (sl < -1e-9 * fmax(1.0, fabs(ub)) && sl < best) { best = sl; code = s | 256; } }
+      if (lb > -QP_INF) { const double sl = x - lb; if (sl < -1e-9 * fmax(1.0, fabs(lb)) && sl < best) { best = sl; code = s; cand_b = lb; } }
+      if (ub < QP_INF) { const double sl = ub - x; if (sl < -1e-9 * fmax(1.0, fabs(ub)) && sl < best) { best = sl; code = s | 256; cand_b = -ub; } }
     }
     if (has_r && !act_r) {
       const double2a c0 = lds2(I.Cq + s * 6), c1 = lds2(I.Cq + s * 6 + 2), c2 = lds2(I.Cq + s * 6 + 4);
       const double2a x0 = lds2(V.xv), x1 = lds2(V.xv + 2), x2 = lds2(V.xv + 4);
       const double v = fma(c0.x, x0.x, fma(c0.y, x0.y, fma(c1.x, x1.x, fma(c1.y, x1.y, fma(c2.x, x2.x, c2.y * x2.y)))));
-      if (clb > -QP_INF) { const double sl = v - clb; if (sl < -1e-9 * fmax(1.0, fabs(clb)) && sl < best) { best = sl; code = n + s; } }
-      if (cub < QP_INF) { const double sl = cub - v; if (sl < -1e-9 * fmax(1.0, fabs(cub)) && sl < best) { best = sl; code = (n + s) | 256; } }
+      if (clb > -QP_INF) { const double sl = v - clb; if (sl < -1e-9 * fmax(1.0, fabs(clb)) && sl < best) { best = sl; code = n + s; cand_b = clb; cand_n2 = cn2; } }
+      if (cub < QP_INF) { const double sl = cub - v; if (sl < -1e-9 * fmax(1.0, fabs(cub)) && sl < best) { best = sl; code = (n + s) | 256; cand_b = -cub; cand_n2 = cn2; } }
     }
     const double worst = rmin16(best);
     if (searching && !(worst < 0.0)) searching = false;               // primal feasible -> this row is optimal
     if (!__ballot(searching)) break;
     const unsigned long long wm = __ballot(searching && best == worst);
     const int wl = __ffs((int)((wm >> rbase) & 0xFFFFull)) - 1;      // first lane of the row holding the worst violation
-    const int wc = bpermi(code, rbase + (wl < 0 ? 0 : wl));
+    const int wsrc = rbase + (wl < 0 ? 0 : wl);                       // (lane s evaluates bound s and row s: the candidate's data sit on its own lane)
+    const int wc = bpermi(code, wsrc);
+    const double b_ip = bperm(cand_b, wsrc);
+    const double np2 = bperm(cand_n2, wsrc);
     const int ip = wc & 255, ip_side = (wc >> 8) & 1;
     const bool is_row = ip >= n;
     const int rr_ = is_row ? ip - n : 0;
-    const int src = rbase + (is_row ? rr_ : (ip & 15));
-    const double b_ip = bperm(is_row ? (ip_side ? -cub : clb) : (ip_side ? -ub : lb), src);
-    const double np2 = is_row ? bperm(cn2, src) : 1.0;
     const double sgn = ip_side ? -1.0 : 1.0;
     double s_ip = worst, u_ip = 0.0;
     bool stepping = searching;              // row inside the partial-step loop for its constraint
@@ -3958,6 +3959,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       const double zn = rsum16(s >= q ? d * d : 0.0);
       double z = 0.0, zb = 0.0, rv = 0.0, rvb = 0.0;
       const int srd = s < PV ? s : PV - 1;
+      const double dq = V.dv[q & 15];                                  // d of slot q and this row's J entry there (the add step's): read
+      const double jq = J[srd * PLD + (q & 15)];                       // in the same round as the products below
 #pragma unroll
       for (int k = 0; k < PV; k += 2) {
         const double2a j2 = lds2(J + srd * PLD + k); const double2a y2 = lds2(V.yv + k);
@@ -3991,11 +3994,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       const bool add = stepping && have_step && t == t2;
       if (__ballot(add)) {
         // ---- add: Householder P with P d2 = delta e1; J2 <- J2 P; T gets column (-r/delta, 1/delta)
-        const double dq = bperm(d, rbase + (q & 15));
         const double sz = sqrt(zn);
         const double delta = (dq >= 0.0) ? -sz : sz;
         const double vv = 2.0 * (zn - delta * dq);
-        const double w = (z - delta * J[srd * PLD + (q & 15)]) * ((vv > 0.0) ? 2.0 / vv : 0.0);
+        const double w = (z - delta * jq) * ((vv > 0.0) ? 2.0 / vv : 0.0);
         if (add && has_b && vv > 0.0) {
 #pragma unroll
           for (int k = 0; k < PV; k += 2) {
