@@ -3282,6 +3282,14 @@ static_assert(sizeof(PInst) % 256 == 0, "matrix blocks: a multiple of the 256-by
 static_assert(sizeof(PVec) % 256 == 128, "vector blocks: half a bank row apart (mod 256 B)");
 struct __attribute__((aligned(16))) SmemP { PInst I[4]; PVec V[4]; };
 
+// 1 / x and 1 / sqrt(x) from the hardware estimates (~2^-24) + two Newton steps: within an ulp or two of the IEEE sequences at a third
+// of their dependent latency (x finite and > 0 — the callers guard). The packed kernel's working-set passes wait on five of them each.
+__device__ __forceinline__ double frcp(double x) { double r = __builtin_amdgcn_rcp(x); r = r * fma(-x, r, 2.0); return r * fma(-x, r, 2.0); }
+__device__ __forceinline__ double frsq(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  return r * fma(-0.5 * x * r, r, 1.5);
+}
 __device__ __forceinline__ double rsum16(double v) {     // sum over the lane's 16-lane row, result in every lane of the row
   v += dpp<DPP_XOR1>(v); v += dpp<DPP_XOR2>(v); v += dpp<DPP_HALF_MIRROR>(v); v += dpp<DPP_MIRROR>(v);
   return v;
@@ -3864,6 +3872,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     }
     const double worst = rmin16(best);
     if (searching && !(worst < 0.0)) searching = false;               // primal feasible -> this row is optimal
+#ifdef WBC_ABLATE
+    if (A.dbg_stop == 108) searching = false;                         // timing cut: one violation scan, no working-set change
+#endif
     if (!__ballot(searching)) break;
     const unsigned long long wm = __ballot(searching && best == worst);
     const int wl = __ffs((int)((wm >> rbase) & 0xFFFFull)) - 1;      // first lane of the row holding the worst violation
@@ -3979,11 +3990,11 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       if (!has_b) z = 0.0;
       const bool have_step = zn > 100.0 * n * EPS2 * jf2 * np2;
       const bool cand = (s < q) && (rv > 0.0);
-      const double ratio = cand ? u / rv : INFINITY;
+      const double ratio = cand ? u * frcp(rv) : INFINITY;
       const double t1 = rmin16(ratio);
       const unsigned long long lm = __ballot(cand && ratio == t1);
       const int l = (t1 < INFINITY) ? __ffs((int)((lm >> rbase) & 0xFFFFull)) - 1 : -1;
-      const double t2 = have_step ? -s_ip / zn : INFINITY;
+      const double t2 = have_step ? -s_ip * frcp(zn) : INFINITY;
       const double t = fmin(t1, t2);
       if (stepping && !(t < INFINITY)) { status = WBC_QP_INFEASIBLE; stepping = false; searching = false; }
       if (stepping) {
@@ -3994,10 +4005,11 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       const bool add = stepping && have_step && t == t2;
       if (__ballot(add)) {
         // ---- add: Householder P with P d2 = delta e1; J2 <- J2 P; T gets column (-r/delta, 1/delta)
-        const double sz = sqrt(zn);
+        const double rsz = frsq(zn), sz = zn * rsz;
         const double delta = (dq >= 0.0) ? -sz : sz;
-        const double vv = 2.0 * (zn - delta * dq);
-        const double w = (z - delta * jq) * ((vv > 0.0) ? 2.0 / vv : 0.0);
+        const double hv = zn - delta * dq;               // v'v / 2
+        const double vv = 2.0 * hv;
+        const double w = (z - delta * jq) * ((vv > 0.0) ? frcp(hv) : 0.0);
         if (add && has_b && vv > 0.0) {
 #pragma unroll
           for (int k = 0; k < PV; k += 2) {
@@ -4008,7 +4020,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
           }
         }
         if (add) {
-          const double idel = 1.0 / delta;
+          const double idel = (dq >= 0.0) ? -rsz : rsz;
           if (s < q) T[s * PLD + q] = -rv * idel;
           if (s == q) { T[s * PLD + q] = idel; u = u_ip; a_code = wc; }
           if (is_row) { if (s == rr_) act_r = true; } else { if (s == (ip & 15)) act_b = true; }
