@@ -73,6 +73,14 @@ __device__ __forceinline__ double rdl(double v, int lane) {  // lane must be wav
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int rdli(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// 1 / x and 1 / sqrt(x) from the hardware estimates (~2^-24) + two Newton steps: within an ulp or two of the IEEE sequences at a third
+// of their dependent latency (x finite and > 0 — the callers guard). A working-set pass of the dual method waits on five of them.
+__device__ __forceinline__ double frcp(double x) { double r = __builtin_amdgcn_rcp(x); r = r * fma(-x, r, 2.0); return r * fma(-x, r, 2.0); }
+__device__ __forceinline__ double frsq(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  return r * fma(-0.5 * x * r, r, 1.5);
+}
 __device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll((long long)m) - 1; }
 
 // DPP move of a double (both halves) with a compile-time control word (gfx9 row operations)
@@ -776,10 +784,10 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
       }
       const bool have_step = zn > 100.0 * n * EPS2 * jf2 * np2;
       const bool cand = (lane >= qe) && (lane < q) && (r > 0.0);
-      const double ratio = cand ? u / r : INFINITY;
+      const double ratio = cand ? u * frcp(r) : INFINITY;
       const double t1 = wmin(lane < 32 ? ratio : INFINITY);
       const int l = (t1 < INFINITY) ? ctz64(__ballot(cand && ratio == t1)) : -1;
-      const double t2 = have_step ? -s_ip / zn : INFINITY;
+      const double t2 = have_step ? -s_ip * frcp(zn) : INFINITY;
       const double t = fmin(t1, t2);
       if (!(t < INFINITY)) { res.status = WBC_QP_INFEASIBLE; goto done; }
       if (have_step) x = fma(t, z, x);
@@ -788,11 +796,12 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
       if (have_step && t == t2) {
         // ---- add: Householder P with P d2 = delta e1; J2 <- J2 P; T gets column (-r/delta, 1/delta)
         const double dq = rdl(d, q);
-        const double sz = sqrt(zn);
+        const double rsz = frsq(zn), sz = zn * rsz;
         const double delta = (dq >= 0.0) ? -sz : sz;
-        const double vv = 2.0 * (zn - delta * dq);
+        const double hv = zn - delta * dq;               // v'v / 2
+        const double vv = 2.0 * hv;
         if (vv > 0.0) {
-          const double w = (z - delta * J[li * LDJ + q]) * (2.0 / vv);
+          const double w = (z - delta * J[li * LDJ + q]) * frcp(hv);
 #pragma unroll
           for (int k = 0; k < NM; k += 2) {
             const double2a j2 = lds2(J + li * LDJ + k); const double2a y2 = lds2(S.yv + k);   // yv = d for k >= q, else 0
@@ -801,7 +810,7 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
             if (lane < n) sts2(J + lane * LDJ + k, fma(-w, v0, j2.x), fma(-w, v1, j2.y));
           }
         }
-        const double idel = 1.0 / delta;
+        const double idel = (dq >= 0.0) ? -rsz : rsz;
         if (lane >= qe && lane < q) T[lane * LDJ + q] = -r * idel;
         if (lane == q) { T[lane * LDJ + q] = idel; u = u_ip; a_code = wc; }
         if (is_row) { if (lane == rr) { act_r = true; side_r = ip_side; } } else { if (lane == ip) { act_b = true; side_b = ip_side; } }
@@ -3282,14 +3291,6 @@ static_assert(sizeof(PInst) % 256 == 0, "matrix blocks: a multiple of the 256-by
 static_assert(sizeof(PVec) % 256 == 128, "vector blocks: half a bank row apart (mod 256 B)");
 struct __attribute__((aligned(16))) SmemP { PInst I[4]; PVec V[4]; };
 
-// 1 / x and 1 / sqrt(x) from the hardware estimates (~2^-24) + two Newton steps: within an ulp or two of the IEEE sequences at a third
-// of their dependent latency (x finite and > 0 — the callers guard). The packed kernel's working-set passes wait on five of them each.
-__device__ __forceinline__ double frcp(double x) { double r = __builtin_amdgcn_rcp(x); r = r * fma(-x, r, 2.0); return r * fma(-x, r, 2.0); }
-__device__ __forceinline__ double frsq(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  r = r * fma(-0.5 * x * r, r, 1.5);
-  return r * fma(-0.5 * x * r, r, 1.5);
-}
 __device__ __forceinline__ double rsum16(double v) {     // sum over the lane's 16-lane row, result in every lane of the row
   v += dpp<DPP_XOR1>(v); v += dpp<DPP_XOR2>(v); v += dpp<DPP_HALF_MIRROR>(v); v += dpp<DPP_MIRROR>(v);
   return v;
