@@ -416,7 +416,7 @@ extern "C" int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, i
     if (!b->d_defer || !b->last_path) return WBC_OK;
     int32_t c = 0;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    HIP_TRY(hipMemcpy(&c, b->d_defer, sizeof c, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&c, b->d_defer + 1 + b->max_batch + 2, sizeof c, hipMemcpyDeviceToHost));
     *out = c;
     return WBC_OK;
   }
@@ -624,12 +624,12 @@ static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
     a.out.status = b->d_status;
   }
   if (!b->d_defer) {
-    HIP_TRY(hipMalloc((void**)&b->d_defer, sizeof(int32_t) * ((size_t)b->max_batch + 2)));
-    HIP_TRY(hipMemset(b->d_defer, 0, sizeof(int32_t) * ((size_t)b->max_batch + 2)));
+    HIP_TRY(hipMalloc((void**)&b->d_defer, sizeof(int32_t) * ((size_t)b->max_batch + 4)));
+    HIP_TRY(hipMemset(b->d_defer, 0, sizeof(int32_t) * ((size_t)b->max_batch + 4)));
   }
-  a.defer = b->d_defer;
+  a.defer = b->d_defer;                                  // (count = 0 here: wbc_tick_deferred_kernel leaves the list empty behind it)
+  a.defer_aux = b->d_defer + 1 + b->max_batch;
   a.dbg_force_defer = b->force_defer;
-  HIP_TRY(hipMemsetAsync(b->d_defer, 0, sizeof(int32_t), (hipStream_t)stream));   // (a memset node when the call is captured into a graph)
   if (b->count_pivoted) {
     a.pivot_count = b->d_defer + 1 + b->max_batch;
     HIP_TRY(hipMemsetAsync(a.pivot_count, 0, sizeof(int32_t), (hipStream_t)stream));

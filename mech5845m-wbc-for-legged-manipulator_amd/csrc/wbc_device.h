@@ -80,6 +80,7 @@ struct KernelArgs {
   int32_t fk_nj, fk_nf;             // oMi / oMf output strides = max njoints / nframes over the handle's models
   int32_t* defer;                   // [1 + max_batch]: count, then the instances wbc_tick_sim3_kernel left to the general path
   int32_t* pivot_count;             // diagnostic (option "count_pivoted"): instances that took the pivoted elimination; else null
+  int32_t* defer_aux;               // [0] the pivot counter's slot, [1] workgroups of the deferred pass that are done, [2] last tick's deferred count
   int32_t dbg_force_defer;          // diagnostic: every instance with a flagged leg block is deferred instead of pivoted
   int32_t presolve_orth;            // the orthonormal contact presolve where DevPlan.orth: 0 off, 1 on, 2 on and a plan of this batch has DevPlan.orth (host)
   int32_t orth_qr, pad3_;           // diagnostic: the null-space basis always through the Householder QR (else only for flagged leg blocks)

@@ -2899,8 +2899,13 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_deferred_kernel(const KernelAr
                                                                   const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   __shared__ Smem S;
   const int lane0 = threadIdx.x;
-  int count = __builtin_amdgcn_readfirstlane(A.defer[0]);
-  if (count > A.B) count = A.B;
+  const int count_raw = __builtin_amdgcn_readfirstlane(A.defer[0]);
+  const int count = count_raw > A.B ? A.B : count_raw;
+  // The list resets itself (no memset launch per tick — at small batches that dispatch was a tenth of the tick): an empty list is
+  // already zero; otherwise the workgroups that had work count themselves out and the last one to finish — every other one has read
+  // the count by then, and a workgroup that has not started yet has index >= count whatever it reads — clears it. defer_aux: [1] done
+  // counter, [2] the count for the "deferred_last" statistic.
+  if (count == 0) { if (blockIdx.x == 0 && lane0 == 0) A.defer_aux[2] = 0; return; }
   if ((int)blockIdx.x >= count) return;
   const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
                     A.in.com_target || A.in.com_target_vel;
@@ -2919,6 +2924,11 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_deferred_kernel(const KernelAr
     WSYNC();
     process_instance<MODE_TICK, true>(S, A, models[mid], cfgs[mid], plans[mid], lc, cur, b, lane, 0ull);
     WSYNC();
+  }
+  if (lane0 == 0) {
+    __threadfence();
+    const int nblk = count < (int)gridDim.x ? count : (int)gridDim.x;
+    if (atomicAdd(A.defer_aux + 1, 1) == nblk - 1) { A.defer_aux[2] = count_raw; A.defer_aux[1] = 0; A.defer[0] = 0; }
   }
 }
 
