@@ -358,8 +358,11 @@ void orc_assemble_one(const WbcModelBlob* m, const WbcConfig* c, const WbcTickIn
   if (q_con_used) memcpy(q_con_used, qc, sizeof(double) * NQS);
   double oMi[WBC_MAX_JOINTS * 12], J[6 * NV], Jf[6 * NV];
   const int mrows = orc_task_rows(c), prows = orc_constraint_rows(c), nv = m->nv;
-  double* At = (double*)calloc((size_t)(mrows ? mrows : 1) * NV, sizeof(double));
-  double* bt = (double*)calloc((size_t)(mrows ? mrows : 1), sizeof(double));
+  /* task stack on the stack (at most 5 x 6 + 6 + 3 + 26 = 65 rows <= WBC_MAX_M): two heap allocations per instance were
+   * a measurable part of a tick and serialised the OpenMP threads in the allocator (the cpu_baseline leg of bench.py) */
+  double At[WBC_MAX_M * NV], bt[WBC_MAX_M];
+  memset(At, 0, sizeof(double) * (size_t)(mrows ? mrows : 1) * NV);
+  memset(bt, 0, sizeof(double) * (size_t)(mrows ? mrows : 1));
   int row = 0;
 
   orc_fk(m, q, oMi);                 /* updateState: Robot_Wrapper4.py:400-405 */
@@ -468,7 +471,6 @@ void orc_assemble_one(const WbcModelBlob* m, const WbcConfig* c, const WbcTickIn
   }
   if (A) memcpy(A, At, sizeof(double) * (size_t)mrows * NV);
   if (bv) memcpy(bv, bt, sizeof(double) * (size_t)mrows);
-  free(At); free(bt);
 
   /* --- constraints in order CoM, Trunk, FR, FL, RR, RL, Grip: findConstraints (Robot_Wrapper4.py:764-836) */
   if (qc != q) {   /* robot_data now belongs to the configuration qpJointb left behind */
