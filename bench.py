@@ -88,10 +88,11 @@ def pmc_static():
 class Comm:
     """torch.distributed as the benchmark uses it: a barrier and a MAX all-reduce — nothing on the data path."""
 
-    def __init__(self, backend, rank, world, device=None):
+    def __init__(self, backend, rank, world, device=None, force=False):
+        """force: create the process group at world size 1 too (tests: the RCCL barrier / all-reduce on one GPU)"""
         self.rank, self.world, self.device = rank, world, device
         self.dist = None
-        if world > 1:
+        if world > 1 or force:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if not dist.is_initialized():

@@ -223,17 +223,24 @@ int wbc_assemble(WbcBatch* b, int B, const WbcTickIn* in, double dt, int mem, co
 /* replaces QP.solveQP / solveQPHotstart given H, g (QP_Wrapper.py:23-73):
  * argmin 1/2 x'Hx + g'x  s.t. lb <= x <= ub, Clb <= C x <= Cub.
  * n <= 26, p <= WBC_MAX_P; H is [B][n][n], C is [B][p][n] (row-major, NOT the reference's C.T view —
- * SURVEY.md C.1); lb/ub/C may be NULL (no box / no rows). */
+ * SURVEY.md C.1); lb/ub/C may be NULL (no box / no rows).
+ * Hot start (solveQPHotstart, QP_Wrapper.py:55-73: qpOASES keeps its working set between calls): working_set_in / working_set_out,
+ * [B][2] words in the QP's own indexing — word 0: bit i = variable i at its lower bound, bit 32 + i = at its upper bound; word 1: the
+ * same for constraint row i. Either may be NULL (cold start / nothing returned); they may be the same buffer. A seed is only a hint:
+ * the answer is the cold solve's (H > 0), wrong seeds are dropped again. An unsolved QP returns an empty set. */
 int wbc_qp_solve(WbcBatch* b, int B, int n, int p, const double* H, const double* g, const double* C,
                  const double* lb, const double* ub, const double* Clb, const double* Cub, int mem,
-                 double* x, int32_t* status, int32_t* iters, void* stream);
+                 double* x, int32_t* status, int32_t* iters, const uint64_t* working_set_in, uint64_t* working_set_out,
+                 void* stream);
 
 /* replaces QP(A, b, ...) + solveQP(): forms H = A'A, g = -A'b on the device (QP_Wrapper.py:17-18)
  * and solves. A is [B][m][n]. H_out/g_out optional. use_mfma: 1 = fp64 MFMA contraction, 0 = VALU, -1 = MFMA from
- * WBC_MFMA_AUTO_ROWS rows on (measured 1.3x at m = 32, 1.8x at m = 64 and 96 on the whole call). */
+ * WBC_MFMA_AUTO_ROWS rows on (measured 1.3x at m = 32, 1.8x at m = 64 and 96 on the whole call).
+ * working_set_in / working_set_out: as in wbc_qp_solve (QP.solveQPHotstart passes the previous call's set). */
 int wbc_qp_solve_ls(WbcBatch* b, int B, int m, int n, int p, const double* A, const double* bvec, const double* C,
                     const double* lb, const double* ub, const double* Clb, const double* Cub, int mem, int use_mfma,
-                    double* x, int32_t* status, int32_t* iters, double* H_out, double* g_out, void* stream);
+                    double* x, int32_t* status, int32_t* iters, double* H_out, double* g_out,
+                    const uint64_t* working_set_in, uint64_t* working_set_out, void* stream);
 
 /* replaces qpJointb's "MANI" / "HYBRID" branches (Robot_Wrapper4.py:1220-1260) under the configured task_joint,
  * arm_base_id and posture_literal: u [B][26] = the posture target before scaling (PREV / zeros for the other modes),

@@ -44,6 +44,7 @@ class QP:
         self.qp = None
         self.status = None
         self.use_mfma = None     # None: the library decides by the row count of A; True / False force the path
+        self._ws = None          # the last solve's working set (qpOASES keeps its own between init and hotstart, :45-48, :70)
 
     # H, g are attributes in the reference (computed eagerly with numpy); here the device forms them on demand.
     @property
@@ -58,7 +59,7 @@ class QP:
             self._solve(form_only=True)
         return self._g
 
-    def _solve(self, form_only=False):
+    def _solve(self, form_only=False, hot=False):
         n = int(self.no_solutions)
         A = np.ascontiguousarray(self._A, dtype=np.float64)
         if A.ndim != 2 or A.shape[1] != n:
@@ -79,10 +80,14 @@ class QP:
             Cr, cl, cu = Cr[None], cl[None], cu[None]
         bt = _batch()
         self.qp = bt
-        x, st, it, H, g = bt.qp_solve_ls(A[None], b[None], Cr, lb[None], ub[None], cl, cu, use_mfma=self.use_mfma, want_Hg=True)
+        ws_in = self._ws if (hot and self._ws is not None and not form_only) else None
+        x, st, it, H, g, ws = bt.qp_solve_ls(A[None], b[None], Cr, lb[None], ub[None], cl, cu, use_mfma=self.use_mfma, want_Hg=True,
+                                             working_set=ws_in, want_working_set=True)
         self._H, self._g = H[0], g[0]
         if form_only:
             return None
+        if int(st[0]) == 0:         # (an unsolved QP keeps the set of the last solved one, like the stale xOpt)
+            self._ws = ws
         self.status = int(st[0])
         self.nWSR = np.array([int(it[0])])
         return x[0]
@@ -106,7 +111,7 @@ class QP:
         self._A, self._b = A, b
         self._H = self._g = None
         self.nWSR = np.array([100000])
-        x = self._solve()
+        x = self._solve(hot=True)       # qp.hotstart (:70): seeded with the previous solve's working set (wbc_qp_solve_ls working_set_in)
         if self.status == 0:            # unsolved: xOpt keeps the previous tick's answer, as in the reference (:71-73)
             self.xOpt[:] = x
         return self.xOpt

@@ -505,7 +505,10 @@ class RobotModel:
         """Drag the neutral pose to the crouched stance with the bounds-only QP (all six Cartesian tasks + Tikhonov
         posture) along the straight-line foot / gripper trajectories, then fix the base: the B = 1 call of
         ``WbcBatch.warm_up`` — the 2 x 1000 QPs run as ONE wbc_rollout (mode WBC_ROLLOUT_WARMUP) on the device. dt is the fixed
-        step_time here (the reference measures wall-clock inside its busy-wait)."""
+        step_time here (the reference measures wall-clock inside its busy-wait).
+        Differences by design: ``solver_status`` is the WORST status over the 2000 QPs (the reference keeps none: qpOASES' return code
+        is dropped, QP_Wrapper.py:49), ``solver_iters`` their sum; the last ``q_vel`` is a local of the reference's loop (:321) and is
+        not kept here either. The gripper goal's height comes from frame role WBC_FR_ARM_BASE = oMi[arm_base_id] (G_base, :37, :253)."""
         nq = self._model.nq
         q0 = self._model.neutral()[:nq]
         for i in range(self.n_velocity_dimensions):          # reference :201-208: only the upper clamp has an effect

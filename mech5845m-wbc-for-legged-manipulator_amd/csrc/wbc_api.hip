@@ -594,7 +594,7 @@ static int launch_update_auto(WbcBatch* b, UpdateArgs& u, int B, void* stream) {
   return packed ? launch_update_packed(u, stream) : launch_update(u, B, stream);
 }
 static bool packed_eligible(const WbcBatch* b, const KernelArgs& a) {
-  bool packed = b->packed_kernel && !a.ws_in && !a.ws_out && !a.in.q_con && !a.in.posture_u &&
+  bool packed = b->packed_kernel && !a.in.q_con && !a.in.posture_u &&
                 !b->force_defer && !b->count_pivoted && !(b->dbg_stop > 0 && b->dbg_stop < 100) && !b->dbg_alias;   // (dbg_stop 101.. cuts the packed kernel)
   for (int i = 0; i < b->n_models && packed; ++i) packed = b->plan_host[i].packed_ok != 0;
   return packed;
@@ -625,7 +625,8 @@ static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
   }
   if (!b->d_defer) {
     HIP_TRY(hipMalloc((void**)&b->d_defer, sizeof(int32_t) * ((size_t)b->max_batch + 4)));
-    HIP_TRY(hipMemset(b->d_defer, 0, sizeof(int32_t) * ((size_t)b->max_batch + 4)));
+    // (on the CALL's stream: a null-stream memset is not ordered against a non-blocking caller stream)
+    HIP_TRY(hipMemsetAsync(b->d_defer, 0, sizeof(int32_t) * ((size_t)b->max_batch + 4), (hipStream_t)stream));
   }
   a.defer = b->d_defer;                                  // (count = 0 here: wbc_tick_deferred_kernel leaves the list empty behind it)
   a.defer_aux = b->d_defer + 1 + b->max_batch;
@@ -638,7 +639,11 @@ static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
     b->last_path = 2;
     if (int e = launch_tick_sim3p(a, stream)) return fail(WBC_E_HIP, "packed sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   } else if (int e = launch_tick_sim3(a, B, stream)) return fail(WBC_E_HIP, "sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-  if (int e = launch_tick_deferred(a, stream)) return fail(WBC_E_HIP, "deferred tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  if (int e = launch_tick_deferred(a, stream)) {
+    // the list the sim3 kernel may have filled stays behind: empty it, or the next tick appends after a stale count
+    (void)hipMemsetAsync(b->d_defer, 0, sizeof(int32_t), (hipStream_t)stream);
+    return fail(WBC_E_HIP, "deferred tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  }
   return WBC_OK;
 }
 
@@ -841,6 +846,7 @@ static int qp_common(WbcBatch* b, int B, QpArgs& a, int mem, void* stream, const
   st.in(&a.H, N * n * n); st.in(&a.g, N * n); st.in(&a.A, N * m * n); st.in(&a.bvec, N * m);
   st.in(&a.C, N * p * n); st.in(&a.lb, N * n); st.in(&a.ub, N * n); st.in(&a.Clb, N * p); st.in(&a.Cub, N * p);
   st.out(&a.x, N * n); st.out(&a.status, N); st.out(&a.iters, N); st.out(&a.H_out, N * n * n); st.out(&a.g_out, N * n);
+  st.in(&a.ws_in, N * 2); st.out(&a.ws_out, N * 2);   // (host buffers are staged separately, so in and out may be the same host array)
   if ((rc = st.stage())) return rc;
   if (int e = launch_qp(a, grid_for(b, B), stream)) return fail(WBC_E_HIP, "qp kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return st.finish();
@@ -848,24 +854,28 @@ static int qp_common(WbcBatch* b, int B, QpArgs& a, int mem, void* stream, const
 
 extern "C" int wbc_qp_solve(WbcBatch* b, int B, int n, int p, const double* H, const double* g, const double* C,
                             const double* lb, const double* ub, const double* Clb, const double* Cub, int mem,
-                            double* x, int32_t* status, int32_t* iters, void* stream) {
+                            double* x, int32_t* status, int32_t* iters, const uint64_t* working_set_in, uint64_t* working_set_out,
+                            void* stream) {
   if (!H || !g) return fail(WBC_E_ARG, "wbc_qp_solve: H and g required");
   QpArgs a;
   memset(&a, 0, sizeof a);
   a.B = B; a.n = n; a.p = p; a.m = 0;
   a.H = H; a.g = g; a.C = C; a.lb = lb; a.ub = ub; a.Clb = Clb; a.Cub = Cub; a.x = x; a.status = status; a.iters = iters;
+  a.ws_in = (const unsigned long long*)working_set_in; a.ws_out = (unsigned long long*)working_set_out;
   return qp_common(b, B, a, mem, stream, "wbc_qp_solve");
 }
 
 extern "C" int wbc_qp_solve_ls(WbcBatch* b, int B, int m, int n, int p, const double* A, const double* bvec, const double* C,
                                const double* lb, const double* ub, const double* Clb, const double* Cub, int mem, int use_mfma,
-                               double* x, int32_t* status, int32_t* iters, double* H_out, double* g_out, void* stream) {
+                               double* x, int32_t* status, int32_t* iters, double* H_out, double* g_out,
+                               const uint64_t* working_set_in, uint64_t* working_set_out, void* stream) {
   if (!A || !bvec || m < 1) return fail(WBC_E_ARG, "wbc_qp_solve_ls: A, b and m >= 1 required");
   QpArgs a;
   memset(&a, 0, sizeof a);
   a.B = B; a.n = n; a.p = p; a.m = m; a.use_mfma = use_mfma < 0 ? (m >= WBC_MFMA_AUTO_ROWS) : (use_mfma != 0);
   a.A = A; a.bvec = bvec; a.C = C; a.lb = lb; a.ub = ub; a.Clb = Clb; a.Cub = Cub;
   a.x = x; a.status = status; a.iters = iters; a.H_out = H_out; a.g_out = g_out;
+  a.ws_in = (const unsigned long long*)working_set_in; a.ws_out = (unsigned long long*)working_set_out;
   return qp_common(b, B, a, mem, stream, "wbc_qp_solve_ls");
 }
 

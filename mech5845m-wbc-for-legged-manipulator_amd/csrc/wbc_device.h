@@ -104,6 +104,8 @@ struct QpArgs {
   const double *H, *g, *A, *bvec, *C, *lb, *ub, *Clb, *Cub;
   double *x, *H_out, *g_out;
   int32_t *status, *iters;
+  const unsigned long long* ws_in;  // hot start (QP.solveQPHotstart): [B][2] working-set words in / out, either may be null, they may alias
+  unsigned long long* ws_out;
 };
 
 struct IntegrateArgs {

@@ -783,7 +783,7 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
         break;
       }
       const bool have_step = zn > 100.0 * n * EPS2 * jf2 * np2;
-      const bool cand = (lane >= qe) && (lane < q) && (r > 0.0);
+      const bool cand = (lane >= qe) && (lane < q) && (r > 2.2250738585072014e-308);   // (normal: frcp's estimate of a denormal is inf)
       const double ratio = cand ? u * frcp(r) : INFINITY;
       const double t1 = wmin(lane < 32 ? ratio : INFINITY);
       const int l = (t1 < INFINITY) ? ctz64(__ballot(cand && ratio == t1)) : -1;
@@ -1143,10 +1143,16 @@ __device__ __forceinline__ void fk_pass(SM& S, double* const oMi, const double* 
 // ------------------------------------------------------------------------------------------------
 constexpr int NR = WBC_PLAN_NR;        // compiled size cap of the reduced problem (16)
 constexpr int GS = 10;                 // row stride of G: 6 base columns + up to 4 extra unknowns (one per rank-deficient stance-leg block)
+// WARM: the carried working set (ws0 / ws1, FULL-problem indexing: KernelArgs.ws_in) is mapped into the reduced problem — reduced
+// variable k is DoF Fd[k], reduced row r is the r-th kept row or, from p_keep on, the velocity bound of eliminated leg DoF legd[r - p_keep]
+// — and the final one mapped back, so that res.ws_b / res.ws_r come out in the caller's indexing (lane = DoF / original constraint row),
+// like process_sim3's.
+template <bool WARM = false>
 __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
                                                  const DevPlan& P, const double dpost, const double g, const double lb,
                                                  const double ub, const double clb, const double cub, const int lane,
-                                                 unsigned long long* ts, QpResult& res) {
+                                                 unsigned long long* ts, QpResult& res, const unsigned long long ws0 = 0ull,
+                                                 const unsigned long long ws1 = 0ull) {
   if (!A.presolve || !P.enabled) return false;
   const int nv = M.nv, p = A.prows;
   const int nelim = P.nelim, n_red = P.n_red, nl = 3 * nelim;
@@ -1277,13 +1283,31 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, c
   }
   WSYNC();
   STAMP(ts, T_PRE);
-  if (n_red <= 12) res = qp_core<12>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);   // (qp_core's sweeps cost ~NM^2)
-  else res = qp_core<NR>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts);
+  int sd_b = 0, sd_r = 0;
+  if (WARM) {
+    int my_orig = -1, cnt = 0;                        // original index of kept row `lane`
+#pragma unroll 1
+    for (int i = 0; i < p; ++i) { if (!((elimrows >> i) & 1u)) { my_orig = (cnt == lane) ? i : my_orig; ++cnt; } }
+    if (lane < n_red) sd_b = (int)(((ws0 >> fj) & 1ull) | (((ws0 >> (32 + fj)) & 1ull) << 1));
+    if (my_orig >= 0) sd_r = (int)(((ws1 >> my_orig) & 1ull) | (((ws1 >> (32 + my_orig)) & 1ull) << 1));
+    else if (cfg.use_bounds && lane >= p_keep && lane < p_keep + nl) sd_r = (int)(((ws0 >> my_legd) & 1ull) | (((ws0 >> (32 + my_legd)) & 1ull) << 1));
+    if (sd_b == 3) sd_b = 0;
+    if (sd_r == 3) sd_r = 0;
+  }
+  if (n_red <= 12) res = qp_core<12, Smem, LDJ, WARM>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, 0, sd_b, sd_r);   // (qp_core's sweeps cost ~NM^2)
+  else res = qp_core<NR, Smem, LDJ, WARM>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, 0, sd_b, sd_r);
   res.iters += nl + P.nlock;                         // the eliminated equalities and the locked DoF, so that `iters` keeps its meaning
   // ---- x = Z y
   WSYNC();
-  if (lane < 32) S.xv[lane] = (lane < n_red) ? res.x : 0.0;
+  if (lane < 32) { S.xv[lane] = (lane < n_red) ? res.x : 0.0; if (WARM) { S.lv[lane] = (double)res.ws_b; S.dinv[lane] = (double)res.ws_r; } }
   WSYNC();
+  if (WARM) {   // the final working set back in full-problem indexing: lane d = DoF d, lane i = original constraint row i
+    int cb = 0, cr = 0;
+    if (my_pos >= 0) cb = (int)S.lv[my_pos];
+    else if (my_l >= 0 && cfg.use_bounds) cb = (int)S.dinv[(p_keep + my_l) & 31];
+    if (lane < p && !((elimrows >> lane) & 1u)) cr = (int)S.dinv[__popc(~elimrows & ((1u << lane) - 1u)) & 31];
+    res.ws_b = cb; res.ws_r = cr;
+  }
   double x = 0.0;
   if (my_pos >= 0) x = S.xv[my_pos];
   else if (my_l >= 0) {
@@ -2148,10 +2172,10 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
 #ifdef WBC_PROFILE
   ts[T_PRE] = 0;
 #endif
-  if (!contact_presolve(S, A, M, cfg, P, dpost, g, lb, ub, clb, cub, lane, ts, res) &&
+  // warm start in the problem's own indexing: lane d <-> bound of DoF d, lane i <-> constraint row i
+  const unsigned long long w0 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b] : 0ull, w1 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b + 1] : 0ull;
+  if (!contact_presolve<WARM>(S, A, M, cfg, P, dpost, g, lb, ub, clb, cub, lane, ts, res, w0, w1) &&
       !(ORTH && contact_presolve_orth(S, A, M, cfg, P, g, lb, ub, clb, cub, lane, ts, res, direct))) {
-    // warm start in the problem's own indexing: lane d <-> bound of DoF d, lane i <-> constraint row i
-    const unsigned long long w0 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b] : 0ull, w1 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b + 1] : 0ull;
     const int sb = (lane < 32) ? (int)(((w0 >> lane) & 1ull) | (((w0 >> (32 + lane)) & 1ull) << 1)) : 0;
     const int sr = (lane < 32) ? (int)(((w1 >> lane) & 1ull) | (((w1 >> (32 + lane)) & 1ull) << 1)) : 0;
     // The DoF the velocity box locks at 0 (>= lock_from, Robot_Wrapper4.py:627-630) are the LAST ones: they leave the problem (x = 0
@@ -2173,7 +2197,7 @@ __device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, c
     } else
     res = qp_core<NV, Smem, LDJ, WARM>(S, g, lb, ub, clb, cub, nv, A.prows, lane, ts, 0, sb == 3 ? 0 : sb, sr == 3 ? 0 : sr);
   }
-  if (WARM && A.ws_out) {   // (the in-kernel presolve path runs cold and carries nothing: res.ws_* = 0 there)
+  if (WARM && A.ws_out) {   // (res.ws_* are in full-problem indexing on every path; an unsolved QP carries nothing)
     const unsigned long long o0 = (__ballot(res.ws_b == 1) & 0xFFFFFFFFull) | (__ballot(res.ws_b == 2) << 32);
     const unsigned long long o1 = (__ballot(res.ws_r == 1) & 0xFFFFFFFFull) | (__ballot(res.ws_r == 2) << 32);
     if (lane == 0) { A.ws_out[2 * (size_t)b] = o0; A.ws_out[2 * (size_t)b + 1] = o1; }
@@ -2682,7 +2706,7 @@ __device__ __forceinline__ void process_sim3(SmemC& S, const KernelArgs& A, cons
       if (lane == 0) {
         A.out.status[b] = WBC_QP_DEFERRED;
         const int slot = atomicAdd(A.defer, 1);
-        A.defer[1 + slot] = b;
+        if (slot < A.B) A.defer[1 + slot] = b;   // (a stale count — a failed second-pass launch, one handle on two streams — must not write past the list)
       }
       WSYNC();
       return;
@@ -2934,7 +2958,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_deferred_kernel(const KernelAr
 
 // Stand-alone QP (QP_Wrapper.QP.solveQP): H, g (or A, b) and constraints straight from HBM.
 // NM: compiled size of the dual active-set core (launch_qp picks the smallest of 12 / 16 / 24 / 26 that holds n: its sweeps cost ~NM^2)
-template <int NM>
+// WARM: working sets in / out (QP.solveQPHotstart, QP_Wrapper.py:55-73): [B][2] words in the problem's own indexing — word 0: bit i / 32 + i =
+// variable i at its lower / upper bound, word 1: constraint row i
+template <int NM, bool WARM = false>
 __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
   __shared__ Smem S;
   S.cl[threadIdx.x] = 0.0;
@@ -3010,7 +3036,18 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
     WSYNC();
     unsigned long long ts[T_NN];
     (void)ts;
-    const QpResult res = qp_core<NM>(S, g, lb, ub, clb, cub, n, p, lane, ts);
+    int sb = 0, sr = 0;
+    if (WARM && A.ws_in) {
+      const unsigned long long w0 = A.ws_in[2 * (size_t)b], w1 = A.ws_in[2 * (size_t)b + 1];
+      sb = (lane < 32) ? (int)(((w0 >> lane) & 1ull) | (((w0 >> (32 + lane)) & 1ull) << 1)) : 0;
+      sr = (lane < 32) ? (int)(((w1 >> lane) & 1ull) | (((w1 >> (32 + lane)) & 1ull) << 1)) : 0;
+    }
+    const QpResult res = qp_core<NM, Smem, LDJ, WARM>(S, g, lb, ub, clb, cub, n, p, lane, ts, 0, sb == 3 ? 0 : sb, sr == 3 ? 0 : sr);
+    if (WARM && A.ws_out) {
+      const unsigned long long o0 = (__ballot(res.ws_b == 1) & 0xFFFFFFFFull) | (__ballot(res.ws_b == 2) << 32);
+      const unsigned long long o1 = (__ballot(res.ws_r == 1) & 0xFFFFFFFFull) | (__ballot(res.ws_r == 2) << 32);
+      if (lane == 0) { A.ws_out[2 * (size_t)b] = o0; A.ws_out[2 * (size_t)b + 1] = o1; }
+    }
     if (lane < n) A.x[(size_t)b * n + lane] = res.x;
     if (lane == 0) {
       if (A.status) A.status[b] = res.status;
@@ -3315,12 +3352,30 @@ __device__ __forceinline__ double bperm(double v, int src_lane) {     // v of la
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int bpermi(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_or(unsigned long long v) {
+  int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+  lo |= __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi |= __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ unsigned long long ror16(unsigned long long v) {   // bitwise OR over the lane's 16-lane row
+  v = dpp_or<DPP_XOR1>(v); v = dpp_or<DPP_XOR2>(v); v = dpp_or<DPP_HALF_MIRROR>(v); v = dpp_or<DPP_MIRROR>(v);
+  return v;
+}
 
 #ifdef WBC_ABLATE
 #define PSTOP(k, val) do { if (A.dbg_stop == 100 + (k)) { if (valid) { A.out.qdot[(size_t)b * NV + s] = (val); if (s == 0) A.out.status[b] = 0; } return; } } while (0)
 #else
 #define PSTOP(k, val) do { } while (0)
 #endif
+// WARM: the variant that takes / returns working sets (warm start, KernelArgs.ws_in / ws_out: the analogue of qpOASES' hotstart,
+// QP_Wrapper.py:55-73); the cold variant carries no trace of it. The seeds go through the dual method's own ADD step (Householder on
+// J2, column (-T r / delta, 1 / delta) of T) without its search / ratio test / partial steps, the iterate and the multipliers are then
+// rebuilt from the factors (x = x0 + J1 w, u = T w, w = T's with s the seeds' slacks at the unconstrained minimiser x0), seeds with
+// a negative multiplier are dropped again (restoration), and the dual iterations carry on from that S-pair: qp_core<.., WARM>'s
+// scheme (tests/gi_variant.py solve_v3) for a problem without equalities.
+template <bool WARM>
 __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                                const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   __shared__ SmemP SP;
@@ -3349,6 +3404,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     if (16 + s < 28) V.in[16 + s] = q1;
     if (s < 10) V.in[28 + s] = ex;
     V.cl[s] = 0.0; V.cl[16 + s] = 0.0;
+    if (WARM && s < 2) {                  // the carried working set: two words per instance, parked (as bit patterns) in V.in[38..39]
+      const unsigned long long w = (A.ws_in && valid) ? A.ws_in[2 * (size_t)b + s] : 0ull;
+      V.in[38 + s] = __longlong_as_double((long long)w);
+    }
     if (A.in.ee_ref_rot) {                // the gripper's orientation reference and its previous value (free vectors until the QP)
       if (s < 9) { V.dv[s] = A.in.ee_ref_rot[(size_t)b * 45 + 36 + s]; V.yv[s] = A.in.ee_prev_rot[(size_t)b * 45 + 36 + s]; }
     }
@@ -3765,7 +3824,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   if (valid && flagged && s == 0) {
     A.out.status[b] = WBC_QP_DEFERRED;
     const int slot = atomicAdd(A.defer, 1);
-    A.defer[1 + slot] = b;
+    if (slot < A.B) A.defer[1 + slot] = b;     // (see wbc_tick_sim3_kernel: never past the list, whatever the count holds)
   }
   WSYNC();
 
@@ -3862,6 +3921,234 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   int a_code = 0, q = 0, iters = 0;
   const int max_iter = 10 * (n + p) + 20;
   bool searching = live;                    // row still iterating
+  // d = J'n of constraint (is_row ? row rr_ : bound of variable ip) with sign sgn, on lane s = slot s
+  auto normal_d = [&](const bool is_row, const int rr_, const int ip, const double sgn) -> double {
+    double d;
+    if (is_row) {
+      const double2a c0 = lds2(I.Cq + rr_ * 6), c1 = lds2(I.Cq + rr_ * 6 + 2), c2 = lds2(I.Cq + rr_ * 6 + 4);
+      d = fma(J[0 * PLD + s], c0.x, fma(J[1 * PLD + s], c0.y, fma(J[2 * PLD + s], c1.x, fma(J[3 * PLD + s], c1.y,
+          fma(J[4 * PLD + s], c2.x, J[5 * PLD + s] * c2.y))))) * sgn;
+    } else d = sgn * J[(ip & 15) * PLD + s];
+    return d;
+  };
+  // drop slot l of the rows `dr`: Givens sequence read off the removed row of T (rare path)
+  auto drop_slot = [&](const bool dr, const int l_) {
+    const int l = dr ? l_ : 0;
+    const int lc = bpermi(a_code, rbase + l) & 255;
+    if (dr) { if (lc >= n) { if (s == lc - n) act_r = false; } else { if (s == lc) act_b = false; } }
+    WSYNC();
+    V.yv[s] = u; V.tv[s] = (double)a_code;
+    WSYNC();
+    if (dr && s >= l && s < q - 1) { u = V.yv[s + 1]; a_code = (int)V.tv[s + 1]; }
+    if (dr && s == q - 1) { u = 0.0; a_code = 0; }
+    const int sv = s < PV ? s : PV - 1;   // (lanes beyond the variables shadow the last row; they never write)
+    const int srow = (sv >= l) ? ((sv + 1 < PV) ? sv + 1 : sv) : sv;
+    double tx = T[srow * PLD + l];
+    double jx = J[sv * PLD + l];
+    double hrun = T[l * PLD + l];
+    const int kend = dr ? q - 1 : 0;    // this row's rotations run k = l .. q - 2
+#pragma unroll 1
+    for (int k0 = 0; k0 < PV - 1; ++k0) {
+      const bool on = dr && (l + k0 < kend);
+      if (!__ballot(on)) break;
+      const int k = on ? l + k0 : 0;
+      const double tb = T[l * PLD + k + 1];
+      const double nrm2 = fma(hrun, hrun, tb * tb);
+      double c_ = 1.0, s_ = 0.0, rho = 0.0;
+      if (nrm2 > 0.0) { const double ri = rsqrt(nrm2); c_ = tb * ri; s_ = -hrun * ri; rho = nrm2 * ri; }
+      const double ty_ = T[srow * PLD + k + 1];
+      const double jy = J[sv * PLD + k + 1];
+      WSYNC();
+      if (on) {
+        hrun = rho;
+        if (s < q - 1) T[s * PLD + k] = fma(c_, tx, s_ * ty_);
+        if (s < n) J[s * PLD + k] = fma(c_, jx, s_ * jy);
+        tx = fma(-s_, tx, c_ * ty_);
+        jx = fma(-s_, jx, c_ * jy);
+      }
+      WSYNC();
+    }
+    WSYNC();
+    if (dr) {
+      if (s < q) T[s * PLD + q - 1] = 0.0;
+    }
+    WSYNC();
+    if (dr) {
+      if (s < q) T[(q - 1) * PLD + s] = 0.0;
+      if (s < n) J[s * PLD + q - 1] = jx;
+      --q;
+    }
+    WSYNC();
+  };
+  // with d staged (V.dv = d, V.yv = d restricted to the slots >= q): z = J2 d2, r = T d1, and the add step's dq = d_q, jq = J[s][q]
+  struct Zr { double z, rv, dq, jq; };
+  auto products = [&](const bool want_r) -> Zr {
+    Zr o;
+    double z = 0.0, zb = 0.0, rv = 0.0, rvb = 0.0;
+    const int srd = s < PV ? s : PV - 1;
+    o.dq = V.dv[q & 15];                                                // d of slot q and this row's J entry there (the add step's): read
+    o.jq = J[srd * PLD + (q & 15)];                                     // in the same round as the products below
+#pragma unroll
+    for (int k = 0; k < PV; k += 2) {
+      const double2a j2 = lds2(J + srd * PLD + k); const double2a y2 = lds2(V.yv + k);
+      z = fma(j2.x, y2.x, z); zb = fma(j2.y, y2.y, zb);
+    }
+    z += zb;
+    if (want_r) {                           // r = T d1: nothing to do while no row of the wave holds an active inequality
+#pragma unroll
+      for (int k = 0; k < PV; k += 2) {
+        const double2a t2 = lds2(T + srd * PLD + k); const double2a d2 = lds2(V.dv + k);
+        rv = fma(t2.x, d2.x, rv); rvb = fma(t2.y, d2.y, rvb);
+      }
+      rv += rvb;
+    }
+    if (s >= q) rv = 0.0;
+    if (!has_b) z = 0.0;
+    o.z = z; o.rv = rv;
+    return o;
+  };
+  // add: Householder P with P d2 = delta e1; J2 <- J2 P; T gets column (-r/delta, 1/delta); the new slot's multiplier is u_new
+  auto add_step = [&](const bool add, const double zn, const Zr& zr, const int wc, const bool is_row, const int rr_, const int ip, const double u_new) {
+    const double rsz = frsq(zn), sz = zn * rsz;
+    const double delta = (zr.dq >= 0.0) ? -sz : sz;
+    const double hv = zn - delta * zr.dq;               // v'v / 2
+    const double vv = 2.0 * hv;
+    const double w = (zr.z - delta * zr.jq) * ((vv > 0.0) ? frcp(hv) : 0.0);
+    if (add && has_b && vv > 0.0) {
+#pragma unroll
+      for (int k = 0; k < PV; k += 2) {
+        const double2a j2 = lds2(J + s * PLD + k); const double2a y2 = lds2(V.yv + k);   // yv = d for k >= q, else 0
+        const double v0 = (k == q) ? y2.x - delta : y2.x;
+        const double v1 = (k + 1 == q) ? y2.y - delta : y2.y;
+        sts2(J + s * PLD + k, fma(-w, v0, j2.x), fma(-w, v1, j2.y));
+      }
+    }
+    if (add) {
+      const double idel = (zr.dq >= 0.0) ? -rsz : rsz;
+      if (s < q) T[s * PLD + q] = -zr.rv * idel;
+      if (s == q) { T[s * PLD + q] = idel; u = u_new; a_code = wc; }
+      if (is_row) { if (s == rr_) act_r = true; } else { if (s == (ip & 15)) act_b = true; }
+      ++q;
+    }
+  };
+
+  // ================================ warm start ======================================================
+  int dofR = 0;                             // DoF whose velocity bound row s (>= p_keep) carries (the working set's indexing)
+  if (WARM) {
+    const unsigned long long ws0 = (unsigned long long)__double_as_longlong(V.in[38]), ws1 = (unsigned long long)__double_as_longlong(V.in[39]);
+    dofR = bpermi(dofB, rbase + ((s - p_keep) & 15));
+    auto bits = [](const unsigned long long w, const int i) -> int { return (int)(((w >> (i & 31)) & 1ull) | (((w >> (32 + (i & 31))) & 1ull) << 1)); };
+    // the seeds seen from the reduced problem: bound of reduced variable s = velocity bound of DoF dofA; row s < p_keep = original
+    // constraint row s (the trunk box leads findConstraints' order here); row s >= p_keep = velocity bound of leg DoF dofR
+    int sb = has_b ? bits(ws0, dofA) : 0;
+    int sr = has_r ? ((s < p_keep) ? bits(ws1, s) : bits(ws0, dofR)) : 0;
+    if (sb == 3) sb = 0;
+    if (sr == 3) sr = 0;
+    // a seed is taken only if the unconstrained minimiser x0 violates it or comes close to it (qp_core, solve_v3 `far`)
+    const double x0r = x;
+    WSYNC();
+    V.xv[s] = x;
+    WSYNC();
+    const double near = 0.25 * fmax(1.0, -rmin16(has_b ? -fabs(x) : 0.0));
+    double vr = 0.0;
+    if (has_r) {
+      const double2a c0 = lds2(I.Cq + s * 6), c1 = lds2(I.Cq + s * 6 + 2), c2 = lds2(I.Cq + s * 6 + 4);
+      const double2a x0 = lds2(V.xv), x1 = lds2(V.xv + 2), x2 = lds2(V.xv + 4);
+      vr = fma(c0.x, x0.x, fma(c0.y, x0.y, fma(c1.x, x1.x, fma(c1.y, x1.y, fma(c2.x, x2.x, c2.y * x2.y)))));
+    }
+    const double slb = (sb == 2) ? ub - x : x - lb;      // slack of the seeded side at x0
+    const double slr = (sr == 2) ? cub - vr : vr - clb;
+    bool pend_b = live && has_b && ((sb == 1 && lb > -QP_INF) || (sb == 2 && ub < QP_INF)) && (slb <= near);
+    bool pend_r = live && has_r && ((sr == 1 && clb > -QP_INF) || (sr == 2 && cub < QP_INF)) && (slr <= near);
+    bool seeded = false;
+#pragma unroll 1
+    for (;;) {                              // one seed per row and pass: bounds first, then rows, lowest index first
+      const unsigned mb = (unsigned)((__ballot(pend_b) >> rbase) & 0xFFFFull), mr = (unsigned)((__ballot(pend_r) >> rbase) & 0xFFFFull);
+      const bool seeding = (mb | mr) != 0u;
+      if (!__ballot(seeding)) break;
+      const bool is_row = mb == 0u;
+      const int idx = seeding ? __ffs((int)(is_row ? mr : mb)) - 1 : 0;
+      if (seeding && s == idx) { if (is_row) pend_r = false; else pend_b = false; }
+      const int c_side = ((is_row ? sr : sb) == 2) ? 256 : 0;
+      const double c_n2 = is_row ? cn2 : 1.0;
+      const int wsrc = rbase + idx;
+      const int wc = ((is_row ? n + idx : idx) & 255) | bpermi(c_side, wsrc);
+      const double np2 = bperm(c_n2, wsrc);
+      const int ip = wc & 255;
+      const int rr_ = is_row ? ip - n : 0;
+      const double sgn = (wc >> 8) ? -1.0 : 1.0;
+      double d = normal_d(is_row, rr_, ip, sgn);
+      if (!has_b || !seeding) d = 0.0;
+      WSYNC();
+      V.dv[s] = d; V.yv[s] = (s >= q) ? d : 0.0;
+      WSYNC();
+      const double zn = rsum16(s >= q ? d * d : 0.0);
+      const Zr zr = products(__ballot(seeding && q > 0) != 0);
+      const bool add = seeding && (zn > 100.0 * n * EPS2 * jf2 * np2);      // (a dependent seed is simply not taken)
+      if (__ballot(add)) {
+        add_step(add, zn, zr, wc, is_row, rr_, ip, 0.0);
+        if (add) { seeded = true; ++iters; }
+      }
+    }
+    // x, u from the factors: with s_j = b_j - n_j'x0 the slacks of the slots at x0:  w = T's,  x = x0 + J1 w,  u = T w
+    auto refresh = [&](const bool on) {
+      const int cc = a_code & 255;
+      const double sb_ = bperm(-slb, rbase + (cc & 15)), sr_ = bperm(-slr, rbase + ((cc - n) & 15));
+      const double sj = (s < q) ? ((cc < n) ? sb_ : sr_) : 0.0;
+      WSYNC();
+      V.dv[s] = sj;
+      WSYNC();
+      const int sv = s < PV ? s : PV - 1;
+      double w = 0.0;
+#pragma unroll
+      for (int j = 0; j < PV; ++j) w = fma(T[j * PLD + sv], V.dv[j], w);        // column s of T (zero outside the slots)
+      WSYNC();
+      V.yv[s] = (s < q && s < PV) ? w : 0.0;
+      WSYNC();
+      double xa = 0.0, ua = 0.0;
+#pragma unroll
+      for (int k = 0; k < PV; k += 2) {
+        const double2a j2 = lds2(J + sv * PLD + k), t2 = lds2(T + sv * PLD + k), w2 = lds2(V.yv + k);
+        xa = fma(j2.x, w2.x, fma(j2.y, w2.y, xa)); ua = fma(t2.x, w2.x, fma(t2.y, w2.y, ua));
+      }
+      if (on) { x = has_b ? x0r + xa : 0.0; u = (s < q) ? ua : 0.0; }
+    };
+    if (__ballot(seeded)) {
+      refresh(seeded);
+      // RESTORATION: while a seeded multiplier is negative the most negative slot is dropped and the iterate moved to the minimiser on
+      // the remaining set (the add step read backwards: x <- x - u_l z, u <- u + u_l r with z, r of the dropped constraint on the NEW
+      // factors); after any drop x, u are rebuilt once more from the factors (they went through where the wrong seeds put them: with
+      // cond(H) ~ 1e9 that costs digits; the factors saw orthogonal updates only) and one more pass runs on the accurate multipliers.
+      bool restoring = seeded, did = false, again = false;
+#pragma unroll 1
+      for (;;) {
+        const double um = rmin16((s < q) ? u : 0.0);
+        bool rest = restoring && (um < 0.0);
+        if (rest && ++iters > max_iter) { status = WBC_QP_MAX_ITER; rest = false; restoring = false; searching = false; }
+        if (!__ballot(rest)) {
+          if (!__ballot(restoring && did && !again)) break;
+          const bool on = restoring && did && !again;
+          refresh(on);
+          if (on) again = true;
+          continue;
+        }
+        const int l = rest ? __ffs((int)((__ballot(rest && s < q && u == um) >> rbase) & 0xFFFFull)) - 1 : 0;
+        const int lcode = bpermi(a_code, rbase + (l < 0 ? 0 : l));
+        drop_slot(rest, l < 0 ? 0 : l);
+        const int ip = lcode & 255;
+        const bool is_row = ip >= n;
+        const int rr_ = is_row ? ip - n : 0;
+        double d = normal_d(is_row, rr_, ip, (lcode >> 8) ? -1.0 : 1.0);
+        if (!has_b || !rest) d = 0.0;
+        WSYNC();
+        V.dv[s] = d; V.yv[s] = (s >= q) ? d : 0.0;
+        WSYNC();
+        const Zr zr = products(__ballot(rest && q > 0) != 0);
+        if (rest) { x = fma(-um, zr.z, x); u = fma(um, zr.rv, u); did = true; }
+      }
+    }
+  }
+
 #pragma unroll 1
   for (;;) {
     // most violated inactive inequality of each row
@@ -3903,55 +4190,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
 #pragma unroll 1
     for (;;) {
       if (stepping && ++iters > max_iter) { status = WBC_QP_MAX_ITER; stepping = false; searching = false; }
-      // ---- drop slot l of the rows that ask for it: Givens sequence read off the removed row of T (rare path)
+      // ---- drop slot l of the rows that ask for it
       if (__ballot(stepping && drop_l >= 0)) {
         const bool dr = stepping && drop_l >= 0;
-        const int l = dr ? drop_l : 0;
-        const int lc = bpermi(a_code, rbase + l) & 255;
-        if (dr) { if (lc >= n) { if (s == lc - n) act_r = false; } else { if (s == lc) act_b = false; } }
-        WSYNC();
-        V.yv[s] = u; V.tv[s] = (double)a_code;
-        WSYNC();
-        if (dr && s >= l && s < q - 1) { u = V.yv[s + 1]; a_code = (int)V.tv[s + 1]; }
-        if (dr && s == q - 1) { u = 0.0; a_code = 0; }
-        const int sv = s < PV ? s : PV - 1;   // (lanes beyond the variables shadow the last row; they never write)
-        const int srow = (sv >= l) ? ((sv + 1 < PV) ? sv + 1 : sv) : sv;
-        double tx = T[srow * PLD + l];
-        double jx = J[sv * PLD + l];
-        double hrun = T[l * PLD + l];
-        const int kend = dr ? q - 1 : 0;    // this row's rotations run k = l .. q - 2
-#pragma unroll 1
-        for (int k0 = 0; k0 < PV - 1; ++k0) {
-          const bool on = dr && (l + k0 < kend);
-          if (!__ballot(on)) break;
-          const int k = on ? l + k0 : 0;
-          const double tb = T[l * PLD + k + 1];
-          const double nrm2 = fma(hrun, hrun, tb * tb);
-          double c_ = 1.0, s_ = 0.0, rho = 0.0;
-          if (nrm2 > 0.0) { const double ri = rsqrt(nrm2); c_ = tb * ri; s_ = -hrun * ri; rho = nrm2 * ri; }
-          const double ty_ = T[srow * PLD + k + 1];
-          const double jy = J[sv * PLD + k + 1];
-          WSYNC();
-          if (on) {
-            hrun = rho;
-            if (s < q - 1) T[s * PLD + k] = fma(c_, tx, s_ * ty_);
-            if (s < n) J[s * PLD + k] = fma(c_, jx, s_ * jy);
-            tx = fma(-s_, tx, c_ * ty_);
-            jx = fma(-s_, jx, c_ * jy);
-          }
-          WSYNC();
-        }
-        WSYNC();
-        if (dr) {
-          if (s < q) T[s * PLD + q - 1] = 0.0;
-        }
-        WSYNC();
-        if (dr) {
-          if (s < q) T[(q - 1) * PLD + s] = 0.0;
-          if (s < n) J[s * PLD + q - 1] = jx;
-          --q;
-        }
-        WSYNC();
+        drop_slot(dr, drop_l);
         // slack of the constraint being added, at the current x
         V.xv[s] = x;
         WSYNC();
@@ -3968,39 +4210,16 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       }
       if (!__ballot(stepping)) break;
       // ---- d = J'n, z = J2 d2, r = T d1
-      double d = 0.0;
-      if (is_row) {
-        const double2a c0 = lds2(I.Cq + rr_ * 6), c1 = lds2(I.Cq + rr_ * 6 + 2), c2 = lds2(I.Cq + rr_ * 6 + 4);
-        d = fma(J[0 * PLD + s], c0.x, fma(J[1 * PLD + s], c0.y, fma(J[2 * PLD + s], c1.x, fma(J[3 * PLD + s], c1.y,
-            fma(J[4 * PLD + s], c2.x, J[5 * PLD + s] * c2.y))))) * sgn;
-      } else d = sgn * J[(ip & 15) * PLD + s];
+      double d = normal_d(is_row, rr_, ip, sgn);
       if (!has_b || !stepping) d = 0.0;      // (lanes >= n read padding: masked here)
       WSYNC();
       V.dv[s] = d; V.yv[s] = (s >= q) ? d : 0.0;
       WSYNC();
       const double zn = rsum16(s >= q ? d * d : 0.0);
-      double z = 0.0, zb = 0.0, rv = 0.0, rvb = 0.0;
-      const int srd = s < PV ? s : PV - 1;
-      const double dq = V.dv[q & 15];                                  // d of slot q and this row's J entry there (the add step's): read
-      const double jq = J[srd * PLD + (q & 15)];                       // in the same round as the products below
-#pragma unroll
-      for (int k = 0; k < PV; k += 2) {
-        const double2a j2 = lds2(J + srd * PLD + k); const double2a y2 = lds2(V.yv + k);
-        z = fma(j2.x, y2.x, z); zb = fma(j2.y, y2.y, zb);
-      }
-      z += zb;
-      if (__ballot(stepping && q > 0)) {      // r = T d1: nothing to do while no row of the wave holds an active inequality
-#pragma unroll
-        for (int k = 0; k < PV; k += 2) {
-          const double2a t2 = lds2(T + srd * PLD + k); const double2a d2 = lds2(V.dv + k);
-          rv = fma(t2.x, d2.x, rv); rvb = fma(t2.y, d2.y, rvb);
-        }
-        rv += rvb;
-      }
-      if (s >= q) rv = 0.0;
-      if (!has_b) z = 0.0;
+      const Zr zr = products(__ballot(stepping && q > 0) != 0);
+      const double z = zr.z, rv = zr.rv;
       const bool have_step = zn > 100.0 * n * EPS2 * jf2 * np2;
-      const bool cand = (s < q) && (rv > 0.0);
+      const bool cand = (s < q) && (rv > 2.2250738585072014e-308);   // (normal: frcp's estimate of a denormal is inf)
       const double ratio = cand ? u * frcp(rv) : INFINITY;
       const double t1 = rmin16(ratio);
       const unsigned long long lm = __ballot(cand && ratio == t1);
@@ -4015,29 +4234,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       }
       const bool add = stepping && have_step && t == t2;
       if (__ballot(add)) {
-        // ---- add: Householder P with P d2 = delta e1; J2 <- J2 P; T gets column (-r/delta, 1/delta)
-        const double rsz = frsq(zn), sz = zn * rsz;
-        const double delta = (dq >= 0.0) ? -sz : sz;
-        const double hv = zn - delta * dq;               // v'v / 2
-        const double vv = 2.0 * hv;
-        const double w = (z - delta * jq) * ((vv > 0.0) ? frcp(hv) : 0.0);
-        if (add && has_b && vv > 0.0) {
-#pragma unroll
-          for (int k = 0; k < PV; k += 2) {
-            const double2a j2 = lds2(J + s * PLD + k); const double2a y2 = lds2(V.yv + k);   // yv = d for k >= q, else 0
-            const double v0 = (k == q) ? y2.x - delta : y2.x;
-            const double v1 = (k + 1 == q) ? y2.y - delta : y2.y;
-            sts2(J + s * PLD + k, fma(-w, v0, j2.x), fma(-w, v1, j2.y));
-          }
-        }
-        if (add) {
-          const double idel = (dq >= 0.0) ? -rsz : rsz;
-          if (s < q) T[s * PLD + q] = -rv * idel;
-          if (s == q) { T[s * PLD + q] = idel; u = u_ip; a_code = wc; }
-          if (is_row) { if (s == rr_) act_r = true; } else { if (s == (ip & 15)) act_b = true; }
-          ++q;
-          stepping = false;                 // this row goes back to the search
-        }
+        add_step(add, zn, zr, wc, is_row, rr_, ip, u_ip);
+        if (add) stepping = false;          // this row goes back to the search
       }
       if (stepping) drop_l = l;             // blocking slot: dropped at the top of the next pass, then the step is retried
     }
@@ -4047,6 +4245,19 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     if ((bad >> rbase) & 0xFFFFull) status = WBC_QP_NUMERICAL;
   }
   if (status != WBC_QP_OPTIMAL) x = 0.0;
+  if (WARM && A.ws_out) {   // the final working set in FULL-problem indexing (KernelArgs.ws_in); an unsolved QP carries nothing
+    const int cc = a_code & 255, sd = (a_code >> 8) & 1;
+    const int dA = bpermi(dofA, rbase + (cc & 15));            // slot holds the bound of reduced variable cc: its DoF
+    const int dR = bpermi(dofR, rbase + ((cc - n) & 15));      // slot holds reduced row cc - n >= p_keep: the leg DoF whose bound it is
+    unsigned long long w0 = 0ull, w1 = 0ull;
+    if (status == WBC_QP_OPTIMAL && s < q) {
+      if (cc < n) w0 = 1ull << (32 * sd + (dA & 31));
+      else if (cc - n < p_keep) w1 = 1ull << (32 * sd + ((cc - n) & 31));
+      else w0 = 1ull << (32 * sd + (dR & 31));
+    }
+    w0 = ror16(w0); w1 = ror16(w1);
+    if (valid && !flagged && s == 0) { A.ws_out[2 * (size_t)b] = w0; A.ws_out[2 * (size_t)b + 1] = w1; }
+  }
 
   // ---- x = Z y, q̇ by DoF through LDS, outputs
   WSYNC();
@@ -4272,14 +4483,19 @@ int launch_tick_deferred(const KernelArgs& a, void* stream) {
   return check_launch("tick_deferred");
 }
 int launch_tick_sim3p(const KernelArgs& a, void* stream) {
-  hipLaunchKernelGGL(wbc_tick_sim3p_kernel, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  if (a.ws_in || a.ws_out) hipLaunchKernelGGL(wbc_tick_sim3p_kernel<true>, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  else hipLaunchKernelGGL(wbc_tick_sim3p_kernel<false>, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   return check_launch("tick_sim3p");
 }
 int sim3_lds_bytes() { return (int)sizeof(SmemC); }
 int sim3p_lds_bytes() { return (int)sizeof(SmemP); }
 int launch_qp(const QpArgs& a, int grid, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (a.n <= 12) hipLaunchKernelGGL(wbc_qp_kernel<12>, dim3(grid), dim3(64), 0, s, a);
+  if (a.ws_in || a.ws_out) {   // hot start: the core sizes the tick problems come in (a reduced problem fits 16, the full one needs 26)
+    if (a.n <= 16) hipLaunchKernelGGL((wbc_qp_kernel<16, true>), dim3(grid), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((wbc_qp_kernel<NV, true>), dim3(grid), dim3(64), 0, s, a);
+  }
+  else if (a.n <= 12) hipLaunchKernelGGL(wbc_qp_kernel<12>, dim3(grid), dim3(64), 0, s, a);
   else if (a.n <= 16) hipLaunchKernelGGL(wbc_qp_kernel<16>, dim3(grid), dim3(64), 0, s, a);
   else if (a.n <= 24) hipLaunchKernelGGL(wbc_qp_kernel<24>, dim3(grid), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(wbc_qp_kernel<NV>, dim3(grid), dim3(64), 0, s, a);

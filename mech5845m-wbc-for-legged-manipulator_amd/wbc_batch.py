@@ -239,10 +239,11 @@ class WbcBatch:
         call._keep = keep
         return call
 
-    def qp_solve(self, H, g, C_=None, lb=None, ub=None, Clb=None, Cub=None):
-        """Batched QP.solveQP given H, g. H [B,n,n], C_ [B,p,n] (row-major rows), returns (x, status, iters)."""
+    def qp_solve(self, H, g, C_=None, lb=None, ub=None, Clb=None, Cub=None, working_set=None, want_working_set=False):
+        """Batched QP.solveQP given H, g. H [B,n,n], C_ [B,p,n] (row-major rows), returns (x, status, iters).
+        working_set [B,2] int64 (include/wbc.h wbc_qp_solve) hot-starts the solve; want_working_set appends the final one to the result."""
         keep = []
-        mem = _mem_of([H, g, C_, lb, ub, Clb, Cub])
+        mem = _mem_of([H, g, C_, lb, ub, Clb, Cub, working_set])
         if len(H.shape) != 3 or H.shape[1] != H.shape[2]:
             raise capi.WbcError("H must be [B, n, n], got %s" % (tuple(H.shape),))
         B, n = H.shape[0], H.shape[-1]
@@ -250,19 +251,23 @@ class WbcBatch:
             raise capi.WbcError("C must be [B, p, %d], got %s" % (n, tuple(C_.shape)))
         p = 0 if C_ is None else C_.shape[-2]
         x, st, it = self._alloc(H, (B, n)), self._alloc(H, (B,), np.int32), self._alloc(H, (B,), np.int32)
+        wso = self._alloc(H, (B, 2), np.int64) if want_working_set else None
         f = np.float64
         P = self._p
         capi.check(self.lib.wbc_qp_solve(self._h, B, n, p, P(H, f, keep), P(g, f, keep, B, n, "g"), P(C_, f, keep, B, p * n, "C"),
                                           P(lb, f, keep, B, n, "lb"), P(ub, f, keep, B, n, "ub"), P(Clb, f, keep, B, p, "Clb"),
                                           P(Cub, f, keep, B, p, "Cub"), mem,
-                                          P(x, f, keep), P(st, np.int32, keep), P(it, np.int32, keep), self._stream(mem)), self.lib)
-        return x, st, it
+                                          P(x, f, keep), P(st, np.int32, keep), P(it, np.int32, keep),
+                                          P(working_set, np.int64, keep, B, 2, "working_set"), P(wso, np.int64, keep), self._stream(mem)), self.lib)
+        return (x, st, it, wso) if want_working_set else (x, st, it)
 
-    def qp_solve_ls(self, A, b, C_=None, lb=None, ub=None, Clb=None, Cub=None, use_mfma=None, want_Hg=False):
+    def qp_solve_ls(self, A, b, C_=None, lb=None, ub=None, Clb=None, Cub=None, use_mfma=None, want_Hg=False, working_set=None,
+                    want_working_set=False):
         """Batched QP(A, b, ...).solveQP(): H = A'A and g = -A'b are formed on the device (QP_Wrapper.py:17-18);
-        use_mfma: True / False, None = matrix cores from WBC_MFMA_AUTO_ROWS rows of A on."""
+        use_mfma: True / False, None = matrix cores from WBC_MFMA_AUTO_ROWS rows of A on. working_set / want_working_set: as in
+        qp_solve (solveQPHotstart); the final set comes last in the returned tuple."""
         keep = []
-        mem = _mem_of([A, b, C_, lb, ub, Clb, Cub])
+        mem = _mem_of([A, b, C_, lb, ub, Clb, Cub, working_set])
         if len(A.shape) != 3:
             raise capi.WbcError("A must be [B, m, n], got %s" % (tuple(A.shape),))
         B, m, n = A.shape
@@ -272,14 +277,17 @@ class WbcBatch:
         x, st, it = self._alloc(A, (B, n)), self._alloc(A, (B,), np.int32), self._alloc(A, (B,), np.int32)
         Ho = self._alloc(A, (B, n, n)) if want_Hg else None
         go = self._alloc(A, (B, n)) if want_Hg else None
+        wso = self._alloc(A, (B, 2), np.int64) if want_working_set else None
         f = np.float64
         P = self._p
         capi.check(self.lib.wbc_qp_solve_ls(self._h, B, m, n, p, P(A, f, keep), P(b, f, keep, B, m, "b"), P(C_, f, keep, B, p * n, "C"),
                                              P(lb, f, keep, B, n, "lb"), P(ub, f, keep, B, n, "ub"), P(Clb, f, keep, B, p, "Clb"),
                                              P(Cub, f, keep, B, p, "Cub"), mem,
                                              -1 if use_mfma is None else int(bool(use_mfma)), P(x, f, keep), P(st, np.int32, keep), P(it, np.int32, keep),
-                                             P(Ho, f, keep), P(go, f, keep), self._stream(mem)), self.lib)
-        return (x, st, it, Ho, go) if want_Hg else (x, st, it)
+                                             P(Ho, f, keep), P(go, f, keep),
+                                             P(working_set, np.int64, keep, B, 2, "working_set"), P(wso, np.int64, keep), self._stream(mem)), self.lib)
+        out = (x, st, it, Ho, go) if want_Hg else (x, st, it)
+        return out + (wso,) if want_working_set else out
 
     def posture_target(self, q, model_id=None, want_q_after=True):
         """qpJointb's "MANI" / "HYBRID" posture target u [B,26] under the configured mode (Robot_Wrapper4.py:1220-1260),
@@ -374,8 +382,8 @@ class WbcBatch:
         goal = ee.copy()                                                   # :238-262
         goal[:, :4, 0] = pos[:, capi.FR_HIP0:capi.FR_HIP0 + 4, 0]          # feet under their hips ...
         goal[:, :4, 2] *= 0.9                                              # ... and 10 % closer to the trunk (multiplier_F / _R)
-        goal[:, 4, 2] = pos[:, capi.FR_HIP0 + 4, 2]                        # gripper: height of the arm base joint (waist), x of the FR hip,
-        goal[:, 4, 0] = pos[:, capi.FR_HIP0, 0]
+        goal[:, 4, 2] = pos[:, capi.FR_ARM_BASE, 2]                        # gripper: height of oMi[arm_base_id] (G_base, :37, :253 — a constructor
+        goal[:, 4, 0] = pos[:, capi.FR_HIP0, 0]                            # argument of its own, not the fifth hip_waist name), x of the FR hip
         goal[:, 4, 0] *= 1.1                                               # multiplier_G = diag(1.1, 1, 1.5)
         goal[:, 4, 2] *= 1.5
         n = int(ticks_per_segment)

@@ -98,8 +98,8 @@ SIGNATURES = {
     "wbc_constraint_rows": (_i, [_vp]),
     "wbc_fk_jacobians": (_i, [_vp, _i, _vp, _vp, _i, C.POINTER(WbcFkOut), _vp]),
     "wbc_assemble": (_i, [_vp, _i, C.POINTER(WbcTickIn), _d, _i, C.POINTER(WbcQpData), _vp]),
-    "wbc_qp_solve": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
-    "wbc_qp_solve_ls": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "wbc_qp_solve": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "wbc_qp_solve_ls": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wbc_posture_target": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "wbc_tick": (_i, [_vp, _i, C.POINTER(WbcTickIn), _d, _i, C.POINTER(WbcTickOut), _vp]),
     "wbc_update_state": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

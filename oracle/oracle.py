@@ -247,7 +247,7 @@ def warmup(models, q0, dt=0.002, ticks_per_segment=1000, foot_radius=0.0, model_
         p2[:, 0] = pos[:, capi.FR_HIP0 + i, 0]
         goal[:, i] = p2 @ np.diag([1.0, 1.0, 0.9])
     g2 = ee[:, 4].copy()
-    g2[:, 2] = pos[:, capi.FR_HIP0 + 4, 2]                 # oMi[arm_base_id] (the waist joint)
+    g2[:, 2] = pos[:, capi.FR_ARM_BASE, 2]                 # oMi[arm_base_id]: G_base, its own constructor argument (:37, :253)
     g2[:, 0] = pos[:, capi.FR_HIP0, 0]                     # oMi[FR_hip_joint]
     goal[:, 4] = g2 @ np.diag([1.1, 1.0, 1.5])
     from scipy.spatial.transform import Rotation as R

@@ -523,3 +523,190 @@ def solve_v3(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, seeds=(), max_i
                 break
             drop(l)
             s_ip = (-1.0 if side else 1.0) * value(ip, x) - b_ip
+
+
+def solve_v4(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, seeds=(), max_iter=None, far=0.25):
+    """The PACKED kernel's warm start (wbc_tick_sim3p_kernel<WARM>; SURVEY.md §8 f2, QP_Wrapper.py:55-73) for a problem WITHOUT
+    equalities (the contact presolve and the locked DoF removed them):
+      1. x0 = -J0 J0'g; a seed is kept only if x0 violates it or comes within far * max(1, |x0|_inf) of it;
+      2. every kept seed goes through the dual method's ADD step alone (Householder on J2, column (-T r / delta, 1 / delta) of T):
+         no search, no ratio test, no partial step; dependent seeds are skipped;
+      3. x, u from the factors: s_j = b_j - n_j'x0, w = T's, x = x0 + J1 w, u = T w;
+      4. restoration (most negative multiplier dropped, x <- x - u_l z, u <- u + u_l r on the new factors), then 3. once more and a
+         second restoration pass on the accurate multipliers;
+      5. solve()'s dual iterations from that S-pair.
+    Returns (x, status, iters, final working set [(constraint, side)])."""
+    n = len(g)
+    p = 0 if C is None else C.shape[0]
+    ncon = n + p
+
+    def lo(c):
+        return (lb[c] if lb is not None else -1e30) if c < n else Clb[c - n]
+
+    def hi(c):
+        return (ub[c] if ub is not None else 1e30) if c < n else Cub[c - n]
+
+    def normal(c, side):
+        sgn = -1.0 if side else 1.0
+        if c < n:
+            e = np.zeros(n)
+            e[c] = sgn
+            return e
+        return sgn * C[c - n]
+
+    def value(c, x):
+        return x[c] if c < n else C[c - n] @ x
+
+    assert not any(lo(c) == hi(c) and abs(lo(c)) < INF for c in range(ncon)), "solve_v4: no equalities"
+    try:
+        L = np.linalg.cholesky(H)
+    except np.linalg.LinAlgError:
+        return np.zeros(n), 3, 0, []
+    J = np.linalg.inv(L).T.copy()
+    jf2 = (J * J).sum()
+    x0 = -J @ (J.T @ g)
+    x = x0.copy()
+    T = np.zeros((n, n))
+    u = np.zeros(n + 1)
+    act, active = [], np.zeros(ncon, bool)
+    q = 0
+    iters = 0
+    max_iter = max_iter or 10 * (n + p) + 20
+
+    def add(c, side, d, zn, z, r, u_new):
+        nonlocal q
+        dq = d[q]
+        delta = -np.sqrt(zn) if dq >= 0 else np.sqrt(zn)
+        v = d[q:].copy()
+        v[0] -= delta
+        vv = 2.0 * (zn - delta * dq)
+        if vv > 0:
+            w = z - delta * J[:, q]
+            J[:, q:] -= np.outer(w, (2.0 / vv) * v)
+        T[:q, q] = -r / delta
+        T[q, q] = 1.0 / delta
+        u[q] = u_new
+        act.append((c, side))
+        active[c] = True
+        q += 1
+
+    def drop(l):
+        nonlocal q
+        trow = T[l, l:q].copy()
+        active[act[l][0]] = False
+        del act[l]
+        u[l:q - 1] = u[l + 1:q].copy()
+        u[q - 1] = 0.0
+        Tt = np.delete(T[:q, :q], l, axis=0)
+        h = trow[0]
+        for k in range(l, q - 1):
+            a_, b_ = h, trow[k - l + 1]
+            rho = np.hypot(a_, b_)
+            c_, s_ = (b_ / rho, -a_ / rho) if rho > 0 else (1.0, 0.0)
+            h = rho
+            ck, ck1 = Tt[:, k].copy(), Tt[:, k + 1].copy()
+            Tt[:, k], Tt[:, k + 1] = c_ * ck + s_ * ck1, -s_ * ck + c_ * ck1
+            jk, jk1 = J[:, k].copy(), J[:, k + 1].copy()
+            J[:, k], J[:, k + 1] = c_ * jk + s_ * jk1, -s_ * jk + c_ * jk1
+        T[:, :] = 0
+        T[:q - 1, :q - 1] = np.triu(Tt[:, :q - 1])
+        q -= 1
+
+    # ---- 1, 2: seeds, bounds first then rows, lowest index first (the kernel's order); one side per constraint
+    near = far * max(1.0, np.abs(x0).max()) if far is not None else np.inf
+    todo, seen = [], {}
+    for c, side in seeds:
+        if 0 <= c < ncon:
+            seen[c] = None if (c in seen and seen[c] != side) else side      # both sides claimed: dropped (the kernel's code 3)
+    for c in sorted(seen):
+        side = seen[c]
+        if side is None:
+            continue
+        if (side == 0 and lo(c) > -INF) or (side == 1 and hi(c) < INF):
+            todo.append((c, side))
+    for c, side in todo:
+        slack = value(c, x0) - lo(c) if side == 0 else hi(c) - value(c, x0)
+        if not slack <= near:
+            continue
+        npv = normal(c, side)
+        d = J.T @ npv
+        zn = d[q:] @ d[q:]
+        if not zn > 100.0 * n * EPS2 * jf2 * (npv @ npv):
+            continue
+        iters += 1
+        add(c, side, d, zn, J[:, q:] @ d[q:], T[:q, :q] @ d[:q], 0.0)
+
+    def refresh():
+        nonlocal x
+        sl = np.array([(lo(c) if sd == 0 else -hi(c)) - normal(c, sd) @ x0 for c, sd in act])
+        w = T[:q, :q].T @ sl
+        x = x0 + J[:, :q] @ w
+        u[:q] = T[:q, :q] @ w
+
+    def restore():
+        nonlocal x, iters
+        did = False
+        while q > 0 and u[:q].min() < 0.0:
+            iters += 1
+            l = int(np.argmin(u[:q]))
+            ul = u[l]
+            c, side = act[l]
+            drop(l)
+            d = J.T @ normal(c, side)
+            x = x - ul * (J[:, q:] @ d[q:])
+            u[:q] += ul * (T[:q, :q] @ d[:q])
+            did = True
+        return did
+
+    if q > 0:
+        refresh()
+        if restore():
+            refresh()
+            restore()
+    # ---- 5: dual iterations
+    while True:
+        worst, ip = 0.0, -1
+        for c in range(ncon):
+            if active[c]:
+                continue
+            v = value(c, x)
+            if lo(c) > -INF:
+                s = v - lo(c)
+                if s < -1e-9 * max(1.0, abs(lo(c))) and s < worst:
+                    worst, ip, side, b_ip = s, c, 0, lo(c)
+            if hi(c) < INF:
+                s = hi(c) - v
+                if s < -1e-9 * max(1.0, abs(hi(c))) and s < worst:
+                    worst, ip, side, b_ip = s, c, 1, -hi(c)
+        if ip < 0:
+            return x, 0, iters, list(act)
+        s_ip = worst
+        npv = normal(ip, side)
+        np2 = npv @ npv
+        u_ip = 0.0
+        while True:
+            iters += 1
+            if iters > max_iter:
+                return x, 1, iters, list(act)
+            d = J.T @ npv
+            zn = d[q:] @ d[q:]
+            z = J[:, q:] @ d[q:]
+            r = T[:q, :q] @ d[:q]
+            have_step = zn > 100.0 * n * EPS2 * jf2 * np2
+            t1, l = np.inf, -1
+            for k in range(q):
+                if r[k] > 0 and u[k] / r[k] < t1:
+                    t1, l = u[k] / r[k], k
+            t2 = -s_ip / zn if have_step else np.inf
+            t = min(t1, t2)
+            if not np.isfinite(t):
+                return x, 2, iters, list(act)
+            if have_step:
+                x = x + t * z
+            u[:q] -= t * r
+            u_ip += t
+            if have_step and t == t2:
+                add(ip, side, d, zn, z, r, u_ip)
+                break
+            drop(l)
+            s_ip = (-1.0 if side else 1.0) * value(ip, x) - b_ip

