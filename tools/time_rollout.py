@@ -41,3 +41,47 @@ for stress in (True, False):
         out.append(rec)
         print(json.dumps(rec), flush=True)
 bt.close()
+
+# ---- (c) open-loop ticks on the same inputs: cold vs hot-started with the previous tick's / the tick's own final working set (the steady
+# state of a smooth trajectory), kernel time by HIP events; "slowest row per wave" = max over the four instances of a wavefront of the
+# inequality working-set changes (iters - eliminated equalities - locked DoF): the passes the packed kernel's loops run
+bt2 = WbcBatch(model, B)
+bt2.configure(cfg)
+fk2 = lambda q: bt2.fk(q, want=("oMf",))["oMf"]
+for stress in (True, False):
+    d = wbc_workload.make_tick_inputs(model, cfg, B, 0, fk2, stress=stress)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d.items()}
+    prev = dict(dev)
+    prev["ee_target"] = dev["ee_target"] - 1e-4
+    ws_prev = bt2.tick(prev, 0.002, want_working_set=True)["working_set"]
+    cold = bt2.tick(dev, 0.002, want_working_set=True)
+    base = int(cold["iters"].min().item())
+    for name, ws in (("cold", None), ("own set", cold["working_set"]), ("previous tick's set", ws_prev)):
+        o = dict(qdot=torch.zeros((B, 26), dtype=torch.float64, device="cuda"), status=torch.zeros(B, dtype=torch.int32, device="cuda"),
+                 iters=torch.zeros(B, dtype=torch.int32, device="cuda"))
+        inp = dict(dev) if ws is None else dict(dev, working_set=ws)
+        if ws is not None:
+            o["working_set"] = torch.zeros((B, 2), dtype=torch.int64, device="cuda")
+        call = bt2.make_tick_call(inp, o, 0.002)
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(K):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / K)
+        it = (o["iters"].cpu().numpy().astype(np.int64) - base).clip(min=0)
+        ok = o["status"].cpu().numpy() == 0
+        per_wave = it[: B // 4 * 4].reshape(-1, 4).max(axis=1)
+        rec = {"inputs": "stressed" if stress else "unstressed", "open_loop_tick": name, "kernel_path": int(bt2.stat("last_path")), "ms_per_tick": float(np.median(ts)),
+               "M_ticks_per_s": B / float(np.median(ts)) / 1e3, "ineq_changes_per_instance": float(it[ok].mean()),
+               "slowest_row_per_wave_mean": float(per_wave.mean()), "slowest_row_per_wave_p99": float(np.percentile(per_wave, 99)),
+               "err_vs_cold": float((o["qdot"] - cold["qdot"]).abs()[torch.from_numpy(ok).cuda()].max().item())}
+        out.append(rec)
+        print(json.dumps(rec), flush=True)
+bt2.close()
