@@ -50,6 +50,8 @@ struct WbcBatch {
   int packed_kernel;     // 1 (default): eligible batches run four instances per wavefront (wbc_tick_sim3p_kernel)
   int warm_start;        // 1: wbc_rollout carries each instance's working set from tick to tick (default 0: measured slower)
   int32_t* d_defer;      // [1 + max_batch]: count + compact list of the instances the sim3 kernel deferred (lazy)
+  unsigned long long* d_dstat;   // packed kernel: (launch sequence, instances its tail redid on the general path) (lazy)
+  uint32_t tick_seq;
   int packed_update, last_update_packed;   // option: wbc_update_packed_kernel where every plan allows it [1]; what the last update ran on
   int last_orth;         // the last general-kernel tick ran the variant with the orthonormal contact presolve
   int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass)
@@ -192,6 +194,7 @@ extern "C" void wbc_batch_destroy(WbcBatch* b) {
   if (b->d_roll) (void)hipFree(b->d_roll);
   if (b->d_status) (void)hipFree(b->d_status);
   if (b->d_defer) (void)hipFree(b->d_defer);
+  if (b->d_dstat) (void)hipFree(b->d_dstat);
   delete b;
 }
 
@@ -413,6 +416,14 @@ extern "C" int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, i
   if (!strcmp(name, "last_orth")) { *out = b->last_path == 0 ? b->last_orth : 0; return WBC_OK; }
   if (!strcmp(name, "deferred_last")) {      // waits for `stream`
     *out = 0;
+    if (b->last_path == 2) {                 // packed kernel: instances its tail redid on the general path in the last launch
+      if (!b->d_dstat) return WBC_OK;
+      unsigned long long v = 0;
+      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      HIP_TRY(hipMemcpy(&v, b->d_dstat, sizeof v, hipMemcpyDeviceToHost));
+      *out = ((uint32_t)(v >> 32) == b->tick_seq) ? (int64_t)(v & 0xFFFFFFFFull) : 0;
+      return WBC_OK;
+    }
     if (!b->d_defer || !b->last_path) return WBC_OK;
     int32_t c = 0;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -595,7 +606,7 @@ static int launch_update_auto(WbcBatch* b, UpdateArgs& u, int B, void* stream) {
 }
 static bool packed_eligible(const WbcBatch* b, const KernelArgs& a) {
   bool packed = b->packed_kernel && !a.in.q_con && !a.in.posture_u &&
-                !b->force_defer && !b->count_pivoted && !(b->dbg_stop > 0 && b->dbg_stop < 100) && !b->dbg_alias;   // (dbg_stop 101.. cuts the packed kernel)
+                !b->count_pivoted && !(b->dbg_stop > 0 && b->dbg_stop < 100) && !b->dbg_alias;   // (dbg_stop 101.. cuts the packed kernel)
   for (int i = 0; i < b->n_models && packed; ++i) packed = b->plan_host[i].packed_ok != 0;
   return packed;
 }
@@ -635,10 +646,19 @@ static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
     a.pivot_count = b->d_defer + 1 + b->max_batch;
     HIP_TRY(hipMemsetAsync(a.pivot_count, 0, sizeof(int32_t), (hipStream_t)stream));
   }
-  if (packed_eligible(b, a)) {
+  if (packed_eligible(b, a)) {   // ONE kernel per tick: what the packed kernel cannot reduce its own wave redoes on the general path
     b->last_path = 2;
+    if (!b->d_dstat) {
+      HIP_TRY(hipMalloc((void**)&b->d_dstat, sizeof(unsigned long long)));
+      HIP_TRY(hipMemsetAsync(b->d_dstat, 0, sizeof(unsigned long long), (hipStream_t)stream));
+    }
+    a.defer_stat = b->d_dstat;
+    a.tick_seq = ++b->tick_seq;
+    if (!b->tick_seq) a.tick_seq = ++b->tick_seq;          // (0 is the cleared word's sequence number)
     if (int e = launch_tick_sim3p(a, stream)) return fail(WBC_E_HIP, "packed sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
-  } else if (int e = launch_tick_sim3(a, B, stream)) return fail(WBC_E_HIP, "sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return WBC_OK;
+  }
+  if (int e = launch_tick_sim3(a, B, stream)) return fail(WBC_E_HIP, "sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   if (int e = launch_tick_deferred(a, stream)) {
     // the list the sim3 kernel may have filled stays behind: empty it, or the next tick appends after a stale count
     (void)hipMemsetAsync(b->d_defer, 0, sizeof(int32_t), (hipStream_t)stream);

@@ -468,6 +468,44 @@ def test_pivoted_elimination_and_second_pass_match_the_oracle(wx200, px100, tol_
     bt.close()
 
 
+@pytest.mark.parametrize("tol_exp,warm", [(0, 0), (3, 0), (3, 1)])
+def test_packed_kernel_redoes_what_it_cannot_reduce_in_its_own_tail(wx200, px100, tol_exp, warm):
+    """The packed kernel launches no second pass: an instance it leaves out (a stance-leg block of rank < 2; here every flagged block, through
+    dbg_force_defer, with the bar for "flagged" lowered by presolve_tol_exp) is redone by its own wave on the general path at the end of the
+    SAME kernel. Count as predicted from the oracle's constraint rows, answers the oracle's — cold and with working sets in and out."""
+    B = 3001
+    models = [wx200, px100]
+    cfgs = [common.config("c3", m) for m in models]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=83 + i) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
+    ratio = _leg_block_ratio(oracle.assemble(models, cfgs, d, DT, B))
+    expect = int((ratio <= 10.0 ** -tol_exp).sum())
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    bt.set_option("presolve_tol_exp", tol_exp)
+    bt.set_option("dbg_force_defer", 1)
+    got = bt.tick(d, DT, want_q_next=True, want_working_set=bool(warm))
+    assert bt.stat("last_path") == 2
+    n = bt.stat("deferred_last")
+    print("packed, tol 1e-%d, warm %d: %d of %d instances redone in the tail (predicted %d)" % (tol_exp, warm, n, B, expect))
+    assert n > 0 and abs(n - expect) <= max(2, expect // 200) and (n == B if tol_exp == 0 else n < B)
+    ok = ref["status"] == 0
+    assert (got["status"] == ref["status"]).all() and ok.mean() > 0.9
+    assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL and np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    if warm:      # the tail's working sets are the packed rows' (full-problem indexing on every path): seeding the next tick with them works
+        again = bt.tick(dict(d, working_set=got["working_set"]), DT, want_working_set=True)
+        assert (again["status"] == ref["status"]).all() and np.abs(again["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+        assert (again["working_set"][ok] == got["working_set"][ok]).all(axis=1).mean() > 0.98
+    bt.set_option("dbg_force_defer", 0)
+    bt.tick(d, DT)
+    assert bt.stat("last_path") == 2 and bt.stat("deferred_last") == 0      # (the statistic is per launch: nothing carried over)
+    bt.close()
+
+
 @pytest.mark.parametrize("cfg_name", ["c2", "everything", "c3"])
 def test_tick_and_assemble_on_the_matrix_cores(wx200, cfg_name):
     """Option jtj_mfma: H = A'A of wbc_assemble / wbc_tick from v_mfma_f64_16x16x4_f64 (QP_Wrapper.py:17) against the oracle,
