@@ -48,6 +48,7 @@ struct WbcBatch {
   int dbg_alias, dbg_stop;
   int count_pivoted, force_defer;   // diagnostics of the sim3 kernel's pivoted elimination / second pass
   int packed_kernel;     // 1 (default): eligible batches run four instances per wavefront (wbc_tick_sim3p_kernel)
+  int packed_orth;       // 1 (default): equality-only task problems run four instances per wavefront (wbc_tick_orthp_kernel)
   int warm_start;        // 1: wbc_rollout carries each instance's working set from tick to tick (default 0: measured slower)
   int32_t* d_defer;      // [1 + max_batch]: count + compact list of the instances the sim3 kernel deferred (lazy)
   unsigned long long* d_dstat;   // packed kernel: (launch sequence, instances its tail redid on the general path) (lazy)
@@ -150,7 +151,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
   b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->presolve_orth = 1; b->packed_update = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
-  b->jtj_mfma = -1; b->warm_start = 0; b->packed_kernel = 1;
+  b->jtj_mfma = -1; b->warm_start = 0; b->packed_kernel = 1; b->packed_orth = 1;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
@@ -254,6 +255,78 @@ static void build_posture_plan(const DevModel& M, const WbcConfig& c, DevPlan* P
   P->post_fk2 = dep ? 1 : 0;
 }
 
+// The packed orth kernel's plan (wbc_tick_orthp_kernel): equality-only task problems — the only constraints are the eliminated stance
+// feet's contact rows (no trunk / CoM box, no velocity box), tasks = any EE tasks + optionally the CoM task + posture Tikhonov / PREV.
+static void build_orthp_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) {
+  P->q_ok = 0;
+  const int nelim = P->nelim, nl = 3 * nelim;
+  if (!P->orth || c.use_bounds || c.con_trunk || c.con_com || c.task_trunk || P->p_keep != 0 || nelim < 1 || nelim > 4) return;
+  if (c.task_joint != WBC_JOINT_TIKHONOV && c.task_joint != WBC_JOINT_PREV) return;
+  if (M.njoints > 22 || M.maxdepth > 7 || P->n_red > 15) return;
+  for (int i = 0; i < 32; ++i) { P->q_scq[i] = -1; memset(&P->q_dof[i], 0, sizeof P->q_dof[i]); P->q_dof[i].bl = P->q_dof[i].red = -1; memset(&P->q_jm[i], 0, sizeof P->q_jm[i]); }
+  for (int i = 0; i < 18; ++i) P->q_bl2dof[i] = 0;
+  for (int i = 0; i < 16; ++i) P->q_red2dof[i] = 0;
+  for (int e = 0; e < 8; ++e) P->q_efoot[e] = -1;
+  // FK schedule: every joint of depth 2 .. 7
+  for (int L = 0; L < 6; ++L) {
+    int cnt = 0;
+    for (int i = 0; i < 16; ++i) { memset(&P->q_fk[L][i], 0, sizeof P->q_fk[L][i]); P->q_fk[L][i].joint = -1; }
+    for (int j = 2; j < M.njoints; ++j)
+      if (M.depth[j] == L + 2) {
+        if (cnt >= 16) return;
+        DevPlan::PkJoint& r = P->q_fk[L][cnt++];
+        const bool rev = M.jtype[j] >= WBC_JT_RX && M.jtype[j] <= WBC_JT_RZ;
+        r.joint = j; r.parent = M.parent[j]; r.a0 = 3 * M.ax0[j]; r.a1 = 3 * M.ax1[j]; r.a2 = 3 * M.ax2[j];
+        r.rev = rev ? 1 : 0; r.q_idx = M.idx_q[j]; r.t0 = M.tp[j][0]; r.t1 = M.tp[j][1]; r.t2 = M.tp[j][2];
+        if (rev) P->q_scq[j] = M.idx_q[j];
+      }
+  }
+  for (int j = 1; j < M.njoints; ++j) { P->q_jm[j].m = M.mass[j]; P->q_jm[j].c0 = M.com[j][0]; P->q_jm[j].c1 = M.com[j][1]; P->q_jm[j].c2 = M.com[j][2]; }
+  // DoF records: [base; eliminated legs] positions, reduced (free) variables 6.., subtree = a contiguous joint range (depth-first numbering)
+  int nred = 6;
+  uint32_t freemask = 0;
+  for (int d = 0; d < M.nv; ++d) {
+    DevPlan::QDof& r = P->q_dof[d];
+    const int j = M.col_joint[d];
+    r.joint = j; r.lin = M.col_lin[d]; r.ang = M.col_ang[d];
+    if (d < 6) r.bl = d;
+    else if (P->lidx[d] >= 0) r.bl = 6 + P->lidx[d];
+    else { if (nred >= 15) return; r.red = nred; P->q_red2dof[nred++] = d; freemask |= 1u << d; }
+    if (r.bl >= 0) P->q_bl2dof[r.bl] = d;
+    const uint32_t sub = M.col_subtree[d];
+    int lo = -1, hi = -1, cntj = 0;
+    for (int k = 1; k < M.njoints; ++k) if ((sub >> k) & 1u) { if (lo < 0) lo = k; hi = k; ++cntj; }
+    if (lo < 0 || hi - lo + 1 != cntj) return;                    // not contiguous
+    if (j != 1 && cntj > 8) return;                               // the kernel's sub-tree loop
+    r.sub_lo = lo; r.sub_hi = hi;
+    for (int e = 0; e < WBC_NEE; ++e) if ((M.frame_support[WBC_FR_EE0 + e] >> d) & 1u) r.supmask |= 1u << e;
+  }
+  if (nred != P->n_red) return;
+  P->q_nred = nred;
+  // EE tasks: support = base + (one eliminated foot's own leg | free variables)
+  P->q_armsup = 0;
+  uint32_t legall = 0;
+  for (int l = 0; l < nl; ++l) legall |= 1u << P->legd[l];
+  for (int e = 0; e < WBC_NEE; ++e) {
+    if (!c.task_ee[e]) continue;
+    const uint32_t sup = M.frame_support[WBC_FR_EE0 + e];
+    if (M.depth[M.frame_joint[WBC_FR_EE0 + e]] > 7) return;
+    if (sup & freemask) P->q_armsup |= 1u << e;
+    const uint32_t legs = sup & legall;
+    if (sup & ~(0x3Fu | legall | freemask)) return;
+    if (legs) {
+      int f = -1;
+      for (int t = 0; t < nelim; ++t) {
+        const uint32_t own = (1u << P->legd[3 * t]) | (1u << P->legd[3 * t + 1]) | (1u << P->legd[3 * t + 2]);
+        if (legs == own) f = t;
+      }
+      if (f < 0) return;
+      P->q_efoot[e] = f;
+    }
+  }
+  P->q_ok = 1;
+}
+
 static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan* P) {
   memset(P, 0, sizeof *P);
   build_posture_plan(M, c, P);
@@ -305,7 +378,7 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
     }
   }
   P->nelim = nelim; P->n_red = n_red; P->p_keep = p_keep;
-  if (!clean) { P->orth = 1; return; }
+  if (!clean) { P->orth = 1; build_orthp_plan(M, c, P); return; }
   P->enabled = 1;
   // ---- the packed kernel (wbc_tick_sim3p_kernel) covers the sim3 switch-set family only: Grip task or none, no trunk / CoM
   // task, the kept rows = the trunk box (base support only), velocity bounds on, a posture mode it can form itself, every
@@ -393,6 +466,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!strcmp(name, "presolve_tol_exp")) { double t = 1.0; for (int i = 0; i < value; ++i) t *= 0.1; b->sing_tol = t; return WBC_OK; }
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
   if (!strcmp(name, "packed_kernel")) { b->packed_kernel = value; return WBC_OK; }
+  if (!strcmp(name, "packed_orth")) { b->packed_orth = value; return WBC_OK; }
   if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
   if (!strcmp(name, "warm_start")) { b->warm_start = value != 0; return WBC_OK; }
   if (!strcmp(name, "count_pivoted")) { b->count_pivoted = value != 0; return WBC_OK; }
@@ -413,10 +487,10 @@ extern "C" int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, i
   HIP_TRY(hipSetDevice(b->device_id));
   if (!strcmp(name, "last_path")) { *out = b->last_path; return WBC_OK; }
   if (!strcmp(name, "last_update_packed")) { *out = b->last_update_packed; return WBC_OK; }
-  if (!strcmp(name, "last_orth")) { *out = b->last_path == 0 ? b->last_orth : 0; return WBC_OK; }
+  if (!strcmp(name, "last_orth")) { *out = (b->last_path == 0 || b->last_path == 3) ? b->last_orth : 0; return WBC_OK; }
   if (!strcmp(name, "deferred_last")) {      // waits for `stream`
     *out = 0;
-    if (b->last_path == 2) {                 // packed kernel: instances its tail redid on the general path in the last launch
+    if (b->last_path >= 2) {                 // packed kernels: instances the tail redid on the general path in the last launch
       if (!b->d_dstat) return WBC_OK;
       unsigned long long v = 0;
       HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -441,6 +515,7 @@ extern "C" int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, i
     return WBC_OK;
   }
   if (!strcmp(name, "sim3_lds_bytes")) { *out = sim3_lds_bytes(); return WBC_OK; }
+  if (!strcmp(name, "orthp_lds_bytes")) { *out = orthp_lds_bytes(); return WBC_OK; }
   if (!strcmp(name, "tick_lds_bytes")) { *out = tick_lds_bytes(); return WBC_OK; }
   return fail(WBC_E_ARG, "unknown statistic %s", name);
 }
@@ -622,7 +697,32 @@ static bool sim3_eligible(const WbcBatch* b, const KernelArgs& a) {
   }
   return true;
 }
+// the packed orth kernel: every plan q_ok, nothing passed that it does not read (orientation references, caller's posture target /
+// constraint state, working sets), the orthonormal presolve on, no forced matrix-core contraction
+static bool orthp_eligible(const WbcBatch* b, const KernelArgs& a) {
+  if (!b->packed_orth || !b->packed_kernel || !b->presolve || !b->presolve_orth || b->n_models < 1 || b->jtj_mfma > 0) return false;
+  if (a.ws_in || a.ws_out || a.in.q_con || a.in.posture_u || a.in.ee_ref_rot || b->dbg_alias || b->dbg_stop) return false;
+  for (int i = 0; i < b->n_models; ++i) if (!b->plan_host[i].q_ok) return false;
+  return true;
+}
 static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
+  if (orthp_eligible(b, a)) {   // ONE kernel per tick; last_path 3
+    b->last_path = 3;
+    b->last_orth = 1;
+    if (!a.out.status) {
+      if (!b->d_status) HIP_TRY(hipMalloc((void**)&b->d_status, sizeof(int32_t) * (size_t)b->max_batch));
+      a.out.status = b->d_status;
+    }
+    if (!b->d_dstat) {
+      HIP_TRY(hipMalloc((void**)&b->d_dstat, sizeof(unsigned long long)));
+      HIP_TRY(hipMemsetAsync(b->d_dstat, 0, sizeof(unsigned long long), (hipStream_t)stream));
+    }
+    a.defer_stat = b->d_dstat;
+    a.tick_seq = ++b->tick_seq;
+    if (!b->tick_seq) a.tick_seq = ++b->tick_seq;
+    if (int e = launch_tick_orthp(a, stream)) return fail(WBC_E_HIP, "packed orth tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return WBC_OK;
+  }
   if (!sim3_eligible(b, a)) {
     b->last_path = 0;
     b->last_orth = a.presolve && a.presolve_orth == 2 && !(a.ws_in || a.ws_out);

@@ -46,6 +46,17 @@ struct DevPlan {
   PkJoint pk_fk[5][16];              // joints of tree depth 2 + L, one per lane-in-instance (joint -1: none)
   PkCol pk_var[16], pk_leg[16];      // reduced variable s / eliminated leg DoF s
   int32_t pk_scq[32];                // joint j (>= 2): q index of its angle if it is a revolute joint the FK needs, else -1
+  // packed orth kernel (wbc_tick_orthp_kernel, round 3): the equality-only task problems (BASELINE configs[1]) four instances per wavefront
+  int32_t q_ok, q_nred, q_armsup, q_pad_;   // eligible; n' = 6 + free DoF outside base and stance legs (<= 15); bit e: EE task e touches a free (arm) variable
+  struct QDof { int32_t joint, lin, ang, bl, red, sub_lo, sub_hi, supmask; };   // DoF d: Jacobian column; position in [base; stance legs] (-1: none);
+                                                                                // reduced variable (>= 6, -1: none); joints of its subtree [lo, hi]; bit e: moves EE frame e
+  struct QJnt { double m, c0, c1, c2; };    // joint j: mass and centre of mass of its body (joint frame)
+  PkJoint q_fk[6][16];               // joints of tree depth 2 + L (all of them: the CoM needs every body)
+  int32_t q_scq[32];                 // joint j: q index of its angle (revolute), else -1
+  QDof q_dof[32];
+  QJnt q_jm[32];
+  int32_t q_bl2dof[18], q_red2dof[16];
+  int32_t q_efoot[8];                // EE e: index of its leg among the eliminated feet (-1: not an eliminated foot)
   uint32_t elimrows;                 // bit i: constraint row i belongs to an eliminated foot
   uint32_t legrows;                  // bit i: kept constraint row i has support on eliminated leg DoF (needs C Z)
   // qpJointb "MANI"/"HYBRID" when EVERY finite difference is structurally zero (the perturbed joint is not a proper ancestor
@@ -150,6 +161,8 @@ struct UpdateArgs {
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream);
 int launch_tick_sim3(const KernelArgs& a, int grid, void* stream);
 int launch_tick_sim3p(const KernelArgs& a, void* stream);      // packed: four instances per wavefront, grid = ceil(B / 4)
+int launch_tick_orthp(const KernelArgs& a, void* stream);      // packed orth kernel (equality-only task problems), grid = ceil(B / 4)
+int orthp_lds_bytes();
 int sim3p_lds_bytes();
 int launch_tick_deferred(const KernelArgs& a, void* stream);   // general path for the instances the sim3 kernel deferred
 int sim3_lds_bytes();

@@ -4487,6 +4487,553 @@ __global__ void __launch_bounds__(64) wbc_update_packed_kernel(const UpdateArgs 
   // (old_ref_trunk_rot_matrix, :996, only moves with the trunk task on — which pk_update_ok excludes)
 }
 
+// ================================================================================================
+// The PACKED ORTH kernel (round 3): FOUR instances per wavefront for the task problems whose only constraints are the stance feet's
+// contact equalities — BASELINE configs[1] (five EE tasks + CoM task + posture, 12 contact rows, no bounds, no inequalities).
+// The contact rows are eliminated through the orthonormal null-space basis of contact_presolve_orth (Z = [I; G] S,
+// S = L^-T, L L' = I + G'G, G = -K^-1 B; [qd_base; qd_legs] = Z y), which leaves an UNCONSTRAINED problem in n' = 6 + (free DoF outside base
+// and stance legs) = 14 / 13 unknowns:  H' = (A Z)'(A Z) + d^2 I,  g' = -(A Z)'b (+ Z'g_posture),  H' y = -g',  qd = Z y.
+// lane = 16 r + s: instance r of the wave; s = FK slot / DoF column s and 16 + s / reduced variable s. Stages:
+//   FK         level-synchronous over DevPlan.q_fk (all joints: the CoM needs every body), sin / cos two per lane;
+//   columns    lane s owns the WORLD Jacobian columns of DoF s and 16 + s, and their CoM-Jacobian columns (subtree sums over the contiguous joint
+//              range of the DoF's subtree, Robot_Wrapper4.py:670 / Robot_Wrapper2.py:600-603);
+//   basis      G on 12 lanes (adjugate), M = I + G'G on 6, its 6 x 6 Cholesky factor and inverse unrolled on every lane, Z to LDS;
+//   tasks      one block of six rows at a time (qpA / qpb order, Robot_Wrapper4.py:1271-1294): the block's rows over [base; legs] -> LDS,
+//              A Z for the six base-reduced variables on 12 lanes (3 rows each), H' rows and g' accumulated in registers;
+//   solve      the packed kernel's two-column Cholesky sweep fused with the forward substitutions (lane s: e_s; lane 15: g'), then
+//              y = -L^-T (L^-1 g') as one dot product per lane against the broadcast L^-1 g' — no matrix ever goes back to LDS.
+// An instance with a (nearly) rank-deficient leg block is redone by its own wave on the general path (the ORTH variant's QR) in the tail.
+// ================================================================================================
+constexpr int QLEV = 6;
+struct __attribute__((aligned(16))) QInst {
+  double X[272];            // oMi [22][12] -> Kb [12][4] @0, Bb [6][4] @48, G [12][6] @72, M [6][6] @144 -> task block Ab [6][18] @0, AZ [6][16] @108
+  double W[136];            // sin / cos [22][2] @0, m c [22][4] @44 -> Z [18][6] @0
+  double in[64];            // q [27] @0, ee_target [15] @28, prev_ee_target [15] @43, com_target [3] @58, com_target_vel [3] @61
+  double pf[16];            // EE frame origins [5][3]
+  double cl[32], yv[32];    // Cholesky column pair (entries 16..31 stay zero)
+  double zv[16], xv[16];    // g' -> L^-1 g';  y -> base twist * dt
+  double gp[32];            // posture part of g by DoF -> qdot by DoF
+};
+static_assert(sizeof(QInst) * 4 <= 20480, "8 waves per CU");
+
+__global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs A, const DevModel* __restrict__ models,
+                                                               const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
+  __shared__ union { QInst Q[4]; Smem G; } SU;
+  const int lane = threadIdx.x, r = lane >> 4, s = lane & 15, rbase = lane & 48;
+  QInst& I = SU.Q[r];
+  const int b_raw = 4 * blockIdx.x + r;
+  const bool valid = b_raw < A.B;
+  const int b = valid ? b_raw : A.B - 1;
+  int mid = 0;
+  if (A.in.model_id) { mid = A.in.model_id[b]; mid = mid < 0 ? 0 : (mid >= A.n_models ? A.n_models - 1 : mid); }
+  const DevModel& M = models[mid];
+  const WbcConfig& cfg = cfgs[mid];
+  const DevPlan& P = plans[mid];
+  const double dt = A.dt, inv_dt = 1.0 / A.dt;
+  // ---- loads: inputs (coalesced per instance), then the per-lane records
+  {
+    const double* qg = A.in.q + (size_t)b * NQ;
+    const double q0 = qg[s], q1 = (16 + s < NQ) ? qg[16 + s] : 0.0;
+    const double et = (s < 15 && A.in.ee_target) ? A.in.ee_target[(size_t)b * 15 + s] : 0.0;
+    const double ep = (s < 15 && A.in.prev_ee_target) ? A.in.prev_ee_target[(size_t)b * 15 + s] : 0.0;
+    double cm = 0.0;
+    if (s < 3) cm = A.in.com_target ? A.in.com_target[(size_t)b * 3 + s] : 0.0;
+    else if (s < 6) cm = A.in.com_target_vel ? A.in.com_target_vel[(size_t)b * 3 + (s - 3)] : 0.0;
+    I.in[s] = q0;
+    if (16 + s < 28) I.in[16 + s] = q1;
+    if (s < 15) { I.in[28 + s] = et; I.in[43 + s] = ep; }
+    if (s < 6) I.in[58 + s] = cm;
+    I.cl[s] = 0.0; I.cl[16 + s] = 0.0; I.yv[s] = 0.0; I.yv[16 + s] = 0.0;
+  }
+  const int nv = M.nv, nq = M.nq, nj = M.njoints, n = P.q_nred, nelim = P.nelim, nl = 3 * nelim;
+  const DevPlan::QDof D0 = P.q_dof[s], D1 = P.q_dof[16 + s];
+  const DevPlan::QJnt Jm0 = P.q_jm[s], Jm1 = P.q_jm[16 + s];
+  DevPlan::PkJoint fkn = P.q_fk[0][s];
+  const int scq0 = P.q_scq[(2 + s) & 31], scq1 = P.q_scq[(18 + s) & 31];
+  const bool has1 = 16 + s < nv;                                  // this lane's second DoF exists
+  const bool c_com = cfg.task_com != 0;
+  const int c_task_joint = cfg.task_joint;
+  const double joint_w = cfg.joint_w;
+  const int fjoint = (s < 5) ? M.frame_joint[WBC_FR_EE0 + s] : 1;
+  const double fp0 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][0] : 0.0, fp1 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][1] : 0.0,
+               fp2 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][2] : 0.0;
+  WSYNC();
+  const double* const qv = I.in;
+  double* const oMi = I.X;                   // [22][12]
+  double* const sc = I.W;                    // sin / cos of joint j at 2 j
+  double* const mc = I.W + 44;               // m_j c_j (world), m_j at 4 j
+  {
+    if (scq0 >= 0) { const SinCos t = sincos_cw(qv[scq0]); sc[2 * (2 + s)] = t.s; sc[2 * (2 + s) + 1] = t.c; }
+    if (scq1 >= 0) { const SinCos t = sincos_cw(qv[scq1]); sc[2 * (18 + s)] = t.s; sc[2 * (18 + s) + 1] = t.c; }
+    if (s == 0) {   // root free-flyer (joint 1): R from the quaternion as Eigen's toRotationMatrix, p = xyz; R column-major then p
+      double Rt[9];
+      quat_to_R(qv + 3, Rt);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) oMi[12 + 3 * c + rr] = Rt[3 * rr + c];
+      oMi[12 + 9] = qv[0]; oMi[12 + 10] = qv[1]; oMi[12 + 11] = qv[2];
+    }
+  }
+  WSYNC();
+  // ---- pin.forwardKinematics, level by level (Robot_Wrapper4.py:400)
+#pragma unroll 1
+  for (int L = 0; L < QLEV; ++L) {
+    const DevPlan::PkJoint fk = fkn;
+    if (L + 1 < QLEV) fkn = P.q_fk[L + 1][s];
+    const int j = fk.joint;
+    if (j >= 0) {
+      const bool rev = fk.rev != 0;
+      const int a0 = fk.a0, a1 = fk.a1, a2 = fk.a2;
+      const double* Pp = oMi + 12 * fk.parent;
+      const double sn = rev ? sc[2 * j] : 0.0, cs = rev ? sc[2 * j + 1] : 1.0;
+      const double pris = rev ? 0.0 : qv[fk.q_idx];
+      double Av[3], Bv[3], Cv[3], Pv[3];
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) { Av[rr] = Pp[a0 + rr]; Bv[rr] = Pp[a1 + rr]; Cv[rr] = Pp[a2 + rr]; Pv[rr] = Pp[9 + rr]; }
+      double* Po = oMi + 12 * j;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        Po[a0 + rr] = Av[rr];
+        Po[a1 + rr] = cs * Bv[rr] + sn * Cv[rr];
+        Po[a2 + rr] = cs * Cv[rr] - sn * Bv[rr];
+        Po[9 + rr] = Pv[rr] + Av[rr] * (fk.t0 + pris) + Bv[rr] * fk.t1 + Cv[rr] * fk.t2;
+      }
+    }
+    WSYNC();
+  }
+  // ---- frame origins (updateFramePlacements, :405), m c per joint, Jacobian columns (WORLD) of DoF s and 16 + s
+  double ms_l = 0.0, sl[3] = {0, 0, 0};
+  {
+    if (s < 5) {
+      const double* Pg = oMi + 12 * fjoint;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) I.pf[3 * s + rr] = Pg[9 + rr] + Pg[rr] * fp0 + Pg[3 + rr] * fp1 + Pg[6 + rr] * fp2;
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int j = s + 16 * hh;
+      const DevPlan::QJnt& Jm = hh ? Jm1 : Jm0;
+      if (j >= 1 && j < nj) {
+        const double* Pj = oMi + 12 * j;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          const double v = Jm.m * (Pj[9 + rr] + Pj[rr] * Jm.c0 + Pj[3 + rr] * Jm.c1 + Pj[6 + rr] * Jm.c2);
+          mc[4 * j + rr] = v; sl[rr] += v;
+        }
+        mc[4 * j + 3] = Jm.m; ms_l += Jm.m;
+      }
+    }
+  }
+  double lin0[3] = {0, 0, 0}, ang0[3] = {0, 0, 0}, lin1[3] = {0, 0, 0}, ang1[3] = {0, 0, 0};
+  {
+    const double* Pj = oMi + 12 * D0.joint;
+    const double pj[3] = {Pj[9], Pj[10], Pj[11]};
+    if (D0.ang >= 0) { ang0[0] = Pj[3 * D0.ang]; ang0[1] = Pj[3 * D0.ang + 1]; ang0[2] = Pj[3 * D0.ang + 2]; cross3(pj, ang0, lin0); }
+    if (D0.lin >= 0) { lin0[0] = Pj[3 * D0.lin]; lin0[1] = Pj[3 * D0.lin + 1]; lin0[2] = Pj[3 * D0.lin + 2]; }
+  }
+  if (has1) {
+    const double* Pj = oMi + 12 * D1.joint;
+    const double pj[3] = {Pj[9], Pj[10], Pj[11]};
+    if (D1.ang >= 0) { ang1[0] = Pj[3 * D1.ang]; ang1[1] = Pj[3 * D1.ang + 1]; ang1[2] = Pj[3 * D1.ang + 2]; cross3(pj, ang1, lin1); }
+    if (D1.lin >= 0) { lin1[0] = Pj[3 * D1.lin]; lin1[1] = Pj[3 * D1.lin + 1]; lin1[2] = Pj[3 * D1.lin + 2]; }
+  }
+  WSYNC();   // oMi is dead: X is free
+  // ---- centre of mass and the CoM-Jacobian columns (pin.jacobianCenterOfMass): jc = (m_sub / M) (lin + ang x c_sub)
+  double com[3] = {0, 0, 0}, jc0[3] = {0, 0, 0}, jc1[3] = {0, 0, 0};
+  if (__ballot(c_com)) {
+    const double Mt = rsum16(ms_l);
+    const double St[3] = {rsum16(sl[0]), rsum16(sl[1]), rsum16(sl[2])};
+    com[0] = St[0] / Mt; com[1] = St[1] / Mt; com[2] = St[2] / Mt;
+    auto jcom = [&](const DevPlan::QDof& D, const double* lin, const double* ang, const bool on, double* jc) {
+      double ms = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+      if (D.joint == 1) { ms = Mt; s0 = St[0]; s1 = St[1]; s2 = St[2]; }          // the free-flyer moves every body
+      else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {                                             // (sub-trees of at most 8 joints: checked on the host)
+          const int j = D.sub_lo + t;
+          if (on && j <= D.sub_hi) {
+            const double2a m0 = lds2(mc + 4 * j), m1 = lds2(mc + 4 * j + 2);
+            s0 += m0.x; s1 += m0.y; s2 += m1.x; ms += m1.y;
+          }
+        }
+      }
+      if (on && ms > 0.0) {
+        const double cs_[3] = {s0 / ms, s1 / ms, s2 / ms};
+        double wxc[3];
+        cross3(ang, cs_, wxc);
+        const double f = ms / Mt;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) jc[rr] = f * (lin[rr] + wxc[rr]);
+      }
+    };
+    jcom(D0, lin0, ang0, true, jc0);
+    jcom(D1, lin1, ang1, has1, jc1);
+  }
+  // ---- contact rows (EEConstraint, :757-761: WORLD linear rows): K (leg DoF) and B (base DoF) through LDS, G = -K^-1 B
+  double* const Kb = I.X;                    // [12][4]
+  double* const Bb = I.X + 48;               // [6][4]
+  double* const Gm = I.X + 72;               // [12][6]
+  double* const Mm = I.X + 144;              // [6][6]
+  {
+    if (D0.bl >= 6) { Kb[4 * (D0.bl - 6)] = lin0[0]; Kb[4 * (D0.bl - 6) + 1] = lin0[1]; Kb[4 * (D0.bl - 6) + 2] = lin0[2]; }
+    else if (D0.bl >= 0) { Bb[4 * D0.bl] = lin0[0]; Bb[4 * D0.bl + 1] = lin0[1]; Bb[4 * D0.bl + 2] = lin0[2]; }
+    if (has1 && D1.bl >= 6) { Kb[4 * (D1.bl - 6)] = lin1[0]; Kb[4 * (D1.bl - 6) + 1] = lin1[1]; Kb[4 * (D1.bl - 6) + 2] = lin1[2]; }
+  }
+  WSYNC();
+  bool defer = false;
+  {
+    double grow[6] = {0, 0, 0, 0, 0, 0};
+    const int f = (s < nl) ? s / 3 : 0, i = (s < nl) ? s - 3 * f : 0;
+    const double* k0 = Kb + 4 * (3 * f); const double* k1 = k0 + 4; const double* k2 = k1 + 4;
+    const double k00 = k0[0], k10 = k0[1], k20 = k0[2], k01 = k1[0], k11 = k1[1], k21 = k1[2], k02 = k2[0], k12 = k2[1], k22 = k2[2];
+    const double a00 = k11 * k22 - k12 * k21, a01 = k02 * k21 - k01 * k22, a02 = k01 * k12 - k02 * k11;
+    const double a10 = k12 * k20 - k10 * k22, a11 = k00 * k22 - k02 * k20, a12 = k02 * k10 - k00 * k12;
+    const double a20 = k10 * k21 - k11 * k20, a21 = k01 * k20 - k00 * k21, a22 = k00 * k11 - k01 * k10;
+    const double det = k00 * a00 + k01 * a10 + k02 * a20;
+    const double sc_ = fabs(k00) + fabs(k01) + fabs(k02) + fabs(k10) + fabs(k11) + fabs(k12) + fabs(k20) + fabs(k21) + fabs(k22);
+    const bool bad = (s < nl) && !(fabs(det) > fmax(1e-6, A.sing_tol) * sc_ * sc_ * sc_);      // (orth_null_basis' bar: below it the QR decides)
+    defer = ((__ballot(bad) >> rbase) & 0xFFFFull) != 0 || (A.orth_qr != 0);
+    const double id = -1.0 / det;
+    const double r0 = (i == 0) ? a00 : (i == 1) ? a10 : a20, r1 = (i == 0) ? a01 : (i == 1) ? a11 : a21, r2 = (i == 0) ? a02 : (i == 1) ? a12 : a22;
+    if (s < nl) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) grow[c] = id * (r0 * Bb[4 * c] + r1 * Bb[4 * c + 1] + r2 * Bb[4 * c + 2]);
+    }
+    if (s < 12) {
+#pragma unroll
+      for (int c = 0; c < 6; c += 2) sts2(Gm + s * 6 + c, grow[c], grow[c + 1]);   // (rows >= nl: zero)
+    }
+  }
+  WSYNC();
+  if (s < 6) {                               // row s of M = I + G'G
+    double mrow[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int l = 0; l < 12; ++l) {
+      const double gl = Gm[l * 6 + s];
+      const double2a t0 = lds2(Gm + l * 6), t1 = lds2(Gm + l * 6 + 2), t2 = lds2(Gm + l * 6 + 4);
+      mrow[0] = fma(gl, t0.x, mrow[0]); mrow[1] = fma(gl, t0.y, mrow[1]); mrow[2] = fma(gl, t1.x, mrow[2]);
+      mrow[3] = fma(gl, t1.y, mrow[3]); mrow[4] = fma(gl, t2.x, mrow[4]); mrow[5] = fma(gl, t2.y, mrow[5]);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Mm[s * 6 + k] = mrow[k] + ((k == s) ? 1.0 : 0.0);
+  }
+  WSYNC();
+  // ---- L L' = M and Li = L^-1 in registers, the same on every lane of the instance (M >= I: no pivot can fail); Z = [S; G S], S = Li'
+  double* const Zm = I.W;                    // [18][6]: rows 0..5 base DoF, 6 + l eliminated leg DoF l
+  {
+    double Lm[6][6], Li[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double2a a = lds2(Mm + 6 * i), bq = lds2(Mm + 6 * i + 2), c = lds2(Mm + 6 * i + 4);
+      Lm[i][0] = a.x; Lm[i][1] = a.y; Lm[i][2] = bq.x; Lm[i][3] = bq.y; Lm[i][4] = c.x; Lm[i][5] = c.y;
+    }
+    double dinv[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double v = Lm[j][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v = fma(-Lm[j][k], Lm[j][k], v);
+      double rs = __builtin_amdgcn_rsq(v);
+      rs = rs * fma(-0.5 * v * rs, rs, 1.5); rs = rs * fma(-0.5 * v * rs, rs, 1.5);
+      dinv[j] = rs;
+      Lm[j][j] = v * rs;
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        double w = Lm[i][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) w = fma(-Lm[i][k], Lm[j][k], w);
+        Lm[i][j] = w * rs;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if (i < c) Li[i][c] = 0.0;
+        else {
+          double w = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+          for (int k = c; k < i; ++k) w = fma(-Lm[i][k], Li[k][c], w);
+          Li[i][c] = w * dinv[i];
+        }
+      }
+    }
+    double grow[6];
+    if (s < 12) {
+      const double2a a = lds2(Gm + s * 6), bq = lds2(Gm + s * 6 + 2), c = lds2(Gm + s * 6 + 4);
+      grow[0] = a.x; grow[1] = a.y; grow[2] = bq.x; grow[3] = bq.y; grow[4] = c.x; grow[5] = c.y;
+    }
+    WSYNC();                                 // (the m c table in W has been read by everyone: W becomes Z)
+    if (s < 6) {
+      double srow[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        double v = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v = (s == c) ? Li[k][c] : v;
+        srow[k] = v;
+      }
+      sts2(Zm + s * 6, srow[0], srow[1]); sts2(Zm + s * 6 + 2, srow[2], srow[3]); sts2(Zm + s * 6 + 4, srow[4], srow[5]);
+    }
+    if (s < 12) {
+      double o[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        double v = 0.0;
+#pragma unroll
+        for (int c2 = 0; c2 <= k; ++c2) v = fma(grow[c2], Li[k][c2], v);
+        o[k] = v;
+      }
+      double* zr = Zm + (6 + s) * 6;
+      sts2(zr, o[0], o[1]); sts2(zr + 2, o[2], o[3]); sts2(zr + 4, o[4], o[5]);
+    }
+  }
+  WSYNC();
+  // ---- the task stack, one block of six rows at a time
+  const int hh = s >> 3, cc = s & 7;         // A Z: lane (hh, cc < 6) forms rows 3 hh .. 3 hh + 2 of the block for base-reduced variable cc
+  double Zc[18];
+#pragma unroll
+  for (int j = 0; j < 18; ++j) Zc[j] = (cc < 6) ? Zm[j * 6 + cc] : 0.0;
+  double h[16], gacc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) h[k] = 0.0;
+  double* const Ab = I.X;                    // [6][18]
+  double* const AZ = I.X + 108;              // [6][16]
+  auto block = [&](const double* a0, const double* a1, const double* br, const int ef, const bool dense, const bool arm) {
+    WSYNC();                                 // the previous block's readers are done
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+      if (D0.bl >= 0) Ab[rr * 18 + D0.bl] = a0[rr]; else if (D0.red >= 6) AZ[rr * 16 + D0.red] = a0[rr];
+      if (has1) { if (D1.bl >= 0) Ab[rr * 18 + D1.bl] = a1[rr]; else if (D1.red >= 6) AZ[rr * 16 + D1.red] = a1[rr]; }
+      if (s >= n) AZ[rr * 16 + s] = 0.0;     // padding variables
+    }
+    WSYNC();
+    if (cc < 6) {
+      double zw[3];
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) zw[jj] = (ef == 0) ? Zc[6 + jj] : (ef == 1) ? Zc[9 + jj] : (ef == 2) ? Zc[12 + jj] : (ef == 3) ? Zc[15 + jj] : 0.0;
+      const int jl = 6 + 3 * (ef < 0 ? 0 : ef);
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        const double* row = Ab + (3 * hh + rr) * 18;
+        double acc = 0.0;
+        if (dense) {
+#pragma unroll
+          for (int j = 0; j < 18; j += 2) { const double2a v = lds2(row + j); acc = fma(v.x, Zc[j], fma(v.y, Zc[j + 1], acc)); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 6; j += 2) { const double2a v = lds2(row + j); acc = fma(v.x, Zc[j], fma(v.y, Zc[j + 1], acc)); }
+          acc = fma(row[jl], zw[0], fma(row[jl + 1], zw[1], fma(row[jl + 2], zw[2], acc)));
+        }
+        AZ[(3 * hh + rr) * 16 + cc] = acc;
+      }
+    }
+    WSYNC();
+    double own[6];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) own[rr] = AZ[rr * 16 + s];
+    gacc = fma(-own[0], br[0], fma(-own[1], br[1], fma(-own[2], br[2], fma(-own[3], br[3], fma(-own[4], br[4], fma(-own[5], br[5], gacc))))));
+    if (arm) {
+#pragma unroll
+      for (int k = 0; k < 16; k += 2) {
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) { const double2a v = lds2(AZ + rr * 16 + k); h[k] = fma(own[rr], v.x, h[k]); h[k + 1] = fma(own[rr], v.y, h[k + 1]); }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; k += 2) {
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) { const double2a v = lds2(AZ + rr * 16 + k); h[k] = fma(own[rr], v.x, h[k]); h[k + 1] = fma(own[rr], v.y, h[k + 1]); }
+      }
+    }
+  };
+  const unsigned tmask = (unsigned)__builtin_amdgcn_readfirstlane((int)P.task_ee_mask);
+  const unsigned armsup = (unsigned)__builtin_amdgcn_readfirstlane((int)P.q_armsup);
+#pragma unroll 1
+  for (unsigned tm = tmask; tm; tm &= tm - 1) {   // endEffectorA2 (:474-484) / calcTargetVelEE3 (:1052-1157) / EndEffectorB2 (:907-910)
+    const int e = __ffs((int)tm) - 1;
+    const double w = cfg.ee_w[e];
+    double Wd[6], Gd[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Wd[i] = cfg.ee_W[e][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Gd[i] = cfg.ee_gain[e][i];
+    const double pfe[3] = {I.pf[3 * e], I.pf[3 * e + 1], I.pf[3 * e + 2]};
+    const bool sup0 = (D0.supmask >> e) & 1, sup1 = has1 && ((D1.supmask >> e) & 1);
+    double a0[6], a1[6], br[6] = {0, 0, 0, 0, 0, 0}, wxp[3];
+    cross3(ang0, pfe, wxp);
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) { a0[rr] = sup0 ? Wd[rr] * ((lin0[rr] + wxp[rr]) * w) : 0.0; a0[3 + rr] = sup0 ? Wd[3 + rr] * (ang0[rr] * w) : 0.0; }
+    cross3(ang1, pfe, wxp);
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) { a1[rr] = sup1 ? Wd[rr] * ((lin1[rr] + wxp[rr]) * w) : 0.0; a1[3 + rr] = sup1 ? Wd[3 + rr] * (ang1[rr] * w) : 0.0; }
+    const double* xt = I.in + 28 + 3 * e;
+    const double* xp = I.in + 43 + 3 * e;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) br[i] = ((xt[i] - xp[i]) * inv_dt + Gd[i] * ((xt[i] - pfe[i]) * inv_dt)) * w;
+    block(a0, a1, br, P.q_efoot[e], false, (armsup >> e) & 1u);
+  }
+  if (__ballot(c_com)) {   // Robot_Wrapper2 comJacobian (:600-603), cartesianTargetCoM (:661-668)
+    double a0[6] = {0, 0, 0, 0, 0, 0}, a1[6] = {0, 0, 0, 0, 0, 0}, br[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      const double cw = cfg.com_W[rr];
+      a0[rr] = cw * jc0[rr]; a1[rr] = has1 ? cw * jc1[rr] : 0.0;
+      br[rr] = I.in[61 + rr] + cfg.com_gain[rr] * (I.in[58 + rr] - com[rr]);
+    }
+    block(a0, a1, br, -1, true, true);
+  }
+  // posture rows (qpJointA / qpJointb, :1199-1268): Z'(d^2 I)Z = d^2 I; the target's part of g through Z
+  const double dpost = (1.0 / nv) * joint_w;
+  if (__ballot(c_task_joint == WBC_JOINT_PREV)) {
+    WSYNC();
+    const bool prev = c_task_joint == WBC_JOINT_PREV;
+    I.gp[s] = prev ? -dpost * ((1.0 / nv) * qv[s < 6 ? s : s + 1] * joint_w) : 0.0;
+    I.gp[16 + s] = (prev && has1) ? -dpost * ((1.0 / nv) * qv[17 + s] * joint_w) : 0.0;
+    WSYNC();
+    if (s < 6) {
+#pragma unroll
+      for (int j = 0; j < 18; ++j) gacc = fma(Zc[j], I.gp[P.q_bl2dof[j] & 31], gacc);
+    } else if (s < n) gacc += I.gp[P.q_red2dof[s] & 31];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) if (k == s) h[k] += (s < n) ? dpost * dpost : 1.0;
+  if (s >= n) gacc = 0.0;
+  bool live = valid && !defer;
+  // ---- Cholesky H' = L L' fused with the substitutions: lane s: L y = e_s (row s of L^-T); lane 15 (a padding variable): L y = g'
+  WSYNC();
+  I.zv[s] = gacc;
+  WSYNC();
+  double y[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) y[k] = (s == 15) ? I.zv[k] : ((k == s) ? 1.0 : 0.0);
+  double pmin = 1.0;
+#pragma unroll 1
+  for (int j = 0; j < 16; j += 2) {
+    WSYNC();
+    I.cl[s] = h[0]; I.yv[s] = h[1];
+    WSYNC();
+    const double* c0 = I.cl + j;
+    const double* c1 = I.yv + j;
+    const double pj = c0[0];
+    pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;
+    const double rinv = rsqrt(pj), ipj = rinv * rinv;
+    double cm0[16], cm1[16];
+#pragma unroll
+    for (int rr = 1; rr < 16; ++rr) { cm0[rr] = c0[rr]; cm1[rr] = c1[rr]; }
+    const double th = h[0] * ipj, ty = y[0] * ipj, yk = y[0] * rinv;
+    const double h1 = fma(-th, cm0[1], h[1]), y1 = fma(-ty, cm0[1], y[1]);
+    const double a = cm0[1];
+#pragma unroll
+    for (int rr = 1; rr < 16; ++rr) cm1[rr] = fma(-(cm0[rr] * ipj), a, cm1[rr]);
+    const double pj2 = cm1[1];
+    pmin = (pj2 > 0.0) ? fmin(pmin, pj2) : -1.0;
+    const double rinv2 = rsqrt(pj2), ipj2 = rinv2 * rinv2;
+    const double th2 = h1 * ipj2, ty2 = y1 * ipj2, yk2 = y1 * rinv2;
+#pragma unroll
+    for (int rr = 2; rr < 16; ++rr) h[rr - 2] = fma(-th2, cm1[rr], fma(-th, cm0[rr], h[rr]));
+#pragma unroll
+    for (int rr = 2; rr < 16; ++rr) y[rr - 2] = fma(-ty2, cm1[rr], fma(-ty, cm0[rr], y[rr]));
+    y[14] = fma(-ty2, 0.0, yk); y[15] = yk2;
+    h[14] = 0.0; h[15] = 0.0;
+  }
+  int status = WBC_QP_OPTIMAL;
+  if (!(pmin > 0.0)) status = WBC_QP_NUMERICAL;
+  WSYNC();
+  if (s == 15) {
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) sts2(I.zv + k, y[k], y[k + 1]);
+  }
+  WSYNC();
+  double x = 0.0;
+  {
+    double xa = 0.0, xb = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) { const double2a v2 = lds2(I.zv + k); xa = fma(y[k], v2.x, xa); xb = fma(y[k + 1], v2.y, xb); }
+    x = (s < n) ? -(xa + xb) : 0.0;
+  }
+  if (status == WBC_QP_OPTIMAL) {
+    const unsigned long long bad = __ballot(s < n && !(fabs(x) <= 1.7976931348623157e308));
+    if ((bad >> rbase) & 0xFFFFull) status = WBC_QP_NUMERICAL;
+  }
+  if (status != WBC_QP_OPTIMAL) x = 0.0;
+  // ---- qd = Z y by DoF, outputs
+  I.xv[s] = x;
+  WSYNC();
+  {
+    auto qd_of = [&](const DevPlan::QDof& D, const bool on) -> double {
+      double v = 0.0;
+      if (on && D.bl >= 0) {
+        const double2a z0 = lds2(Zm + D.bl * 6), z1 = lds2(Zm + D.bl * 6 + 2), z2 = lds2(Zm + D.bl * 6 + 4);
+        const double2a v0 = lds2(I.xv), v1 = lds2(I.xv + 2), v2 = lds2(I.xv + 4);
+        v = fma(z0.x, v0.x, fma(z0.y, v0.y, fma(z1.x, v1.x, fma(z1.y, v1.y, fma(z2.x, v2.x, z2.y * v2.y)))));
+      } else if (on && D.red >= 6) v = I.xv[D.red & 15];
+      return v;
+    };
+    const double v0 = qd_of(D0, true), v1 = qd_of(D1, has1);
+    I.gp[s] = v0; I.gp[16 + s] = v1;
+  }
+  WSYNC();
+  const bool wr = live;
+  if (wr) {
+    double* qo = A.out.qdot + (size_t)b * NV;
+    qo[s] = I.gp[s];
+    if (16 + s < NV) qo[16 + s] = I.gp[16 + s];
+    if (s == 0) {
+      A.out.status[b] = status;
+      if (A.out.iters) A.out.iters[b] = nl;     // the eliminated equalities, so that `iters` keeps its meaning
+    }
+  }
+  if (A.out.q_next) {   // jointVelocitiestoConfig (Robot_Wrapper4.py:440-441)
+    WSYNC();
+    I.xv[s] = (s < 6) ? I.gp[s] * dt : 0.0;
+    WSYNC();
+    double* qn = A.out.q_next + (size_t)b * NQ;
+    if (wr) {
+      integrate_ff(I, s, qn);
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int d = 6 + s + 16 * h2;
+        if (d < nv) { const int qi = M.col_q[d]; qn[qi] = qv[qi] + I.gp[d] * dt; }
+      }
+      if (s < NQ - nq) qn[nq + s] = 0.0;
+    }
+  }
+  // ---- the tail: instances left out above (a flagged leg block; diagnostic orth_qr) are redone by this wave on the general path
+  const unsigned long long tailm = __ballot(valid && defer && s == 0);
+  if (tailm) {
+    if (valid && defer && s == 0 && A.defer_stat) {
+      unsigned long long old = *(volatile unsigned long long*)A.defer_stat, assumed;
+      do {
+        assumed = old;
+        const unsigned long long cnt = ((assumed >> 32) == (unsigned long long)A.tick_seq) ? (assumed & 0xFFFFFFFFull) + 1ull : 1ull;
+        old = atomicCAS(A.defer_stat, assumed, ((unsigned long long)A.tick_seq << 32) | cnt);
+      } while (old != assumed);
+    }
+    Smem& S = SU.G;
+    const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
+                      A.in.com_target || A.in.com_target_vel;
+    const bool has3 = A.in.ee_ref_rot != nullptr;
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+      if (!((tailm >> (16 * rr)) & 1ull)) continue;
+      const int bt_ = 4 * (int)blockIdx.x + rr;
+      int ln = threadIdx.x;
+      asm volatile("" : "+v"(ln));
+      WSYNC();
+      S.cl[ln] = 0.0;
+      const int mi = model_index(A.in.model_id, bt_, A.n_models);
+      const InRegs cur = load_inputs(A.in, bt_, ln, has2, has3);
+      const LaneConst lc = load_lane_const(models[mi], cfgs[mi], ln);
+      stage_inputs(S, cur, ln, has2, has3);
+      WSYNC();
+      process_instance<MODE_TICK, false, true>(S, A, models[mi], cfgs[mi], plans[mi], lc, cur, bt_, ln, 0ull);
+      WSYNC();
+    }
+  }
+}
+
 static int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   (void)what;
@@ -4521,6 +5068,11 @@ int launch_tick_sim3p(const KernelArgs& a, void* stream) {
   else hipLaunchKernelGGL(wbc_tick_sim3p_kernel<false>, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   return check_launch("tick_sim3p");
 }
+int launch_tick_orthp(const KernelArgs& a, void* stream) {
+  hipLaunchKernelGGL(wbc_tick_orthp_kernel, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  return check_launch("tick_orthp");
+}
+int orthp_lds_bytes() { return (int)(4 * sizeof(QInst)); }
 int sim3_lds_bytes() { return (int)sizeof(SmemC); }
 int sim3p_lds_bytes() { return (int)sizeof(SmemP); }
 int launch_qp(const QpArgs& a, int grid, void* stream) {

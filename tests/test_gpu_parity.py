@@ -331,7 +331,17 @@ def test_orthonormal_contact_presolve_matches_the_oracle(wx200, px100, cfg_name,
     for i, c in enumerate(cfgs):
         bt.configure(c, i)
     got = bt.tick(d, DT, want_q_next=True)
-    assert bt.stat("last_path") == 0 and bt.stat("last_orth") == 1
+    # config 2 proper runs on the PACKED orth kernel (four instances per wavefront, last_path 3); the others on the general kernel's ORTH variant
+    assert bt.stat("last_path") == (3 if cfg_name == "c2" else 0) and bt.stat("last_orth") == 1
+    if cfg_name == "c2":
+        assert bt.stat("deferred_last") < B // 50                        # (flagged leg blocks: redone by the wave's tail on the general path)
+        bt.set_option("packed_orth", 0)
+        one = bt.tick(d, DT, want_q_next=True)
+        assert bt.stat("last_path") == 0 and bt.stat("last_orth") == 1
+        okp = (ref["status"] == 0)
+        assert (one["status"] == got["status"]).all() and np.abs(one["qdot"] - got["qdot"])[okp].max() < 1e-6
+        assert (one["iters"] == got["iters"]).all()
+        bt.set_option("packed_orth", 1)
     bt.set_option("orth_qr", 1)              # the basis through the Householder QR for every instance (by default: flagged leg blocks only)
     qr = bt.tick(d, DT, want_q_next=True)
     bt.set_option("orth_qr", 0)
@@ -772,7 +782,7 @@ def test_full_size_properties(wx200, cfg_name):
     scale = 1 + np.abs(x).max(axis=1, keepdims=True)
     c0 = 4 if cfg_name == "c3" else 0                                            # (config 2 has no trunk box in front of the contact rows)
     assert (np.abs(Cx[:, c0:])[ok] / scale[ok]).max() < 1e-8                     # 12 contact equalities
-    assert bt.stat("last_path") == (2 if cfg_name == "c3" else 0) and bt.stat("last_orth") == (0 if cfg_name == "c3" else 1)
+    assert bt.stat("last_path") == (2 if cfg_name == "c3" else 3) and bt.stat("last_orth") == (0 if cfg_name == "c3" else 1)
     assert ((a["Clb"] - Cx)[ok] / scale[ok]).max() < 1e-8 and ((Cx - a["Cub"])[ok] / scale[ok]).max() < 1e-8
     assert ((a["lb"] - x)[ok]).max() < 1e-8 and ((x - a["ub"])[ok]).max() < 1e-8
     rng = np.random.default_rng(0)
@@ -927,6 +937,8 @@ def test_gpu_solution_against_the_exact_optimum(wx200, px100, cfg_name, with_rot
         assert {(2, 0), (1, 0), (0, 0)} <= paths          # packed, one-instance compact, general
     if cfg_name in ("c2", "everything"):
         assert {(0, 1), (0, 0)} <= paths                  # orthonormal presolve, full size
+    if cfg_name == "c2":
+        assert (3, 1) in paths                            # the packed orth kernel
     bt.close()
 
 
