@@ -228,7 +228,8 @@ class GpuEngine:
             ms = ev0.elapsed_time(ev1) / 10
             out["c2_B%d" % B] = {"ticks_per_s": B / ms * 1e3, "ms_per_step": ms, "task_rows": bt.task_rows, "constraint_rows": bt.constraint_rows,
                                  "optimal_frac": float((dev_out["status"] == 0).double().mean().item()),
-                                 "kernel_path": "wbc_tick_kernel<MODE_TICK, ORTH>" if bt.stat("last_orth") else "wbc_tick_kernel<MODE_TICK>"}
+                                 "kernel_path": "wbc_tick_orthp_kernel (packed: four instances per wavefront)" if bt.stat("last_path") == 3 else
+                                                ("wbc_tick_kernel<MODE_TICK, ORTH>" if bt.stat("last_orth") else "wbc_tick_kernel<MODE_TICK>")}
             bt.close()
         return out
 

@@ -4510,11 +4510,14 @@ struct __attribute__((aligned(16))) QInst {
   double W[136];            // sin / cos [22][2] @0, m c [22][4] @44 -> Z [18][6] @0
   double in[64];            // q [27] @0, ee_target [15] @28, prev_ee_target [15] @43, com_target [3] @58, com_target_vel [3] @61
   double pf[16];            // EE frame origins [5][3]
-  double cl[32], yv[32];    // Cholesky column pair (entries 16..31 stay zero)
-  double zv[16], xv[16];    // g' -> L^-1 g';  y -> base twist * dt
+  double cl[32], yv[32];    // the configuration's task weights and gains (wt [96], staged at the top: no global load inside the task loop) ->
+  double zv[16], xv[16];    //   Cholesky column pair (entries 16..31 zero); g' -> L^-1 g';  y -> base twist * dt
   double gp[32];            // posture part of g by DoF -> qdot by DoF
 };
 static_assert(sizeof(QInst) * 4 <= 20480, "8 waves per CU");
+static_assert(offsetof(QInst, xv) - offsetof(QInst, cl) == 80 * sizeof(double), "wt [96] = cl | yv | zv | xv");
+static_assert(offsetof(WbcConfig, joint_w) - offsetof(WbcConfig, ee_W) == 84 * sizeof(double), "ee_W [30] ee_w [5] ee_gain [30] trunk [13] com_W [3] com_gain [3] joint_w");
+constexpr int WT_W = 0, WT_w = 30, WT_G = 35, WT_CW = 78, WT_CG = 81;   // offsets inside wt
 
 __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                                const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
@@ -4543,9 +4546,16 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     if (16 + s < 28) I.in[16 + s] = q1;
     if (s < 15) { I.in[28 + s] = et; I.in[43 + s] = ep; }
     if (s < 6) I.in[58 + s] = cm;
-    I.cl[s] = 0.0; I.cl[16 + s] = 0.0; I.yv[s] = 0.0; I.yv[16 + s] = 0.0;
+    // the configuration's weights and gains: 85 contiguous doubles of WbcConfig, six per lane, parked in wt (= cl | yv | zv | xv)
+    const double* cw = &cfg.ee_W[0][0];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) I.cl[s + 16 * i] = (s + 16 * i < 85) ? cw[s + 16 * i] : 0.0;
   }
+  const double* const wt = I.cl;
   const int nv = M.nv, nq = M.nq, nj = M.njoints, n = P.q_nred, nelim = P.nelim, nl = 3 * nelim;
+  int efoot[5];
+#pragma unroll
+  for (int e = 0; e < 5; ++e) efoot[e] = P.q_efoot[e];
   const DevPlan::QDof D0 = P.q_dof[s], D1 = P.q_dof[16 + s];
   const DevPlan::QJnt Jm0 = P.q_jm[s], Jm1 = P.q_jm[16 + s];
   DevPlan::PkJoint fkn = P.q_fk[0][s];
@@ -4553,7 +4563,6 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
   const bool has1 = 16 + s < nv;                                  // this lane's second DoF exists
   const bool c_com = cfg.task_com != 0;
   const int c_task_joint = cfg.task_joint;
-  const double joint_w = cfg.joint_w;
   const int fjoint = (s < 5) ? M.frame_joint[WBC_FR_EE0 + s] : 1;
   const double fp0 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][0] : 0.0, fp1 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][1] : 0.0,
                fp2 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][2] : 0.0;
@@ -4853,12 +4862,12 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
 #pragma unroll 1
   for (unsigned tm = tmask; tm; tm &= tm - 1) {   // endEffectorA2 (:474-484) / calcTargetVelEE3 (:1052-1157) / EndEffectorB2 (:907-910)
     const int e = __ffs((int)tm) - 1;
-    const double w = cfg.ee_w[e];
+    const double w = wt[WT_w + e];
     double Wd[6], Gd[3];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) Wd[i] = cfg.ee_W[e][i];
+    for (int i = 0; i < 6; ++i) Wd[i] = wt[WT_W + 6 * e + i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) Gd[i] = cfg.ee_gain[e][i];
+    for (int i = 0; i < 3; ++i) Gd[i] = wt[WT_G + 6 * e + i];
     const double pfe[3] = {I.pf[3 * e], I.pf[3 * e + 1], I.pf[3 * e + 2]};
     const bool sup0 = (D0.supmask >> e) & 1, sup1 = has1 && ((D1.supmask >> e) & 1);
     double a0[6], a1[6], br[6] = {0, 0, 0, 0, 0, 0}, wxp[3];
@@ -4872,19 +4881,23 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     const double* xp = I.in + 43 + 3 * e;
 #pragma unroll
     for (int i = 0; i < 3; ++i) br[i] = ((xt[i] - xp[i]) * inv_dt + Gd[i] * ((xt[i] - pfe[i]) * inv_dt)) * w;
-    block(a0, a1, br, P.q_efoot[e], false, (armsup >> e) & 1u);
+    int ef = efoot[0];
+#pragma unroll
+    for (int i = 1; i < 5; ++i) ef = (e == i) ? efoot[i] : ef;
+    block(a0, a1, br, ef, false, (armsup >> e) & 1u);
   }
   if (__ballot(c_com)) {   // Robot_Wrapper2 comJacobian (:600-603), cartesianTargetCoM (:661-668)
     double a0[6] = {0, 0, 0, 0, 0, 0}, a1[6] = {0, 0, 0, 0, 0, 0}, br[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) {
-      const double cw = cfg.com_W[rr];
+      const double cw = wt[WT_CW + rr];
       a0[rr] = cw * jc0[rr]; a1[rr] = has1 ? cw * jc1[rr] : 0.0;
-      br[rr] = I.in[61 + rr] + cfg.com_gain[rr] * (I.in[58 + rr] - com[rr]);
+      br[rr] = I.in[61 + rr] + wt[WT_CG + rr] * (I.in[58 + rr] - com[rr]);
     }
     block(a0, a1, br, -1, true, true);
   }
   // posture rows (qpJointA / qpJointb, :1199-1268): Z'(d^2 I)Z = d^2 I; the target's part of g through Z
+  const double joint_w = wt[84];
   const double dpost = (1.0 / nv) * joint_w;
   if (__ballot(c_task_joint == WBC_JOINT_PREV)) {
     WSYNC();
@@ -4902,7 +4915,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
   if (s >= n) gacc = 0.0;
   bool live = valid && !defer;
   // ---- Cholesky H' = L L' fused with the substitutions: lane s: L y = e_s (row s of L^-T); lane 15 (a padding variable): L y = g'
-  WSYNC();
+  WSYNC();                                   // (wt is dead: its memory becomes the sweep's vectors, zero beyond entry 15)
+  I.cl[16 + s] = 0.0; I.yv[16 + s] = 0.0;
   I.zv[s] = gacc;
   WSYNC();
   double y[16];
@@ -4995,7 +5009,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
         const int d = 6 + s + 16 * h2;
-        if (d < nv) { const int qi = M.col_q[d]; qn[qi] = qv[qi] + I.gp[d] * dt; }
+        if (d < nv) { const int qi = d + 1; qn[qi] = qv[qi] + I.gp[d] * dt; }   // (one free-flyer + 1-DoF joints: q index = DoF + 1)
       }
       if (s < NQ - nq) qn[nq + s] = 0.0;
     }

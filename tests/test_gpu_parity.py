@@ -330,6 +330,8 @@ def test_orthonormal_contact_presolve_matches_the_oracle(wx200, px100, cfg_name,
     bt = WbcBatch(models, B)
     for i, c in enumerate(cfgs):
         bt.configure(c, i)
+    if cfg_name == "c2":
+        bt.set_option("packed_orth", 2)      # (1, the default, keeps batches this small on the one-instance kernel: shorter dependent chain)
     got = bt.tick(d, DT, want_q_next=True)
     # config 2 proper runs on the PACKED orth kernel (four instances per wavefront, last_path 3); the others on the general kernel's ORTH variant
     assert bt.stat("last_path") == (3 if cfg_name == "c2" else 0) and bt.stat("last_orth") == 1
@@ -341,7 +343,7 @@ def test_orthonormal_contact_presolve_matches_the_oracle(wx200, px100, cfg_name,
         okp = (ref["status"] == 0)
         assert (one["status"] == got["status"]).all() and np.abs(one["qdot"] - got["qdot"])[okp].max() < 1e-6
         assert (one["iters"] == got["iters"]).all()
-        bt.set_option("packed_orth", 1)
+        bt.set_option("packed_orth", 2)
     bt.set_option("orth_qr", 1)              # the basis through the Householder QR for every instance (by default: flagged leg blocks only)
     qr = bt.tick(d, DT, want_q_next=True)
     bt.set_option("orth_qr", 0)
@@ -913,6 +915,7 @@ def test_gpu_solution_against_the_exact_optimum(wx200, px100, cfg_name, with_rot
     for key in ((1, 1, 1, 1), (1, 1, 1, 0), (1, 1, 0, 0), (1, 0, 0, 0), (0, 0, 0, 0)):
         for name, v in zip(("presolve", "presolve_orth", "sim3_kernel", "packed_kernel"), key):
             bt.set_option(name, v)
+        bt.set_option("packed_orth", 2)      # (small batch: 1 would keep config 2 on the one-instance kernel)
         got = bt.tick(d, DT)
         path = (bt.stat("last_path"), bt.stat("last_orth"))
         # an instance is solved on every kernel path or on none: a path that fails where another succeeds must not go unnoticed
