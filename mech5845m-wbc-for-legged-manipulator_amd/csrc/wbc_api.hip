@@ -383,7 +383,9 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
   // ---- the packed kernel (wbc_tick_sim3p_kernel) covers the sim3 switch-set family only: Grip task or none, no trunk / CoM
   // task, the kept rows = the trunk box (base support only), velocity bounds on, a posture mode it can form itself, every
   // joint it needs within tree depth 6 and at most 16 joints per level
-  bool ok = c.use_bounds && !c.task_trunk && !c.task_com && !c.con_com && !c.con_ee[4] && p_keep == (c.con_trunk ? 4 : 0) &&
+  // (a trunk task — base support only — runs on the kernel's TRUNK variant)
+  const bool trunk_is_root = M.frame_joint[WBC_FR_TRUNK] == 1 && M.frame_p[WBC_FR_TRUNK][0] == 0 && M.frame_p[WBC_FR_TRUNK][1] == 0 && M.frame_p[WBC_FR_TRUNK][2] == 0;
+  bool ok = c.use_bounds && !(c.task_trunk && !trunk_is_root) && !c.task_com && !c.con_com && !c.con_ee[4] && p_keep == (c.con_trunk ? 4 : 0) &&
             n_red <= 12 && (P->task_ee_mask & ~16u) == 0 && P->legrows == 0 &&
             (c.task_joint == WBC_JOINT_TIKHONOV || c.task_joint == WBC_JOINT_PREV || (c.task_joint >= WBC_JOINT_MANI && c.task_joint <= WBC_JOINT_HYBRID && P->post_static && !P->post_fk2));
   int need_depth = 0;
@@ -420,7 +422,7 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
     }
   }
   P->packed_ok = ok ? 1 : 0;
-  bool upd = ok;
+  bool upd = ok && !c.task_trunk;   // (the packed state update advances no trunk reference state)
   for (int e = 0; e < 5; ++e) if (M.depth[M.frame_joint[WBC_FR_EE0 + e]] > need_depth) upd = false;
   if (M.depth[M.frame_joint[WBC_FR_TRUNK]] > need_depth) upd = false;
   P->pk_update_ok = upd ? 1 : 0;
@@ -758,6 +760,7 @@ static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
       HIP_TRY(hipMemsetAsync(b->d_dstat, 0, sizeof(unsigned long long), (hipStream_t)stream));
     }
     a.defer_stat = b->d_dstat;
+    a.packed_trunk = b->cfg_host[0].task_trunk != 0;
     a.tick_seq = ++b->tick_seq;
     if (!b->tick_seq) a.tick_seq = ++b->tick_seq;          // (0 is the cleared word's sequence number)
     if (int e = launch_tick_sim3p(a, stream)) return fail(WBC_E_HIP, "packed sim3 tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));

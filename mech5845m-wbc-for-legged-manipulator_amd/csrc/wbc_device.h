@@ -93,6 +93,7 @@ struct KernelArgs {
   int32_t* pivot_count;             // diagnostic (option "count_pivoted"): instances that took the pivoted elimination; else null
   int32_t* defer_aux;               // [0] the pivot counter's slot, [1] workgroups of the deferred pass that are done, [2] last tick's deferred count
   int32_t dbg_force_defer;          // diagnostic: every instance with a flagged leg block is deferred instead of pivoted
+  int32_t packed_trunk;             // packed kernel: the configuration has the trunk task on (the TRUNK variant is launched)
   uint32_t tick_seq;                // packed kernel: this launch's sequence number (the "deferred_last" statistic is (seq, count) in one word)
   unsigned long long* defer_stat;   // packed kernel: that word (instances its tail redid on the general path), or null
   int32_t presolve_orth;            // the orthonormal contact presolve where DevPlan.orth: 0 off, 1 on, 2 on and a plan of this batch has DevPlan.orth (host)

@@ -3375,7 +3375,10 @@ __device__ __forceinline__ unsigned long long ror16(unsigned long long v) {   //
 // rebuilt from the factors (x = x0 + J1 w, u = T w, w = T's with s the seeds' slacks at the unconstrained minimiser x0), seeds with
 // a negative multiplier are dropped again (restoration), and the dual iterations carry on from that S-pair: qp_core<.., WARM>'s
 // scheme (tests/gi_variant.py solve_v3) for a problem without equalities.
-template <bool WARM>
+// TRUNK: the variant that carries the trunk task (trunkA / calcTargetVelTrunk2, Robot_Wrapper4.py:487-490, 948-1015): six more task rows on
+// the base columns; its inputs and parameters are staged in vectors that are free until the contact stage, so the common variant's
+// register allocation is untouched.
+template <bool WARM, bool TRUNK = false>
 __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                                const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   // (the general kernel's layout shares the allocation: an instance this kernel cannot reduce — a stance-leg block of rank < 2 — is
@@ -3408,6 +3411,18 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     if (16 + s < 28) V.in[16 + s] = q1;
     if (s < 10) V.in[28 + s] = ex;
     V.cl[s] = 0.0; V.cl[16 + s] = 0.0;
+    if (TRUNK) {   // trunk_target [3], prev_trunk_target [3], trunk_ref_euler [3], trunk_prev_rot [9] -> V.tv [16] + V.xv [0..1]; the configuration's
+                   // trunk_W [6], trunk_w, trunk_gain [6] -> V.xv [2..14] (both vectors are free until the contact stage)
+      auto tin = [&](const int k) -> double {
+        return (k < 3) ? A.in.trunk_target[(size_t)b * 3 + k] : (k < 6) ? A.in.prev_trunk_target[(size_t)b * 3 + (k - 3)]
+             : (k < 9) ? A.in.trunk_ref_euler[(size_t)b * 3 + (k - 6)] : A.in.trunk_prev_rot[(size_t)b * 9 + (k - 9)];
+      };
+      const double t0 = tin(s), t1 = (s < 2) ? tin(16 + s) : 0.0;
+      const double tw = (s < 13) ? (&cfg.trunk_W[0])[s] : 0.0;
+      V.tv[s] = t0;
+      if (s < 2) V.xv[s] = t1;
+      if (s < 13) V.xv[2 + s] = tw;
+    }
     if (WARM && s < 2) {                  // the carried working set: two words per instance, parked (as bit patterns) in V.in[38..39]
       const unsigned long long w = (A.ws_in && valid) ? A.ws_in[2 * (size_t)b + s] : 0ull;
       V.in[38 + s] = __longlong_as_double((long long)w);
@@ -3443,6 +3458,51 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   WSYNC();
   const double* const qv = V.in;
   PSTOP(6, qv[s] + dlo0 + dlo1 + eW[0] + (double)(fkn.joint + scq0 + scq1));
+  if (TRUNK) {
+    // calcTargetVelTrunk2 (Robot_Wrapper4.py:948-1015) / TrunkB (:914-920): the trunk frame is the free-flyer's own placement (the plan checks
+    // it), so the target velocity depends on the inputs alone — formed here, where hardly anything is live, and parked in V.xv[9..14]
+    const double* tw = V.xv + 2;           // trunk_W [0..5], trunk_w [6], trunk_gain [7..12]
+    const double* xt = V.tv;
+    const double* xp = V.tv + 3;
+    const double* er = V.tv + 6;
+    double* const sh = I.M2;               // (free until the FK)
+    double Rt_[9], fq[4], rq[4], Rs[9], vel[6];
+    quat_to_R(qv + 3, Rt_);
+    R_to_quat(Rt_, fq);
+    {
+      const SinCos t = sincos_cw(s < 3 ? er[s < 3 ? s : 0] : 0.5 * er[(s < 6 ? s : 3) - 3]);   // reference angles and their halves, one per lane
+      if (s < 6) { sh[2 * s] = t.s; sh[2 * s + 1] = t.c; }
+      WSYNC();
+      const double sa = sh[0], ca = sh[1], sb = sh[2], cb = sh[3], sc_ = sh[4], cc = sh[5];
+      Rs[0] = cc * cb; Rs[1] = cc * sb * sa - sc_ * ca; Rs[2] = cc * sb * ca + sc_ * sa;
+      Rs[3] = sc_ * cb; Rs[4] = sc_ * sb * sa + cc * ca; Rs[5] = sc_ * sb * ca - cc * sa;
+      Rs[6] = -sb;      Rs[7] = cb * sa;                 Rs[8] = cb * ca;
+      const double qx[4] = {sh[6], 0, 0, sh[7]}, qy[4] = {0, sh[8], 0, sh[9]}, qz[4] = {0, 0, sh[10], sh[11]};
+      double tq[4];
+      quat_mul(qy, qx, tq);
+      quat_mul(qz, tq, rq);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) * inv_dt + tw[7 + i] * ((xt[i] - qv[i]) * inv_dt);
+    const double qe0 = fq[3] * rq[0] - fq[0] * rq[3] + fq[1] * rq[2] - fq[2] * rq[1];   // :974
+    const double qe1 = fq[3] * rq[1] - fq[1] * rq[3] - fq[0] * rq[2] + fq[2] * rq[0];   // :975
+    const double qe2 = fq[3] * rq[2] - fq[3] * rq[2] + fq[0] * rq[1] - fq[1] * rq[0];   // :976 (sic)
+    const double Ro[9] = {V.tv[9], V.tv[10], V.tv[11], V.tv[12], V.tv[13], V.tv[14], V.tv[15], V.xv[0], V.xv[1]};
+    double D[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) D[i] = (Rs[i] - Ro[i]) * inv_dt;
+    // skew = D Rs (R*, not R*^T: :984); omega = (S[2][1], S[0][2], S[1][0]) + K qe
+    vel[3] = (D[6] * Rs[1] + D[7] * Rs[4] + D[8] * Rs[7]) + tw[10] * qe0;
+    vel[4] = (D[0] * Rs[2] + D[1] * Rs[5] + D[2] * Rs[8]) + tw[11] * qe1;
+    vel[5] = (D[3] * Rs[0] + D[4] * Rs[3] + D[5] * Rs[6]) + tw[12] * qe2;
+    const double trunk_w = tw[6];
+    WSYNC();                               // (everyone has read the gains)
+    if (s == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) V.xv[9 + i] = vel[i] * trunk_w;
+    }
+    WSYNC();
+  }
 
   // ---- sin / cos of the joint angles: joint j (>= 2) reads q[idx_q[j]]; two joints per lane
   double* const oMi = I.M1;                 // [22][12], runs on into M2
@@ -3554,6 +3614,24 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       g = fma(-a[3], w3 * ee_w, g); g = fma(-a[4], w4 * ee_w, g); g = fma(-a[5], w5 * ee_w, g);
     }
   }
+  double at[6] = {0, 0, 0, 0, 0, 0};       // trunk task rows of reduced variable s
+  double* const At2 = I.M1 + 48;           // [6][6] (M1 beyond Ex is free between the FK and the Cholesky sweep)
+  if (TRUNK) {   // trunkA (Robot_Wrapper4.py:487-490, WORLD); the target velocity was formed at the top (V.xv[9..14])
+    const double* tw = V.xv + 2;           // trunk_W [0..5], trunk_w [6]
+    const double trunk_w = tw[6];
+    const bool sup = (s < n) && ((P.redsup[WBC_FR_TRUNK] >> s) & 1u);
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      at[rr] = sup ? (tw[rr] * lin0[rr]) * trunk_w : 0.0;
+      at[3 + rr] = sup ? (tw[3 + rr] * ang0[rr]) * trunk_w : 0.0;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) g = fma(-at[rr], V.xv[9 + rr], g);
+    if (s < 6) {
+#pragma unroll
+      for (int rr = 0; rr < 6; rr += 2) sts2(At2 + s * 6 + rr, at[rr], at[rr + 1]);
+    }
+  }
 #pragma unroll
   for (int rr = 0; rr < 6; rr += 2) sts2(At + s * 6 + rr, a[rr], a[rr + 1]);
   if (s < nl) { Kb[4 * s] = lin1[0]; Kb[4 * s + 1] = lin1[1]; Kb[4 * s + 2] = lin1[2]; }
@@ -3586,6 +3664,13 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     }
 #pragma unroll
     for (int k = 0; k < PV; ++k) if (k == s) h[k] += (s < n) ? dpost * dpost : 1.0;   // (lanes >= PV carry an all-zero row: harmless)
+    if (TRUNK) {   // the trunk rows: support on the six base columns
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const double2a t0 = lds2(At2 + k * 6), t1 = lds2(At2 + k * 6 + 2), t2 = lds2(At2 + k * 6 + 4);
+        h[k] += fma(at[0], t0.x, fma(at[1], t0.y, fma(at[2], t1.x, fma(at[3], t1.y, fma(at[4], t2.x, at[5] * t2.y)))));
+      }
+    }
   }
   PSTOP(2, h[0] + h[5] + h[11] + g);
 
@@ -3863,12 +3948,15 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     WSYNC();
     const double* c0 = V.cl + j;
     const double* c1 = V.yv + j;
-    const double pj = c0[0];
-    pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;
-    const double rinv = rsqrt(pj), ipj = rinv * rinv;
     double cm0[PV], cm1[PV];
 #pragma unroll
-    for (int rr = 1; rr < PV; ++rr) { cm0[rr] = c0[rr]; cm1[rr] = c1[rr]; }
+    for (int rr = 0; rr < PV; rr += 2) {     // (j is even: the columns come in 16-byte pairs, half the LDS instructions of entry-wise reads)
+      const double2a v0 = lds2(c0 + rr), v1 = lds2(c1 + rr);
+      cm0[rr] = v0.x; cm0[rr + 1] = v0.y; cm1[rr] = v1.x; cm1[rr + 1] = v1.y;
+    }
+    const double pj = cm0[0];
+    pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;
+    const double rinv = rsqrt(pj), ipj = rinv * rinv;
     // step j on this row
     const double th = h[0] * ipj, ty = y[0] * ipj, yk = y[0] * rinv;
     const double h1 = fma(-th, cm0[1], h[1]), y1 = fma(-ty, cm0[1], y[1]);
@@ -4335,6 +4423,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     }
   }
 }
+template __global__ void wbc_tick_sim3p_kernel<false, false>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
+template __global__ void wbc_tick_sim3p_kernel<true, false>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
+template __global__ void wbc_tick_sim3p_kernel<false, true>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
+template __global__ void wbc_tick_sim3p_kernel<true, true>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
 
 // ------------------------------------------------------------------------------------------------
 // wbc_update_kernel for four instances per wavefront (same lane layout and FK records as the packed tick kernel): the one-instance
@@ -4930,12 +5022,15 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     WSYNC();
     const double* c0 = I.cl + j;
     const double* c1 = I.yv + j;
-    const double pj = c0[0];
-    pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;
-    const double rinv = rsqrt(pj), ipj = rinv * rinv;
     double cm0[16], cm1[16];
 #pragma unroll
-    for (int rr = 1; rr < 16; ++rr) { cm0[rr] = c0[rr]; cm1[rr] = c1[rr]; }
+    for (int rr = 0; rr < 16; rr += 2) {
+      const double2a v0 = lds2(c0 + rr), v1 = lds2(c1 + rr);
+      cm0[rr] = v0.x; cm0[rr + 1] = v0.y; cm1[rr] = v1.x; cm1[rr + 1] = v1.y;
+    }
+    const double pj = cm0[0];
+    pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;
+    const double rinv = rsqrt(pj), ipj = rinv * rinv;
     const double th = h[0] * ipj, ty = y[0] * ipj, yk = y[0] * rinv;
     const double h1 = fma(-th, cm0[1], h[1]), y1 = fma(-ty, cm0[1], y[1]);
     const double a = cm0[1];
@@ -5078,8 +5173,12 @@ int launch_tick_deferred(const KernelArgs& a, void* stream) {
   return check_launch("tick_deferred");
 }
 int launch_tick_sim3p(const KernelArgs& a, void* stream) {
-  if (a.ws_in || a.ws_out) hipLaunchKernelGGL(wbc_tick_sim3p_kernel<true>, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
-  else hipLaunchKernelGGL(wbc_tick_sim3p_kernel<false>, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  const bool warm = a.ws_in || a.ws_out, trunk = a.in.trunk_target && a.packed_trunk;
+  const dim3 grid((a.B + 3) / 4);
+  if (warm && trunk) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<true, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  else if (trunk) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<false, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  else if (warm) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<true, false>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  else hipLaunchKernelGGL((wbc_tick_sim3p_kernel<false, false>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   return check_launch("tick_sim3p");
 }
 int launch_tick_orthp(const KernelArgs& a, void* stream) {

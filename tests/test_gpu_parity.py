@@ -239,9 +239,9 @@ def test_contact_presolve_and_general_path_agree(wx200, px100, cfg_name):
     mid = (np.arange(B) % 2).astype(np.int32)
     parts = [common.tick_inputs(m, c, B, seed=51 + i, with_rot=(cfg_name in ("everything", "c3_trunk_task")))
              for i, (m, c) in enumerate(zip(models, cfgs))]
-    if cfg_name == "c3_trunk_task":          # orientation references rule the sim3 kernel out; drop the EE ones, keep the trunk's
+    if cfg_name == "c3_trunk_task":          # a MOVING trunk reference (omega_ref != 0); the packed kernel honours the gripper's orientation reference too
         for prt in parts:
-            prt.pop("ee_ref_rot"), prt.pop("ee_prev_rot")
+            prt["trunk_prev_rot"] = prt["trunk_prev_rot"] + 0.0     # (with_rot set them: R*_prev != R*)
     d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
     d["model_id"] = mid
     ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
@@ -266,7 +266,7 @@ def test_contact_presolve_and_general_path_agree(wx200, px100, cfg_name):
         cfg_name, "ran" if packed_ran else "not eligible", errs[(1, 1, 1)], errs[(1, 1, 0)], errs[(1, 0, 0)], errs[(0, 0, 0)],
         res[(1, 1, 1)]["iters"][ok].mean(), res[(1, 1, 0)]["iters"][ok].mean(), res[(1, 0, 0)]["iters"][ok].mean(),
         res[(0, 0, 0)]["iters"][ok].mean(), ref["iters"][ok].mean()))
-    assert packed_ran == (cfg_name == "c3")
+    assert packed_ran == (cfg_name in ("c3", "c3_trunk_task"))        # (the trunk task: the packed kernel's TRUNK variant)
     assert max(errs.values()) < QDOT_TOL
     for key in ((1, 1, 1), (1, 1, 0)):
         assert np.abs(res[key]["qdot"] - res[(0, 0, 0)]["qdot"])[ok].max() < QDOT_TOL

@@ -10,7 +10,8 @@ wx, px = common.models()
 dev = torch.device("cuda", 0)
 only = sys.argv[1:]          # optional: configuration names to time (default: all)
 for name, B, mixed in (("c2", 1024, False), ("c2", 4096, False), ("c2", 65536, False), ("c3", 1024, False), ("c3", 4096, False), ("c3", 65536, False),
-                       ("c3", 65536, True), ("everything", 65536, False), ("full", 65536, False), ("hybrid_grip_com", 65536, False)):
+                       ("c3", 65536, True), ("c3_trunk_task", 65536, False), ("c3_mani", 65536, False), ("everything", 65536, False), ("full", 65536, False),
+                       ("hybrid_grip_com", 65536, False)):
     if only and name not in only:
         continue
     models = [wx, px] if mixed else [wx]
@@ -39,6 +40,7 @@ for name, B, mixed in (("c2", 1024, False), ("c2", 4096, False), ("c2", 65536, F
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
-    print("%-16s B=%6d mixed=%d  m=%2d p=%2d  %.3f ms/step  %.1f M ticks/s  (optimal %.3f, iters %.1f)" % (
-        name, B, mixed, bt.task_rows, bt.constraint_rows, ms, B / ms / 1e3, (out["status"] == 0).double().mean().item(), out["iters"].double().mean().item()))
+    print("%-16s B=%6d mixed=%d  m=%2d p=%2d  %.3f ms/step  %.1f M ticks/s  (optimal %.3f, iters %.1f, kernel path %d)" % (
+        name, B, mixed, bt.task_rows, bt.constraint_rows, ms, B / ms / 1e3, (out["status"] == 0).double().mean().item(), out["iters"].double().mean().item(),
+        bt.stat("last_path")))
     bt.close()
