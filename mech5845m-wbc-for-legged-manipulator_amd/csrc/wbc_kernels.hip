@@ -968,7 +968,8 @@ __device__ __forceinline__ LaneConst load_lane_const(const DevModel& M, const Wb
 // the per-instance inputs, one value per lane per group (coalesced loads), staged into S.in
 struct InRegs { double g1, g2, g3a, g3b, pu, qc; };
 
-__device__ __forceinline__ InRegs load_inputs(const WbcTickIn& in, const int b, const int lane, const bool has2, const bool has3) {
+template <class TI>
+__device__ __forceinline__ InRegs load_inputs(const TI& in, const int b, const int lane, const bool has2, const bool has3) {
   InRegs r;
   r.g1 = r.g2 = r.g3a = r.g3b = r.pu = r.qc = 0.0;
   if (in.posture_u && lane < NV) r.pu = in.posture_u[(size_t)b * NV + lane];
@@ -1147,8 +1148,8 @@ constexpr int GS = 10;                 // row stride of G: 6 base columns + up t
 // variable k is DoF Fd[k], reduced row r is the r-th kept row or, from p_keep on, the velocity bound of eliminated leg DoF legd[r - p_keep]
 // — and the final one mapped back, so that res.ws_b / res.ws_r come out in the caller's indexing (lane = DoF / original constraint row),
 // like process_sim3's.
-template <bool WARM = false>
-__device__ __forceinline__ bool contact_presolve(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
+template <bool WARM = false, class KA = KernelArgs>
+__device__ __forceinline__ bool contact_presolve(Smem& S, const KA& A, const DevModel& M, const WbcConfig& cfg,
                                                  const DevPlan& P, const double dpost, const double g, const double lb,
                                                  const double ub, const double clb, const double cub, const int lane,
                                                  unsigned long long* ts, QpResult& res, const unsigned long long ws0 = 0ull,
@@ -1545,7 +1546,8 @@ __device__ __forceinline__ bool orth_null_basis(const double* const rows, const 
 #else
 #define OCUT(k, val) do { } while (0)
 #endif
-__device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
+template <class KA>
+__device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KA& A, const DevModel& M, const WbcConfig& cfg,
                                                       const DevPlan& P, const double g, const double lb, const double ub,
                                                       const double clb, const double cub, const int lane,
                                                       unsigned long long* ts, QpResult& res, const bool have_h = false) {
@@ -1716,7 +1718,8 @@ __device__ __forceinline__ bool contact_presolve_orth(Smem& S, const KernelArgs&
 // constraint stage. Only where the constraints are evaluated at the same state as the tasks (no second FK pass). Returns false —
 // RA zeroed again for the general path — when two contact rows are numerically dependent.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool orth_direct_assemble(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
+template <class KA>
+__device__ __forceinline__ bool orth_direct_assemble(Smem& S, const KA& A, const DevModel& M, const WbcConfig& cfg,
                                                      const DevPlan& P, const double* const At, const int mtp,
                                                      const double (&lin)[3], const int lane) {
   const int nv = M.nv, nelim = P.nelim, nl = 3 * nelim, n_red = P.n_red, mc = A.mcart;
@@ -1824,8 +1827,8 @@ __device__ __forceinline__ bool orth_direct_assemble(Smem& S, const KernelArgs& 
 // One instance: FK -> Jacobians -> task stack -> H, g, C, bounds [-> QP -> qdot -> q_next]
 // (inputs already staged in S.in)
 // ------------------------------------------------------------------------------------------------
-template <int MODE, bool WARM = false, bool ORTH = false>
-__device__ __forceinline__ void process_instance(Smem& S, const KernelArgs& A, const DevModel& M, const WbcConfig& cfg,
+template <int MODE, bool WARM = false, bool ORTH = false, class KA = KernelArgs>
+__device__ __forceinline__ void process_instance(Smem& S, const KA& A, const DevModel& M, const WbcConfig& cfg,
                                                  const DevPlan& P, const LaneConst& lc, const InRegs& inr, const int b,
                                                  const int lane, const unsigned long long t_entry = 0) {
   const int nv = M.nv, nq = M.nq, nj = M.njoints;
@@ -3296,6 +3299,36 @@ __global__ void __launch_bounds__(64) wbc_update_kernel(const UpdateArgs A, cons
   }
 }
 
+// One instance on the general path, called by the packed kernels for what they cannot reduce themselves (the TAIL: a stance-leg block of rank < 2,
+// a flagged block on the orth kernel). It reads the kernel's argument block AGAIN, through the kernarg segment pointer (KernelArgs is the first
+// kernel parameter of both callers): handed the caller's own `A`, the general path's ~90 scalars were fetched at kernel entry and kept alive —
+// spilled to VGPR lanes — across the whole packed path: 480 extra v_writelane / v_readlane in the common path, 3 % of the step (same-box A/B,
+// tools/ab_bench.sh). A real call is not an option: arguments arrive in VGPRs, and the general path pins configuration scalars to SGPRs.
+template <bool WARM, bool ORTH>
+__device__ __forceinline__ void tail_instance(Smem* Sp, const int bt_v, const DevModel* __restrict__ models, const WbcConfig* __restrict__ cfgs,
+                                              const DevPlan* __restrict__ plans) {   // (the kernel's own noalias table pointers: scalar loads)
+  Smem& S = *Sp;
+  __attribute__((address_space(4))) const KernelArgs* Ap =
+      (const __attribute__((address_space(4))) KernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(Ap));                                   // (opaque: these loads are not merged with, nor hoisted to, the kernel's entry loads)
+  const __attribute__((address_space(4))) KernelArgs& A = *Ap;   // (kept in the constant address space: scalar loads)
+  const int bt_ = __builtin_amdgcn_readfirstlane(bt_v);
+  const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
+                    A.in.com_target || A.in.com_target_vel;
+  const bool has3 = A.in.ee_ref_rot != nullptr;
+  int ln = threadIdx.x;
+  asm volatile("" : "+v"(ln));
+  WSYNC();
+  S.cl[ln] = 0.0;
+  const int mi = model_index(A.in.model_id, bt_, A.n_models);
+  const InRegs cur = load_inputs(A.in, bt_, ln, has2, has3);
+  const LaneConst lc = load_lane_const(models[mi], cfgs[mi], ln);
+  stage_inputs(S, cur, ln, has2, has3);
+  WSYNC();
+  process_instance<MODE_TICK, WARM, ORTH>(S, A, models[mi], cfgs[mi], plans[mi], lc, cur, bt_, ln, 0ull);
+  WSYNC();
+}
+
 // ================================================================================================
 // The PACKED sim3-tick kernel: FOUR robot instances per wavefront, one per 16-lane DPP row.
 //
@@ -3431,34 +3464,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       if (s < 9) { V.dv[s] = A.in.ee_ref_rot[(size_t)b * 45 + 36 + s]; V.yv[s] = A.in.ee_prev_rot[(size_t)b * 45 + 36 + s]; }
     }
   }
-  const int nv = M.nv, nq = M.nq, n = P.n_red, nelim = P.nelim, nl = 3 * nelim, p_keep = P.p_keep, p = p_keep + nl;
-  const unsigned fl = P.flags;
-  const bool c_con_trunk = fl & 2u;
-  const int c_task_joint = (fl >> 4) & 7u;
-  const bool has_grip = (P.task_ee_mask >> 4) & 1u;
-  // per-lane records (one load level: nothing waits for an index): reduced variable s, eliminated leg DoF s, first FK level
-  const DevPlan::PkCol cv = P.pk_var[s], cg = P.pk_leg[s];
-  DevPlan::PkJoint fkn = P.pk_fk[0][s];
-  const int scq0 = P.pk_scq[(2 + s) & 31], scq1 = P.pk_scq[(18 + s) & 31];
-  const int dof0 = cv.dof, dof1 = cg.dof;
-  const int c0_joint = cv.joint, c0_lin = cv.lin, c0_ang = cv.ang, c1_joint = cg.joint, c1_lin = cg.lin, c1_ang = cg.ang;
-  const int dq0 = cv.dq_idx, dq1 = cg.dq_idx;
-  const double dlo0 = cv.d_lo, dhi0 = cv.d_hi, dvm0 = cv.d_vm, dlo1 = cg.d_lo, dhi1 = cg.d_hi, dvm1 = cg.d_vm;
-  const double dcoef = cfg.damper_coef, dqi = cfg.damper_qi, dqs = cfg.damper_qs;
-  const int gj = M.frame_joint[WBC_FR_EE0 + 4];
-  const double gp0 = M.frame_p[WBC_FR_EE0 + 4][0], gp1 = M.frame_p[WBC_FR_EE0 + 4][1], gp2 = M.frame_p[WBC_FR_EE0 + 4][2];
-  const unsigned gsup = P.redsup[WBC_FR_EE0 + 4];
-  const double ee_w = cfg.ee_w[4];
-  double eW[6], eG[3];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) eW[i] = cfg.ee_W[4][i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) eG[i] = cfg.ee_gain[4][i];
-  const double joint_w = cfg.joint_w, tb_z = cfg.trunk_box_z_frac, tb_a = cfg.trunk_box_ang, tb_s = cfg.trunk_box_scale;
-  WSYNC();
-  const double* const qv = V.in;
-  PSTOP(6, qv[s] + dlo0 + dlo1 + eW[0] + (double)(fkn.joint + scq0 + scq1));
   if (TRUNK) {
+    WSYNC();                               // (the staged inputs are visible)
+    const double* const qv = V.in;
     // calcTargetVelTrunk2 (Robot_Wrapper4.py:948-1015) / TrunkB (:914-920): the trunk frame is the free-flyer's own placement (the plan checks
     // it), so the target velocity depends on the inputs alone — formed here, where hardly anything is live, and parked in V.xv[9..14]
     const double* tw = V.xv + 2;           // trunk_W [0..5], trunk_w [6], trunk_gain [7..12]
@@ -3502,8 +3510,35 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       for (int i = 0; i < 6; ++i) V.xv[9 + i] = vel[i] * trunk_w;
     }
     WSYNC();
+    __builtin_amdgcn_sched_barrier(0);    // (the per-lane records below are fetched after this block: live across it they spilled 110 VGPRs)
   }
-
+  const int nv = M.nv, nq = M.nq, n = P.n_red, nelim = P.nelim, nl = 3 * nelim, p_keep = P.p_keep, p = p_keep + nl;
+  const unsigned fl = P.flags;
+  const bool c_con_trunk = fl & 2u;
+  const int c_task_joint = (fl >> 4) & 7u;
+  const bool has_grip = (P.task_ee_mask >> 4) & 1u;
+  // per-lane records (one load level: nothing waits for an index): reduced variable s, eliminated leg DoF s, first FK level
+  const DevPlan::PkCol cv = P.pk_var[s], cg = P.pk_leg[s];
+  DevPlan::PkJoint fkn = P.pk_fk[0][s];
+  const int scq0 = P.pk_scq[(2 + s) & 31], scq1 = P.pk_scq[(18 + s) & 31];
+  const int dof0 = cv.dof, dof1 = cg.dof;
+  const int c0_joint = cv.joint, c0_lin = cv.lin, c0_ang = cv.ang, c1_joint = cg.joint, c1_lin = cg.lin, c1_ang = cg.ang;
+  const int dq0 = cv.dq_idx, dq1 = cg.dq_idx;
+  const double dlo0 = cv.d_lo, dhi0 = cv.d_hi, dvm0 = cv.d_vm, dlo1 = cg.d_lo, dhi1 = cg.d_hi, dvm1 = cg.d_vm;
+  const double dcoef = cfg.damper_coef, dqi = cfg.damper_qi, dqs = cfg.damper_qs;
+  const int gj = M.frame_joint[WBC_FR_EE0 + 4];
+  const double gp0 = M.frame_p[WBC_FR_EE0 + 4][0], gp1 = M.frame_p[WBC_FR_EE0 + 4][1], gp2 = M.frame_p[WBC_FR_EE0 + 4][2];
+  const unsigned gsup = P.redsup[WBC_FR_EE0 + 4];
+  const double ee_w = cfg.ee_w[4];
+  double eW[6], eG[3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) eW[i] = cfg.ee_W[4][i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) eG[i] = cfg.ee_gain[4][i];
+  const double joint_w = cfg.joint_w, tb_z = cfg.trunk_box_z_frac, tb_a = cfg.trunk_box_ang, tb_s = cfg.trunk_box_scale;
+  WSYNC();
+  const double* const qv = V.in;
+  PSTOP(6, qv[s] + dlo0 + dlo1 + eW[0] + (double)(fkn.joint + scq0 + scq1));
   // ---- sin / cos of the joint angles: joint j (>= 2) reads q[idx_q[j]]; two joints per lane
   double* const oMi = I.M1;                 // [22][12], runs on into M2
   double* const sc = I.M2 + PV * PLD - 48;  // sin / cos table: the tail of M2, free until J is written
@@ -4399,29 +4434,16 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // ---- the tail: an instance left out above (a stance-leg block of rank < 2 — never seen on the benchmark distribution — or the
   // diagnostic dbg_force_defer) is redone here, by this wave, on the general path (process_instance, one instance per wavefront, LDS
   // shared with the packed layout). No list, no second launch, and a batch that defers everything runs at the general kernel's occupancy.
+#ifndef WBC_NO_TAIL   // (A/B variant builds only: make variant VFLAGS=-DWBC_NO_TAIL measures what carrying the tail costs the common path)
   const unsigned long long tailm = __ballot(valid && flagged && s == 0);
   if (tailm) {
-    Smem& S = SU.G;
-    const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
-                      A.in.com_target || A.in.com_target_vel;
-    const bool has3 = A.in.ee_ref_rot != nullptr;
 #pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
       if (!((tailm >> (16 * rr)) & 1ull)) continue;
-      const int bt_ = 4 * (int)blockIdx.x + rr;
-      int ln = threadIdx.x;
-      asm volatile("" : "+v"(ln));
-      WSYNC();
-      S.cl[ln] = 0.0;
-      const int mi = model_index(A.in.model_id, bt_, A.n_models);
-      const InRegs cur = load_inputs(A.in, bt_, ln, has2, has3);
-      const LaneConst lc = load_lane_const(models[mi], cfgs[mi], ln);
-      stage_inputs(S, cur, ln, has2, has3);
-      WSYNC();
-      process_instance<MODE_TICK, WARM>(S, A, models[mi], cfgs[mi], plans[mi], lc, cur, bt_, ln, 0ull);
-      WSYNC();
+      tail_instance<WARM, false>(&SU.G, 4 * (int)blockIdx.x + rr, models, cfgs, plans);
     }
   }
+#endif
 }
 template __global__ void wbc_tick_sim3p_kernel<false, false>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
 template __global__ void wbc_tick_sim3p_kernel<true, false>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
@@ -5120,25 +5142,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
         old = atomicCAS(A.defer_stat, assumed, ((unsigned long long)A.tick_seq << 32) | cnt);
       } while (old != assumed);
     }
-    Smem& S = SU.G;
-    const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
-                      A.in.com_target || A.in.com_target_vel;
-    const bool has3 = A.in.ee_ref_rot != nullptr;
 #pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
       if (!((tailm >> (16 * rr)) & 1ull)) continue;
-      const int bt_ = 4 * (int)blockIdx.x + rr;
-      int ln = threadIdx.x;
-      asm volatile("" : "+v"(ln));
-      WSYNC();
-      S.cl[ln] = 0.0;
-      const int mi = model_index(A.in.model_id, bt_, A.n_models);
-      const InRegs cur = load_inputs(A.in, bt_, ln, has2, has3);
-      const LaneConst lc = load_lane_const(models[mi], cfgs[mi], ln);
-      stage_inputs(S, cur, ln, has2, has3);
-      WSYNC();
-      process_instance<MODE_TICK, false, true>(S, A, models[mi], cfgs[mi], plans[mi], lc, cur, bt_, ln, 0ull);
-      WSYNC();
+      tail_instance<false, true>(&SU.G, 4 * (int)blockIdx.x + rr, models, cfgs, plans);
     }
   }
 }
