@@ -40,7 +40,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak
 ALGO_FLOP_PER_TICK = 5.5e4     # dense count of the n = 26 problem (+ ~1e4 per working-set change)
 REDUCED_FLOP_PER_TICK = 1.1e4  # the problem the sim3 kernels actually solve (n' = 11, no equalities): DESIGN.md §4
-PMC_PROFILE = "r02_pmc_summary_packed.txt"   # committed rocprofv3 PMC passes the static roofline.traffic / roofline.issue fields come from
+PMC_PROFILE = "r03_pmc_summary_packed.txt"   # committed rocprofv3 PMC passes the static roofline.issue fields come from (tools/gpu_profile.sh)
+TRAFFIC_PROFILE = "r03_traffic_calibration.txt"   # FETCH_SIZE / WRITE_SIZE of the tick kernel, calibrated against known-byte-count kernels in the
+                                                  # tick's own access pattern (tools/calib_traffic.sh): roofline.traffic
 DT = 0.002
 QDOT_TOL = 1e-5
 
@@ -69,9 +71,13 @@ def pmc_static():
     if not s:
         return None, None
     traffic = 0.0
-    for kn in v:
-        traffic += v[kn].get("FETCH_SIZE", 0.0) + v[kn].get("WRITE_SIZE", 0.0)       # KiB per dispatch; 8-byte-per-lane accesses:
-    try:                                                                             # the gfx950 x2 correction for 16-byte streams does not apply
+    try:     # bytes per 65536-tick dispatch: counters x the factors measured on tools/calib_traffic's tick-pattern kernel (FETCH_SIZE reads ~1/2 on gfx950)
+        for line in open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)):
+            if line.startswith("CALIBRATED_TRAFFIC_BYTES_PER_DISPATCH"):
+                traffic = float(line.split()[1]) / 1024.0
+    except Exception:
+        traffic = 0.0
+    try:
         cu_cycles = 256.0 * s["GRBM_GUI_ACTIVE"] / 8.0
         ticks = 65536.0                      # the profile was taken at the bench batch; the packed kernel runs four ticks per wave
         issue = {"valu_busy": s["SQ_ACTIVE_INST_VALU"] / cu_cycles, "lds_busy": s["SQ_LDS_IDX_ACTIVE"] / cu_cycles,
@@ -286,8 +292,10 @@ def run_rank(args, comm, engine, make_inputs):
                     "spread": (max(elapsed) - min(elapsed)) / t_med, "reported": "median block"},
         "roofline": {"bound": "valu_lds_issue_latency", "contract_bound": "hbm",
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC, batch 65536)", "traffic_static_from_profile": "profiles/" + PMC_PROFILE,
-                     "kernel": engine.path(), "kernel_ms": k_med,
+                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE + WRITE_SIZE at batch 65536, calibrated on a known-byte-count kernel "
+                                                         "with the tick's own access pattern: x1.905 / x0.964)",
+                     "traffic_static_from_profile": "profiles/" + TRAFFIC_PROFILE,
+                     "kernel": engine.path(), "kernel_ms": k_med, "kernel_ms_mean_all_blocks": float(np.mean(kernel_ms)),
                      "algorithmic_bytes_per_tick": ALGO_BYTES_PER_TICK, "streamed_bytes_per_tick": ACTUAL_BYTES_PER_TICK,
                      "issue_frac": None if not issue else max(issue["valu_busy"], issue["lds_busy"]),
                      "fp64_tflops_nominal_n26": ALGO_FLOP_PER_TICK * B / (k_med * 1e-3) / 1e12,

@@ -16,13 +16,14 @@ step() {  # name, timeout, command...
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $name was killed at its limit: stopping"; exit 1; fi
 }
 step list 60 rocprofv3 -L
-step stats 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH
+# kernel time: the bench command in its default shape (3 warm-up + 5 x 20 timed steps), so that the kernel average covers the same launches
+# as bench.py's own HIP events (stats.log holds that run's JSON line: roofline.kernel_ms = the median block, repeats.kernel_ms_per_step = all)
+step stats 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --rollout-ticks 0 --no-cpu-baseline ${BENCH_ARGS:-}
 pmc() { step "pmc_$1" 200 rocprofv3 --kernel-trace --pmc ${@:2} --output-format csv -d "$OUT/pmc_$1" -- $BENCH; }
 pmc inst SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM
 pmc cyc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES
-pmc fetch FETCH_SIZE
-pmc write WRITE_SIZE
+# (FETCH_SIZE / WRITE_SIZE: tools/calib_traffic.sh — calibrated against known-byte-count kernels in the tick's own access pattern)
 pmc grbm GRBM_GUI_ACTIVE GRBM_COUNT
 # condense: per-counter sums for the tick kernel
 python3 - "$OUT" <<'PY'
