@@ -48,6 +48,7 @@ struct WbcBatch {
   int dbg_alias, dbg_stop;
   int count_pivoted, force_defer;   // diagnostics of the sim3 kernel's pivoted elimination / second pass
   int packed_kernel;     // 1 (default): eligible batches run four instances per wavefront (wbc_tick_sim3p_kernel)
+  int posture_par, last_posture_par;   // option [1]: MANI / HYBRID posture targets on wbc_posture_par_kernel (every finite-difference point on its own lane); what the last one ran on
   int packed_orth;       // 1 (default): equality-only task problems run four instances per wavefront (wbc_tick_orthp_kernel)
   int warm_start;        // 1: wbc_rollout carries each instance's working set from tick to tick (default 0: measured slower)
   int32_t* d_defer;      // [1 + max_batch]: count + compact list of the instances the sim3 kernel deferred (lazy)
@@ -151,7 +152,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
   b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->presolve_orth = 1; b->packed_update = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
-  b->jtj_mfma = -1; b->warm_start = 0; b->packed_kernel = 1; b->packed_orth = 1;
+  b->jtj_mfma = -1; b->warm_start = 0; b->packed_kernel = 1; b->packed_orth = 1; b->posture_par = 1;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
@@ -225,9 +226,44 @@ static int any_orth_plan(const WbcBatch* b) {
 // qpJointb "MANI"/"HYBRID" (Robot_Wrapper4.py:1220-1260) analysed on the tree: DoF i differentiates joint_id with respect to
 // q[qi]; that finite difference is exactly zero unless q[qi] belongs to the free-flyer or to a PROPER ancestor of joint_id
 // (wbc_posture_kernel makes the same test per sweep). If no sweep matters the tick kernels need no posture kernel at all.
+// The sweeps of qpJointb "MANI" / "HYBRID" that matter, for wbc_posture_par_kernel (same loop, same skips, same `matters` test as
+// wbc_posture_kernel): one record per sweep, with the configuration entries the reference's loop has left perturbed before it.
+static void build_posture_par_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) {
+  P->mp_ok = 0; P->mp_n = 0; P->mp_all = 0; P->mp_prevmode = 0;
+  const int mode = c.task_joint, literal = c.posture_literal;
+  if (mode != WBC_JOINT_MANI && mode != WBC_JOINT_HYBRID) return;
+  if (M.njoints > 22 || M.maxdepth > 8) return;
+  uint32_t prev = 0, swept = 0;
+  int n = 0;
+  for (int i = 0; i < M.nv; ++i) {
+    int joint_id;
+    if (mode == WBC_JOINT_MANI) joint_id = (i < 6) ? 1 : (literal ? i + 1 - 5 : i - 4);
+    else { joint_id = i - 6; if (joint_id < c.arm_base_id) continue; }
+    if (joint_id >= M.njoints) continue;
+    const int qi = literal ? i : ((i < 6) ? i : i + 1);
+    swept |= 1u << i;                                            // (a sweep that does not matter still sets u_i = 0.5 (0 - 0) / d = 0)
+    int jp = 1;
+    for (int j = 2; j < M.njoints; ++j) if (M.idx_q[j] == qi) jp = j;
+    const bool matters = (jp == 1) || (jp != joint_id && ((M.col_subtree[M.idx_v_of[jp]] >> joint_id) & 1u));
+    if (matters) {
+      if (n >= 32) return;
+      P->mp_i[n] = i; P->mp_qi[n] = qi; P->mp_joint[n] = joint_id; P->mp_prev[n] = literal ? prev : 0u;
+      int chain[8], len = 0;
+      for (int j = joint_id; j > 1; j = M.parent[j]) { if (len >= 8) return; chain[len++] = j; }
+      for (int k = 0; k < 8; ++k) P->mp_chain[n][k] = (k < len) ? chain[len - 1 - k] : -1;
+      ++n;
+    }
+    if (literal) prev |= 1u << qi;
+  }
+  P->mp_n = n; P->mp_all = literal ? prev : 0u;
+  if (mode == WBC_JOINT_HYBRID) P->mp_prevmode = ((M.nv >= 32) ? 0xFFFFFFFFu : ((1u << M.nv) - 1u)) & ~swept;   // DoF whose u stays the PREV value
+  P->mp_ok = 1;
+}
+
 static void build_posture_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) {
   const int mode = c.task_joint;
   if (mode != WBC_JOINT_MANI && mode != WBC_JOINT_HYBRID) return;
+  build_posture_par_plan(M, c, P);
   const int literal = c.posture_literal;
   uint32_t zero = 0, pert = 0;
   for (int i = 0; i < M.nv; ++i) {
@@ -469,6 +505,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
   if (!strcmp(name, "packed_kernel")) { b->packed_kernel = value; return WBC_OK; }
   if (!strcmp(name, "packed_orth")) { b->packed_orth = value; return WBC_OK; }
+  if (!strcmp(name, "posture_par")) { b->posture_par = value; return WBC_OK; }
   if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
   if (!strcmp(name, "warm_start")) { b->warm_start = value != 0; return WBC_OK; }
   if (!strcmp(name, "count_pivoted")) { b->count_pivoted = value != 0; return WBC_OK; }
@@ -489,6 +526,7 @@ extern "C" int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, i
   HIP_TRY(hipSetDevice(b->device_id));
   if (!strcmp(name, "last_path")) { *out = b->last_path; return WBC_OK; }
   if (!strcmp(name, "last_update_packed")) { *out = b->last_update_packed; return WBC_OK; }
+  if (!strcmp(name, "last_posture_par")) { *out = b->last_posture_par; return WBC_OK; }
   if (!strcmp(name, "last_orth")) { *out = (b->last_path == 0 || b->last_path == 3) ? b->last_orth : 0; return WBC_OK; }
   if (!strcmp(name, "deferred_last")) {      // waits for `stream`
     *out = 0;
@@ -631,8 +669,11 @@ static int validate_tick_in(const WbcBatch* b, const WbcTickIn* in, const char* 
 static int run_posture(WbcBatch* b, int B, const double* q, const int32_t* model_id, double* u, double* q_after, void* stream) {
   PostureArgs pa;
   memset(&pa, 0, sizeof pa);
-  pa.models = b->d_models; pa.cfgs = b->d_cfgs; pa.B = B; pa.n_models = b->n_models; pa.q = q; pa.model_id = model_id; pa.u = u; pa.q_after = q_after;
-  if (int e = launch_posture(pa, B, stream)) return fail(WBC_E_HIP, "posture kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  pa.models = b->d_models; pa.cfgs = b->d_cfgs; pa.plans = b->d_plans; pa.B = B; pa.n_models = b->n_models; pa.q = q; pa.model_id = model_id; pa.u = u; pa.q_after = q_after;
+  bool par = b->posture_par != 0;
+  for (int i = 0; i < b->n_models && par; ++i) par = b->configured[i] && b->plan_host[i].mp_ok != 0;
+  b->last_posture_par = par;
+  if (int e = par ? launch_posture_par(pa, B, stream) : launch_posture(pa, B, stream)) return fail(WBC_E_HIP, "posture kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return WBC_OK;
 }
 static int auto_posture(WbcBatch* b, KernelArgs& a, int B, void* stream) {

@@ -66,6 +66,16 @@ struct DevPlan {
   int32_t post_fk2;                  // 1: an active constraint depends on a perturbed joint -> second FK pass needed
   uint32_t post_zero;                // DoF bits
   uint32_t post_pert;                // q-index bits (literal mode only; 0 when the configuration is restored)
+  // qpJointb "MANI" / "HYBRID" with sweeps that DO matter: wbc_posture_par_kernel evaluates every finite-difference point on a lane of its own
+  // (the perturbations the reference accumulates are known up front: the configuration of sweep i is q0 with the entries of the earlier
+  // sweeps at (q + d) - 2 d). mp_n sweeps (<= 32); sweep k: DoF mp_i, perturbed configuration entry mp_qi, differentiated joint mp_joint, its
+  // ancestor chain (joints below the free-flyer, top down, -1 padded), configuration entries perturbed before it (literal mode)
+  int32_t mp_ok, mp_n, mp_pad_[2];
+  int32_t mp_i[32], mp_qi[32], mp_joint[32];
+  int32_t mp_chain[32][8];
+  uint32_t mp_prev[32];
+  uint32_t mp_all;                   // configuration entries left at (q + d) - 2 d when the loop is through (literal mode)
+  uint32_t mp_prevmode;              // DoF bits whose u is the PREV value (HYBRID: the DoF its loop skips); every other DoF: its sweep's value or 0
   uint32_t flags;                    // bit 0 con_com, 1 con_trunk, 2 task_trunk, 3 use_bounds, bits 4..6 task_joint
   uint32_t task_ee_mask, con_ee_mask; // bit e: cfg.task_ee[e] / cfg.con_ee[e] (one scalar instead of five flag loads per loop)
   int32_t rowstart[4];               // first constraint row of eliminated foot f
@@ -134,6 +144,7 @@ struct IntegrateArgs {
 struct PostureArgs {
   const DevModel* models;
   const WbcConfig* cfgs;
+  const DevPlan* plans;                // wbc_posture_par_kernel (every model's plan mp_ok); else unused
   int32_t B, n_models;
   const double* q;
   const int32_t* model_id;
@@ -170,6 +181,7 @@ int sim3_lds_bytes();
 int launch_qp(const QpArgs& a, int grid, void* stream);
 int launch_integrate(const IntegrateArgs& a, int grid, void* stream);
 int launch_posture(const PostureArgs& a, int grid, void* stream);
+int launch_posture_par(const PostureArgs& a, int grid, void* stream);   // every finite-difference point on its own lane (DevPlan.mp_ok)
 int launch_update(const UpdateArgs& a, int grid, void* stream);
 int launch_update_packed(const UpdateArgs& a, void* stream);   // four instances per wavefront (every plan pk_update_ok)
 int tick_lds_bytes();

@@ -3198,6 +3198,190 @@ __global__ void __launch_bounds__(64) wbc_posture_kernel(const PostureArgs A, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// qpJointb "MANI" / "HYBRID" (Robot_Wrapper4.py:1220-1260) with every finite-difference point on a LANE OF ITS OWN (round 3): one instance per
+// wavefront, lane e = 2 k + side evaluates f = sqrt(det(J J')) of sweep k's joint at q + d e_i (side 0) or (q + d e_i) - 2 d e_i (side 1).
+// The reference's loop is sequential only in appearance: in literal mode the perturbations accumulate, but the state sweep k
+// sees is known up front — q0 with the entries of the earlier sweeps at (q + d) - 2 d (DevPlan.mp_prev) — so all 2 x mp_n (<= 52) points
+// are independent. A lane walks the ancestor chain of its joint twice in registers (no cross-lane traffic): pass 1 the joint's origin,
+// pass 2 the LOCAL_WORLD_ALIGNED Jacobian columns (six of the free-flyer + one per chain joint) accumulated straight into G = J J'
+// (21 entries), then det by the elimination of wbc_posture_kernel. sin / cos of every joint angle in its three possible states (q, q + d,
+// (q + d) - 2 d) are computed once, one per lane, and shared through LDS. Sweeps that cannot change f (DevPlan: not in the list) are u = 0.
+// wbc_posture_kernel (52 sequential whole-tree sweeps per instance) stays as the fallback and as the cross-check in the tests.
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) MPSmem {
+  double q[32];
+  double sc[24 * 6];      // joint j: sin, cos of q, of q + d, of (q + d) - 2 d
+  double f[64];
+  double uo[32];          // u of the swept DoF
+};
+__global__ void __launch_bounds__(64) wbc_posture_par_kernel(const PostureArgs A, const DevModel* __restrict__ models,
+                                                             const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
+  __shared__ MPSmem S;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int mid = model_index(A.model_id, b, A.n_models);
+  const DevModel& M = models[mid];
+  const DevPlan& P = plans[mid];
+  const int nv = M.nv, nq = M.nq, nj = M.njoints;
+  const double dq = 0.0002;
+  const double q0 = (lane < nq) ? A.q[(size_t)b * NQ + lane] : 0.0;
+  if (lane < 32) S.q[lane] = q0;
+  // this lane's evaluation
+  const int k = lane >> 1, side = lane & 1;
+  const bool on = k < P.mp_n;
+  const int kk = on ? k : 0;
+  const int my_i = P.mp_i[kk], my_qi = P.mp_qi[kk];
+  const unsigned my_prev = P.mp_prev[kk];
+  int chain[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) chain[c] = on ? P.mp_chain[kk][c] : -1;
+  WSYNC();
+  // sin / cos table: lane t < 3 (nj - 2): joint 2 + t / 3 in state t % 3
+  {
+    const int j = 2 + lane / 3, st = lane - 3 * (lane / 3);
+    if (j < nj) {
+      const int jt = M.jtype[j];
+      if (jt >= WBC_JT_RX && jt <= WBC_JT_RZ) {
+        const double a0 = S.q[M.idx_q[j]];
+        const double a = (st == 0) ? a0 : ((st == 1) ? a0 + dq : (a0 + dq) - (dq * 2));
+        const SinCos t = sincos_cw(a);
+        S.sc[6 * j + 2 * st] = t.s; S.sc[6 * j + 2 * st + 1] = t.c;
+      }
+    }
+  }
+  WSYNC();
+  // state of configuration entry e for this lane: 0 = q, 1 = q + d, 2 = (q + d) - 2 d
+  auto state_of = [&](const int e) -> int { return (e == my_qi) ? (side ? 2 : 1) : (((my_prev >> e) & 1u) ? 2 : 0); };
+  auto value_of = [&](const int e) -> double {
+    const double a0 = S.q[e];
+    const int st = state_of(e);
+    return (st == 0) ? a0 : ((st == 1) ? a0 + dq : (a0 + dq) - (dq * 2));
+  };
+  double f = 0.0;
+  {
+    // the free-flyer: R from the (possibly perturbed, not renormalised) quaternion exactly as the FK does, p = xyz
+    const double qq[4] = {value_of(3), value_of(4), value_of(5), value_of(6)};
+    double R1[9];
+    quat_to_R(qq, R1);                                  // row-major
+    const double p1[3] = {value_of(0), value_of(1), value_of(2)};
+    double pJ[3] = {p1[0], p1[1], p1[2]};
+    double G[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) G[i] = 0.0;
+    auto add_col = [&](const double* c) {               // G += c c' (upper triangle, row-major packed)
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int bb = a; bb < 6; ++bb) { G[t] = fma(c[a], c[bb], G[t]); ++t; }
+    };
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      double X[3] = {R1[0], R1[3], R1[6]}, Y[3] = {R1[1], R1[4], R1[7]}, Z[3] = {R1[2], R1[5], R1[8]};   // columns of the parent's rotation
+      double p[3] = {p1[0], p1[1], p1[2]};
+      if (pass == 1) {   // free-flyer columns (LOCAL_WORLD_ALIGNED at the joint's origin): linear DoF (R e_i, 0), angular DoF (R e_i x (pJ - p1), R e_i)
+        const double dd[3] = {pJ[0] - p1[0], pJ[1] - p1[1], pJ[2] - p1[2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const double* ax = (i == 0) ? X : ((i == 1) ? Y : Z);
+          const double cl[6] = {ax[0], ax[1], ax[2], 0.0, 0.0, 0.0};
+          add_col(cl);
+          double cr[3];
+          cross3(ax, dd, cr);
+          const double ca[6] = {cr[0], cr[1], cr[2], ax[0], ax[1], ax[2]};
+          add_col(ca);
+        }
+      }
+#pragma unroll 1
+      for (int c = 0; c < 8; ++c) {
+        const int j = chain[c];
+        if (j < 0) continue;
+        const int a = M.ax0[j], jt = M.jtype[j];
+        const bool rev = jt >= WBC_JT_RX && jt <= WBC_JT_RZ;
+        const double t0 = M.tp[j][0], t1 = M.tp[j][1], t2 = M.tp[j][2];
+        const int qe = M.idx_q[j];
+        const int st = state_of(qe);
+        const double sn = rev ? S.sc[6 * j + 2 * st] : 0.0, cs = rev ? S.sc[6 * j + 2 * st + 1] : 1.0;
+        const double pris = rev ? 0.0 : value_of(qe);
+        double Av[3], Bv[3], Cv[3];                     // the axis column of the parent's rotation and its cyclic successors
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          Av[rr] = (a == 0) ? X[rr] : ((a == 1) ? Y[rr] : Z[rr]);
+          Bv[rr] = (a == 0) ? Y[rr] : ((a == 1) ? Z[rr] : X[rr]);
+          Cv[rr] = (a == 0) ? Z[rr] : ((a == 1) ? X[rr] : Y[rr]);
+        }
+        double nB[3], nC[3];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          nB[rr] = cs * Bv[rr] + sn * Cv[rr];
+          nC[rr] = cs * Cv[rr] - sn * Bv[rr];
+          p[rr] = p[rr] + Av[rr] * (t0 + pris) + Bv[rr] * t1 + Cv[rr] * t2;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          const double na = Av[rr], nb = nB[rr], nc = nC[rr];
+          X[rr] = (a == 0) ? na : ((a == 1) ? nc : nb);
+          Y[rr] = (a == 0) ? nb : ((a == 1) ? na : nc);
+          Z[rr] = (a == 0) ? nc : ((a == 1) ? nb : na);
+        }
+        if (pass == 1) {   // this joint's column: revolute (axis x (pJ - p), axis), prismatic (axis, 0)
+          double col[6];
+          if (rev) {
+            const double dd[3] = {pJ[0] - p[0], pJ[1] - p[1], pJ[2] - p[2]};
+            double cr[3];
+            cross3(Av, dd, cr);
+            col[0] = cr[0]; col[1] = cr[1]; col[2] = cr[2]; col[3] = Av[0]; col[4] = Av[1]; col[5] = Av[2];
+          } else { col[0] = Av[0]; col[1] = Av[1]; col[2] = Av[2]; col[3] = 0.0; col[4] = 0.0; col[5] = 0.0; }
+          add_col(col);
+        }
+      }
+      if (pass == 0) { pJ[0] = p[0]; pJ[1] = p[1]; pJ[2] = p[2]; }
+    }
+    // det of the symmetric positive semi-definite G by elimination without pivoting (det6_spd, on the packed upper triangle)
+    double m[6][6];
+    {
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int bb = a; bb < 6; ++bb) { m[a][bb] = G[t]; m[bb][a] = G[t]; ++t; }
+    }
+    double det = 1.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double piv = m[c][c];
+      det *= piv;
+      const double ip = (piv > 0.0) ? 1.0 / piv : 0.0;
+#pragma unroll
+      for (int rr = c + 1; rr < 6; ++rr) {
+        const double ff = m[rr][c] * ip;
+#pragma unroll
+        for (int kx = c + 1; kx < 6; ++kx) m[rr][kx] = fma(-ff, m[c][kx], m[rr][kx]);
+      }
+    }
+    f = sqrt(det > 0.0 ? det : 0.0);
+  }
+  S.f[lane] = on ? f : 0.0;
+  WSYNC();
+  // u by DoF: the sweep's central difference, the PREV value where the loop skips the DoF (HYBRID), else 0
+  double u = 0.0;
+  if (lane < nv && ((P.mp_prevmode >> lane) & 1u)) u = S.q[lane < 6 ? lane : lane + 1];
+  if (on && side == 0) S.uo[my_i & 31] = 0.5 * (S.f[lane] - S.f[lane + 1]) / dq;   // lane 2 k holds f1, lane 2 k + 1 f2 of sweep k
+  WSYNC();
+  if (lane < nv) {
+    bool mine = false;
+#pragma unroll 1
+    for (int t = 0; t < P.mp_n; ++t) mine |= (P.mp_i[t] == lane);
+    if (mine) u = S.uo[lane];
+  }
+  if (A.u && lane < NV) A.u[(size_t)b * NV + lane] = (lane < nv) ? u : 0.0;
+  if (A.q_after && lane < NQ) {
+    const double a0 = S.q[lane & 31];
+    A.q_after[(size_t)b * NQ + lane] = (lane < nq) ? (((P.mp_all >> lane) & 1u) ? (a0 + dq) - (dq * 2) : a0) : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The tail of runWBC: updateState(joint_config, base_config, running=True) (Robot_Wrapper4.py:1397-1399, 387-428) with
 // trunkWorldPos (:1297-1327). One instance per wave. In a rollout the same wave then applies the side effects qpb() has on
 // the controller's reference state (:1151-1152, :995-996) and moves the targets one step along their segment.
@@ -5214,6 +5398,10 @@ int launch_integrate(const IntegrateArgs& a, int grid, void* stream) {
 int launch_posture(const PostureArgs& a, int grid, void* stream) {
   hipLaunchKernelGGL(wbc_posture_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs);
   return check_launch("posture");
+}
+int launch_posture_par(const PostureArgs& a, int grid, void* stream) {
+  hipLaunchKernelGGL(wbc_posture_par_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  return check_launch("posture_par");
 }
 int launch_update(const UpdateArgs& a, int grid, void* stream) {
   hipLaunchKernelGGL(wbc_update_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs);

@@ -168,9 +168,15 @@ def test_posture_target_parity(wx200, px100, mode, literal):
     for i, c in enumerate(cfgs):
         bt.configure(c, i)
     u, qa = bt.posture_target(q, mid)
+    assert bt.stat("last_posture_par") == 1       # every finite-difference point on a lane of its own (wbc_posture_par_kernel)
     # f = sqrt(det(J J')) is O(1..10) and is differenced over 2e-4: rounding in f (1e-16 relative) shows as ~1e-11 in u
     assert np.abs(u - ur).max() < 1e-9
     assert (qa == qar).all()                      # same IEEE operations on q: bit-equal
+    bt.set_option("posture_par", 0)               # the sequential whole-tree kernel (52 sweeps per instance) says the same
+    u1, qa1 = bt.posture_target(q, mid)
+    assert bt.stat("last_posture_par") == 0
+    assert np.abs(u1 - ur).max() < 1e-9 and (qa1 == qar).all() and np.abs(u1 - u).max() < 1e-9
+    assert ((u == 0) == (u1 == 0)).all()          # the same DoF are exactly zero (sweeps that cannot change f, DoF the loop skips)
     assert np.abs(ur).max() > 1e-3
     if literal:
         assert np.abs(qa - q).max() == pytest.approx(2e-4, rel=1e-6)
