@@ -5013,84 +5013,68 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     }
   }
   WSYNC();
-  if (s < 6) {                               // row s of M = I + G'G
-    double mrow[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int l = 0; l < 12; ++l) {
-      const double gl = Gm[l * 6 + s];
-      const double2a t0 = lds2(Gm + l * 6), t1 = lds2(Gm + l * 6 + 2), t2 = lds2(Gm + l * 6 + 4);
-      mrow[0] = fma(gl, t0.x, mrow[0]); mrow[1] = fma(gl, t0.y, mrow[1]); mrow[2] = fma(gl, t1.x, mrow[2]);
-      mrow[3] = fma(gl, t1.y, mrow[3]); mrow[4] = fma(gl, t2.x, mrow[4]); mrow[5] = fma(gl, t2.y, mrow[5]);
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Mm[s * 6 + k] = mrow[k] + ((k == s) ? 1.0 : 0.0);
-  }
-  WSYNC();
-  // ---- L L' = M and Li = L^-1 in registers, the same on every lane of the instance (M >= I: no pivot can fail); Z = [S; G S], S = Li'
+  // ---- M = I + G'G (lane s < 6: row s) and its Cholesky factor L L' = M, COOPERATIVELY: lane r keeps row r of L in six registers, a finished
+  // row and the reciprocal of its pivot go through LDS (M >= I: no pivot can fail). Unrolled on every lane the factor and its inverse took
+  // 66+ VGPRs and pushed ~20 live values out to scratch — 0.35 GB of spill traffic per 65536-tick launch (FETCH_SIZE / WRITE_SIZE).
   double* const Zm = I.W;                    // [18][6]: rows 0..5 base DoF, 6 + l eliminated leg DoF l
+  double xc[6];
   {
-    double Lm[6][6], Li[6][6];
+    double Lr[6] = {0, 0, 0, 0, 0, 0};
+    if (s < 6) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const double2a a = lds2(Mm + 6 * i), bq = lds2(Mm + 6 * i + 2), c = lds2(Mm + 6 * i + 4);
-      Lm[i][0] = a.x; Lm[i][1] = a.y; Lm[i][2] = bq.x; Lm[i][3] = bq.y; Lm[i][4] = c.x; Lm[i][5] = c.y;
+      for (int l = 0; l < 12; ++l) {
+        const double gl = Gm[l * 6 + s];
+        const double2a t0 = lds2(Gm + l * 6), t1 = lds2(Gm + l * 6 + 2), t2 = lds2(Gm + l * 6 + 4);
+        Lr[0] = fma(gl, t0.x, Lr[0]); Lr[1] = fma(gl, t0.y, Lr[1]); Lr[2] = fma(gl, t1.x, Lr[2]);
+        Lr[3] = fma(gl, t1.y, Lr[3]); Lr[4] = fma(gl, t2.x, Lr[4]); Lr[5] = fma(gl, t2.y, Lr[5]);
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Lr[k] += (k == s) ? 1.0 : 0.0;
     }
-    double dinv[6];
+    double* const Lq = Mm;                   // finished rows of L [6][6], then 1 / L_jj at [36 + j]
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      double v = Lm[j][j];
+      double v = Lr[j];
 #pragma unroll
-      for (int k = 0; k < j; ++k) v = fma(-Lm[j][k], Lm[j][k], v);
+      for (int k = 0; k < j; ++k) v = fma(-Lr[k], Lr[k], v);
+      v = (s == j) ? v : 1.0;
       double rs = __builtin_amdgcn_rsq(v);
       rs = rs * fma(-0.5 * v * rs, rs, 1.5); rs = rs * fma(-0.5 * v * rs, rs, 1.5);
-      dinv[j] = rs;
-      Lm[j][j] = v * rs;
+      if (s == j) {
+        Lr[j] = v * rs;
 #pragma unroll
-      for (int i = j + 1; i < 6; ++i) {
-        double w = Lm[i][j];
+        for (int k = 0; k <= j; ++k) Lq[j * 6 + k] = Lr[k];
+        Lq[36 + j] = rs;
+      }
+      WSYNC();
+      if (j < 5) {
+        double w = Lr[j];
 #pragma unroll
-        for (int k = 0; k < j; ++k) w = fma(-Lm[i][k], Lm[j][k], w);
-        Lm[i][j] = w * rs;
+        for (int k = 0; k < j; ++k) w = fma(-Lr[k], Lq[j * 6 + k], w);
+        if (s > j && s < 6) Lr[j] = w * Lq[36 + j];
       }
     }
+    // lane c = min(s, 5): column c of L^-1 (L x = e_c; entries above c are zero) = row c of S = L^-T, the base part of Z
+    const int cs = s < 6 ? s : 5;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
+    for (int i = 0; i < 6; ++i) {
+      double w = (i == cs) ? 1.0 : 0.0;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        if (i < c) Li[i][c] = 0.0;
-        else {
-          double w = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-          for (int k = c; k < i; ++k) w = fma(-Lm[i][k], Li[k][c], w);
-          Li[i][c] = w * dinv[i];
-        }
-      }
-    }
-    double grow[6];
-    if (s < 12) {
-      const double2a a = lds2(Gm + s * 6), bq = lds2(Gm + s * 6 + 2), c = lds2(Gm + s * 6 + 4);
-      grow[0] = a.x; grow[1] = a.y; grow[2] = bq.x; grow[3] = bq.y; grow[4] = c.x; grow[5] = c.y;
+      for (int k = 0; k < i; ++k) w = fma(-Lq[i * 6 + k], xc[k], w);
+      xc[i] = (i < cs) ? 0.0 : w * Lq[36 + i];
     }
     WSYNC();                                 // (the m c table in W has been read by everyone: W becomes Z)
-    if (s < 6) {
-      double srow[6];
+    if (s < 6) { sts2(Zm + s * 6, xc[0], xc[1]); sts2(Zm + s * 6 + 2, xc[2], xc[3]); sts2(Zm + s * 6 + 4, xc[4], xc[5]); }   // S[s][k] = Li[k][s]
+    WSYNC();
+    if (s < 12) {                            // Z_leg row s = G row s times S
+      const double2a a = lds2(Gm + s * 6), bq = lds2(Gm + s * 6 + 2), c = lds2(Gm + s * 6 + 4);
+      const double grow[6] = {a.x, a.y, bq.x, bq.y, c.x, c.y};
+      double o[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        double v = 0.0;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) v = (s == c) ? Li[k][c] : v;
-        srow[k] = v;
-      }
-      sts2(Zm + s * 6, srow[0], srow[1]); sts2(Zm + s * 6 + 2, srow[2], srow[3]); sts2(Zm + s * 6 + 4, srow[4], srow[5]);
-    }
-    if (s < 12) {
-      double o[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        double v = 0.0;
-#pragma unroll
-        for (int c2 = 0; c2 <= k; ++c2) v = fma(grow[c2], Li[k][c2], v);
-        o[k] = v;
+      for (int c2 = 0; c2 < 6; ++c2) {
+        const double2a z0 = lds2(Zm + c2 * 6), z1 = lds2(Zm + c2 * 6 + 2), z2 = lds2(Zm + c2 * 6 + 4);
+        o[0] = fma(grow[c2], z0.x, o[0]); o[1] = fma(grow[c2], z0.y, o[1]); o[2] = fma(grow[c2], z1.x, o[2]);
+        o[3] = fma(grow[c2], z1.y, o[3]); o[4] = fma(grow[c2], z2.x, o[4]); o[5] = fma(grow[c2], z2.y, o[5]);
       }
       double* zr = Zm + (6 + s) * 6;
       sts2(zr, o[0], o[1]); sts2(zr + 2, o[2], o[3]); sts2(zr + 4, o[4], o[5]);
@@ -5117,10 +5101,11 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     }
     WSYNC();
     if (cc < 6) {
+      // (the leg window of Z column cc straight from LDS: picked out of the register copy by `ef`, the compiler turned Zc into a scratch array)
+      const int jl = 6 + 3 * (ef < 0 ? 0 : ef);
       double zw[3];
 #pragma unroll
-      for (int jj = 0; jj < 3; ++jj) zw[jj] = (ef == 0) ? Zc[6 + jj] : (ef == 1) ? Zc[9 + jj] : (ef == 2) ? Zc[12 + jj] : (ef == 3) ? Zc[15 + jj] : 0.0;
-      const int jl = 6 + 3 * (ef < 0 ? 0 : ef);
+      for (int jj = 0; jj < 3; ++jj) zw[jj] = (ef >= 0) ? Zm[(jl + jj) * 6 + cc] : 0.0;
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr) {
         const double* row = Ab + (3 * hh + rr) * 18;
@@ -5155,6 +5140,18 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
       }
     }
   };
+  // (the CoM block goes first — H' is a sum, the order is free — so that its Jacobian columns are dead before the EE loop: live across it they
+  //  were spilled around the loop, 20 values per lane per wave)
+  if (__ballot(c_com)) {   // Robot_Wrapper2 comJacobian (:600-603), cartesianTargetCoM (:661-668)
+    double a0[6] = {0, 0, 0, 0, 0, 0}, a1[6] = {0, 0, 0, 0, 0, 0}, br[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      const double cw = wt[WT_CW + rr];
+      a0[rr] = cw * jc0[rr]; a1[rr] = has1 ? cw * jc1[rr] : 0.0;
+      br[rr] = I.in[61 + rr] + wt[WT_CG + rr] * (I.in[58 + rr] - com[rr]);
+    }
+    block(a0, a1, br, -1, true, true);
+  }
   const unsigned tmask = (unsigned)__builtin_amdgcn_readfirstlane((int)P.task_ee_mask);
   const unsigned armsup = (unsigned)__builtin_amdgcn_readfirstlane((int)P.q_armsup);
 #pragma unroll 1
@@ -5183,16 +5180,6 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
 #pragma unroll
     for (int i = 1; i < 5; ++i) ef = (e == i) ? efoot[i] : ef;
     block(a0, a1, br, ef, false, (armsup >> e) & 1u);
-  }
-  if (__ballot(c_com)) {   // Robot_Wrapper2 comJacobian (:600-603), cartesianTargetCoM (:661-668)
-    double a0[6] = {0, 0, 0, 0, 0, 0}, a1[6] = {0, 0, 0, 0, 0, 0}, br[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {
-      const double cw = wt[WT_CW + rr];
-      a0[rr] = cw * jc0[rr]; a1[rr] = has1 ? cw * jc1[rr] : 0.0;
-      br[rr] = I.in[61 + rr] + wt[WT_CG + rr] * (I.in[58 + rr] - com[rr]);
-    }
-    block(a0, a1, br, -1, true, true);
   }
   // posture rows (qpJointA / qpJointb, :1199-1268): Z'(d^2 I)Z = d^2 I; the target's part of g through Z
   const double joint_w = wt[84];

@@ -22,6 +22,7 @@ for models in ([wx], [wx, px]):
     bt = WbcBatch(models, Bc)
     for i, c in enumerate(cfgs):
         bt.configure(c, i)
+    bt.set_option("packed_orth", 2)      # (1, the default, keeps batches below WBC_ORTHP_MIN_BATCH on the one-instance kernel)
     got = bt.tick(d, 0.002, want_q_next=True)
     path = bt.stat("last_path")
     ok = ref["status"] == 0

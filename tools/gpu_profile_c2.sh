@@ -17,7 +17,9 @@ pmc inst SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INST
 pmc cyc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 pmc mfma SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 pmc grbm GRBM_GUI_ACTIVE GRBM_COUNT
-pmc mem FETCH_SIZE WRITE_SIZE
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950: 3 + 2 of the 4 TCC slots)
+pmc fetch FETCH_SIZE
+pmc write WRITE_SIZE
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys, collections
 out = sys.argv[1]
