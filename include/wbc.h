@@ -314,9 +314,19 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *   "sim3_kernel"      [1] batches whose every model has such an elimination plan, <= 16 constraint rows and no orientation
  *                          references run on the compact wbc_tick_sim3_kernel (+ a second pass of the general kernel over the
  *                          instances whose leg blocks it could not eliminate); 0: the general kernel does the elimination.
- *   "packed_kernel"    [1] batches of the sim3 switch-set family itself (Grip task or none, trunk box + foot contacts, velocity
- *                          bounds, posture PREV / Tikhonov / static HYBRID; no warm start; the gripper's orientation reference is honoured) run FOUR
- *                          instances per wavefront (wbc_tick_sim3p_kernel); 0: one instance per wavefront (wbc_tick_sim3_kernel).
+ *   "packed_kernel"    [1] batches of the sim3 switch-set family itself (Grip task or none, optionally the trunk task, trunk box + foot
+ *                          contacts, velocity bounds, posture PREV / Tikhonov / static HYBRID; the gripper's orientation reference is
+ *                          honoured; working sets in and out are taken: the WARM variant) run FOUR instances per wavefront
+ *                          (wbc_tick_sim3p_kernel: ONE kernel per tick — an instance it cannot reduce, a stance-leg block of rank < 2, is
+ *                          redone by its own wave on the general path at the end of the same kernel); 0: one instance per wavefront
+ *                          (wbc_tick_sim3_kernel + second pass). Also gates "packed_orth".
+ *   "packed_orth"      [1] the equality-only task problems (BASELINE configs[1]: EE tasks + CoM task + posture Tikhonov / PREV, foot
+ *                          contacts the only constraints, no velocity box) run FOUR instances per wavefront on wbc_tick_orthp_kernel
+ *                          (orthonormal contact presolve, unconstrained reduced problem) from 4608 instances on — below that one round
+ *                          of waves covers the batch and the one-instance kernel's shorter dependent chain wins (25 vs 55 us at
+ *                          B = 1024, equal at 4096, 0.29 vs 0.78 ms at 65536); 2: at every batch size; 0: never.
+ *   "posture_par"      [1] qpJointb "MANI" / "HYBRID" targets on wbc_posture_par_kernel (every finite-difference point on a lane of
+ *                          its own, statistic "last_posture_par"); 0: the sequential whole-tree kernel (52 sweeps per instance).
  *   "packed_update"    [1] wbc_update_state / the roll-out's state update run four instances per wavefront where every model's
  *                          configuration is of the packed kernel's family (statistic "last_update_packed"); 0: one per wavefront.
  *   "presolve_tol_exp" [7] a stance-leg 3 x 3 block K with |det K| <= 10^-value (sum |K_ij|)^3 is treated as rank deficient: the
@@ -325,13 +335,17 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          0: every block of every instance takes that path.
  *   "count_pivoted"    [0] diagnostic: count the instances that took the pivoted elimination (statistic "pivoted_last"; one
  *                          atomic per such instance — leave it off when timing).
- *   "dbg_force_defer"  [0] diagnostic: an instance with a flagged block is handed to the second pass (general kernel over the
- *                          compact list) instead — the path a block of rank < 2 takes.
+ *   "dbg_force_defer"  [0] diagnostic: an instance with a flagged block takes the path of a block of rank < 2 instead of the pivoted
+ *                          elimination — the packed kernel's tail (general path, same kernel), the one-instance kernel's second pass.
  *   "warm_start"       [0] 1: wbc_rollout carries every instance's final working set into its next tick (the hot start the
  *                          reference gets from QP.solveQPHotstart, Robot_Wrapper4.py:1389-1394); 0: every tick starts cold.
- *                          Same minimiser either way (H > 0). Off by default because it measured 4 % SLOWER on MI355X
- *                          (profiles/r02_rollout_warm_vs_cold.txt): a sim3 tick has ~1.6 active inequalities, and seeding them
- *                          costs the wavefront as much as the ~1.6 dual iterations it replaces.
+ *                          Same minimiser either way (H > 0). Warm ticks stay on the packed kernel (its WARM variant: seeds through
+ *                          the add step, x / u rebuilt from the factors, restoration). Measured on MI355X at B = 65536
+ *                          (profiles/r03_rollout_warm_vs_cold.txt): closed loop 277.5 vs 280.6 M ticks/s un-stressed (-1 %), 190.0
+ *                          vs 197.7 M on the stress recipe (-4 %); open-loop ticks seeded with their own set +2 % / 0 %, with the
+ *                          previous tick's -1.5 %: a dual method that starts at the unconstrained minimiser needs one iteration
+ *                          per active inequality (0.9-1.05 here), a seed replaces it by an add step + a share of the rebuild, and
+ *                          both pay the final feasibility scan. Off by default; never the 2.2x of round 2's fallback kernel.
  *                          (wbc_tick is warm exactly when WbcTickIn.working_set is passed.)
  *   "grid"                 workgroups of the grid-stride kernels (wbc_qp_solve*, wbc_integrate); default = what fills the chip.
  *   "dbg_alias_inputs" [0] diagnostic: every instance reads instance 0's inputs (isolates input latency in timings).
@@ -340,11 +354,12 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
 int wbc_batch_set_option(WbcBatch* b, const char* name, int value);
 
 /* Read-only statistics of a handle: "last_path" (kernel the last tick ran on: 0 general, 1 compact sim3 + second pass, 2 packed
- * compact sim3 — four instances per wavefront — + second pass), "last_orth" (1: that general-kernel tick ran the variant with the
- * orthonormal contact presolve, option "presolve_orth"), "last_update_packed" (1: the last state update ran on the packed kernel),
- * "deferred_last" (instances the last sim3-kernel tick left to the second pass; waits for `stream`), "pivoted_last" (instances
- * that took the pivoted elimination, with option "count_pivoted"),
- * "sim3_lds_bytes" / "tick_lds_bytes" (LDS per instance of the two tick kernels). */
+ * compact sim3 — four instances per wavefront, one kernel —, 3 packed orth kernel), "last_orth" (1: that tick ran with the
+ * orthonormal contact presolve, option "presolve_orth": the general kernel's ORTH variant or the packed orth kernel),
+ * "last_update_packed" (1: the last state update ran on the packed kernel), "last_posture_par" (1: the last MANI / HYBRID posture target
+ * ran on wbc_posture_par_kernel), "deferred_last" (instances the last tick's kernel could not reduce itself: redone in the packed kernels'
+ * tail or left to the one-instance kernel's second pass; waits for `stream`), "pivoted_last" (instances that took the pivoted
+ * elimination, with option "count_pivoted"), "sim3_lds_bytes" / "tick_lds_bytes" / "orthp_lds_bytes" (LDS per workgroup of the tick kernels). */
 int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, int64_t* out);
 
 /* wait for everything queued by this handle on `stream`. */
