@@ -881,6 +881,47 @@ def test_infeasible_and_degenerate_instances_agree_with_the_oracle(wx200):
     bt.close()
 
 
+@pytest.mark.parametrize("posture", ["TIKHONOV", "PREV"])
+def test_packed_orth_kernel_variants_and_non_finite_inputs(wx200, px100, posture):
+    """wbc_tick_orthp_kernel beyond BASELINE configs[1]'s own switch set: the PREV posture target (its part of g goes through Z), a mixed
+    wx200 / px100 batch at a size the default policy sends to it (B >= 4608), ragged tail (B not a multiple of four), q_next, and non-finite
+    inputs — an instance with a NaN / Inf in its state is flagged like the oracle flags it, returns q̇ = 0 and does not disturb the three
+    other instances of its wavefront."""
+    B = 4610
+    models = [wx200, px100]
+    cfgs = [wbc_model.make_config(m, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=(True if posture == "TIKHONOV" else "PREV"), task_com=True,
+                                  cFR=True, cFL=True, cRR=True, cRL=True, use_bounds=False) for m in models]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=31 + i) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    d["q"] = d["q"].copy()
+    d["q"][5, 9] = np.nan                       # a leg angle
+    d["q"][1002, 4] = np.inf                    # a quaternion component
+    d["ee_target"] = d["ee_target"].copy()
+    d["ee_target"][2007, 4, 1] = np.nan         # the gripper target
+    ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
+    bad = np.zeros(B, bool)
+    bad[[5, 1002, 2007]] = True
+    assert (ref["status"][bad] != 0).all() and (ref["status"][~bad] == 0).mean() > 0.99
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    got = bt.tick(d, DT, want_q_next=True)
+    assert bt.stat("last_path") == 3 and bt.stat("last_orth") == 1     # the default policy: packed from 4608 instances on
+    ok = ref["status"] == 0
+    assert ((got["status"] != 0) == (ref["status"] != 0)).all()
+    assert (got["qdot"][~ok] == 0).all() and np.isfinite(got["qdot"]).all()
+    err = np.abs(got["qdot"] - ref["qdot"])[ok].max()
+    print("packed orth kernel, posture %s, mixed batch: qdot max-abs err %.3e" % (posture, err))
+    assert err < QDOT_TOL and np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    assert (got["iters"][ok] == 12).all()
+    bt.set_option("packed_orth", 0)
+    one = bt.tick(d, DT)
+    assert bt.stat("last_path") == 0 and np.abs(one["qdot"] - got["qdot"])[ok].max() < 1e-6
+    bt.close()
+
+
 def test_rollouts_are_deterministic_and_survive_unsolvable_ticks(wx200):
     """Run-to-run bit equality of a long roll-out in which some instances run into unsolvable QPs on the way (they hold
     still from then on instead of integrating a partial iterate into garbage — found with tools/determinism.py)."""

@@ -9,9 +9,9 @@ from wbc_batch import WbcBatch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 wx, px = common.models()
-threads = len(os.sched_getaffinity(0))
+threads = min(32, len(os.sched_getaffinity(0)))   # (the box's CPU share: 32 threads beat 256, bench.py's sweep)
 worst = 0.0
-for cfg_name in ("c3", "c3_hybrid", "c2", "everything"):
+for cfg_name in ("c3", "c3_hybrid", "c3_trunk_task", "c3_mani", "c2", "everything"):
     for mixed in (False, True):
         if mixed and cfg_name != "c3":
             continue
@@ -21,7 +21,7 @@ for cfg_name in ("c3", "c3_hybrid", "c2", "everything"):
         for i, c in enumerate(cfgs):
             bt.configure(c, i)
         for seed in range(seeds):
-            n = B if cfg_name in ("c3", "c3_hybrid") else B // 8
+            n = B if cfg_name in ("c3", "c3_hybrid") else B // 8      # (B // 8 = 32768 by default: config 2 runs on the packed orth kernel)
             if mixed:
                 mid = (np.arange(n) % 2).astype(np.int32)
                 parts = [common.tick_inputs(m, c, n, 1000 + seed + 17 * k) for k, (m, c) in enumerate(zip(models, cfgs))]
@@ -33,13 +33,14 @@ for cfg_name in ("c3", "c3_hybrid", "c2", "everything"):
             ref = oracle.tick(models, cfgs, d, 0.002, n, nthreads=threads, want_q_next=False)
             t1 = time.perf_counter()
             got = bt.tick(d, 0.002)
+            path = bt.stat("last_path")
             ok = (ref["status"] == 0) & (got["status"] == 0)
             err = np.abs(got["qdot"] - ref["qdot"]).max(axis=1)
             agree = (ref["status"] == got["status"]).mean()
             bad = int((~np.isfinite(got["qdot"])).any(axis=1).sum())
             worst = max(worst, err[ok].max())
             print("%-11s mixed=%d seed %d n=%d: status agree %.6f (optimal %.4f, infeasible %.4f), qdot err max %.2e p99.9 %.2e, "
-                  "non-finite rows %d, oracle %.1f s" % (cfg_name, mixed, seed, n, agree, (ref["status"] == 0).mean(),
-                                                          (ref["status"] == 2).mean(), err[ok].max(), np.quantile(err[ok], 0.999), bad, t1 - t0), flush=True)
+                  "non-finite rows %d, oracle %.1f s, kernel path %d" % (cfg_name, mixed, seed, n, agree, (ref["status"] == 0).mean(),
+                                                          (ref["status"] == 2).mean(), err[ok].max(), np.quantile(err[ok], 0.999), bad, t1 - t0, path), flush=True)
         bt.close()
 print("worst qdot error over all optimal instances: %.3e" % worst)
