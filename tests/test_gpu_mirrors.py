@@ -51,6 +51,31 @@ def test_qp_class_matches_reference_surface_and_oracle():
     assert np.abs(qm.solveQP() - ref["qdot"][0]).max() < 1e-5
 
 
+def test_integration_md_ctypes_stub_runs_as_written():
+    """INTEGRATION.md §2 shows the ctypes binding a maintainer of the reference would add to QP_Wrapper.py. Execute that very block (only the
+    library path is substituted): cold solve = the oracle's answer, hot-started solve = the same answer in no more working-set changes."""
+    import re
+    root = os.path.dirname(HERE)
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "wbc_qp_solve_ls.argtypes" in b)
+    stub = stub.replace('C.CDLL("libwbc_hip.so")', "C.CDLL(%r)" % capi.LIB_PATH)
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md#stub", "exec"), ns)
+    wx = wbc_model.load_model("a1_wx200")
+    cfg = common.config("c1", wx)
+    d = common.tick_inputs(wx, cfg, 2, seed=50)
+    a = oracle.assemble([wx], [cfg], d, DT, 2)
+    ref = oracle.tick([wx], [cfg], d, DT, 2)
+    for k in range(2):
+        args = (a["A"][k], a["b"][k], a["lb"][k].copy(), a["ub"][k].copy(), a["C"][k].T, a["Clb"][k].copy(), a["Cub"][k].copy(), 26)
+        x, st = ns["_solve"](*args)                      # cold (solveQP)
+        assert st == 0 and np.abs(x - ref["qdot"][k]).max() < 1e-5
+        x2, st2 = ns["_solve"](*args, hot=True)          # solveQPHotstart: seeded with the set the cold solve left in _ws
+        assert st2 == 0 and np.abs(x2 - ref["qdot"][k]).max() < 1e-5
+        assert ns["_ws"].any()                           # a working set came back
+
+
 GOLDEN_CFG = {"tick_c1": "c1", "tick_c2": "c2", "tick_c3": "c3", "tick_c5_mixed": "c3", "tick_everything": "everything",
               "tick_c3_hybrid": "c3_hybrid", "tick_c3_mani": "c3_mani"}
 
