@@ -749,7 +749,7 @@ constexpr int WBC_ORTHP_MIN_BATCH = 4608;
 static bool orthp_eligible(const WbcBatch* b, const KernelArgs& a) {
   if (b->packed_orth == 1 && a.B < WBC_ORTHP_MIN_BATCH) return false;
   if (!b->packed_orth || !b->packed_kernel || !b->presolve || !b->presolve_orth || b->n_models < 1 || b->jtj_mfma > 0) return false;
-  if (a.ws_in || a.ws_out || a.in.q_con || a.in.posture_u || a.in.ee_ref_rot || b->dbg_alias || b->dbg_stop) return false;
+  if (a.ws_in || a.ws_out || a.in.q_con || a.in.posture_u || a.in.ee_ref_rot || b->dbg_alias || (b->dbg_stop > 0 && b->dbg_stop < 200)) return false;   // (dbg_stop 201.. cuts this kernel)
   for (int i = 0; i < b->n_models; ++i) if (!b->plan_host[i].q_ok) return false;
   return true;
 }

@@ -4817,6 +4817,11 @@ static_assert(offsetof(QInst, xv) - offsetof(QInst, cl) == 80 * sizeof(double), 
 static_assert(offsetof(WbcConfig, joint_w) - offsetof(WbcConfig, ee_W) == 84 * sizeof(double), "ee_W [30] ee_w [5] ee_gain [30] trunk [13] com_W [3] com_gain [3] joint_w");
 constexpr int WT_W = 0, WT_w = 30, WT_G = 35, WT_CW = 78, WT_CG = 81;   // offsets inside wt
 
+#ifdef WBC_ABLATE   // timing cuts 201.. (tools/ablate_orthp.py): the kernel returns after stage k with garbage
+#define QSTOP(k, val) do { if (A.dbg_stop == 200 + (k)) { if (valid) { A.out.qdot[(size_t)b * NV + s] = (val); if (s == 0) A.out.status[b] = 0; } return; } } while (0)
+#else
+#define QSTOP(k, val) do { } while (0)
+#endif
 __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                                const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   __shared__ union { QInst Q[4]; Smem G; } SU;
@@ -4883,6 +4888,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     }
   }
   WSYNC();
+  QSTOP(1, sc[4 + s] + oMi[12 + s]);
   // ---- pin.forwardKinematics, level by level (Robot_Wrapper4.py:400)
 #pragma unroll 1
   for (int L = 0; L < QLEV; ++L) {
@@ -4909,6 +4915,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     }
     WSYNC();
   }
+  QSTOP(2, oMi[12 * 4 + (s & 7)]);
   // ---- frame origins (updateFramePlacements, :405), m c per joint, Jacobian columns (WORLD) of DoF s and 16 + s
   double ms_l = 0.0, sl[3] = {0, 0, 0};
   {
@@ -4977,6 +4984,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     jcom(D0, lin0, ang0, true, jc0);
     jcom(D1, lin1, ang1, has1, jc1);
   }
+  QSTOP(3, lin0[0] + ang0[1] + lin1[2] + jc0[0] + jc1[1] + com[2]);
   // ---- contact rows (EEConstraint, :757-761: WORLD linear rows): K (leg DoF) and B (base DoF) through LDS, G = -K^-1 B
   double* const Kb = I.X;                    // [12][4]
   double* const Bb = I.X + 48;               // [6][4]
@@ -5081,6 +5089,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     }
   }
   WSYNC();
+  QSTOP(4, Zm[s * 6 + 1] + lin0[0] + lin1[1] + jc0[2] + jc1[0]);
   // ---- the task stack, one block of six rows at a time
   const int hh = s >> 3, cc = s & 7;         // A Z: lane (hh, cc < 6) forms rows 3 hh .. 3 hh + 2 of the block for base-reduced variable cc
   double Zc[18];
@@ -5181,6 +5190,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     for (int i = 1; i < 5; ++i) ef = (e == i) ? efoot[i] : ef;
     block(a0, a1, br, ef, false, (armsup >> e) & 1u);
   }
+  QSTOP(5, h[0] + h[5] + h[13] + gacc);
   // posture rows (qpJointA / qpJointb, :1199-1268): Z'(d^2 I)Z = d^2 I; the target's part of g through Z
   const double joint_w = wt[84];
   const double dpost = (1.0 / nv) * joint_w;
@@ -5240,6 +5250,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     y[14] = fma(-ty2, 0.0, yk); y[15] = yk2;
     h[14] = 0.0; h[15] = 0.0;
   }
+  QSTOP(6, y[0] + y[15] + h[0]);
   int status = WBC_QP_OPTIMAL;
   if (!(pmin > 0.0)) status = WBC_QP_NUMERICAL;
   WSYNC();
