@@ -56,7 +56,7 @@ struct WbcBatch {
   uint32_t tick_seq;
   int packed_update, last_update_packed;   // option: wbc_update_packed_kernel where every plan allows it [1]; what the last update ran on
   int last_orth;         // the last general-kernel tick ran the variant with the orthonormal contact presolve
-  int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass)
+  int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass), 2 packed sim3, 3 packed orth
   int max_nj, max_nf;    // FK output strides: the largest model's joint / frame counts
   unsigned long long* d_prof;
   double *d_pu, *d_pq;   // qpJointb MANI/HYBRID results: u [max_batch][26], q_after [max_batch][27] (lazy)

@@ -3527,9 +3527,11 @@ __device__ __forceinline__ void tail_instance(Smem* Sp, const int bt_v, const De
 //   QP          the dual active-set of qp_core with per-row state: reductions are DPP row butterflies (no v_readlane), a value
 //               at a row-dependent lane comes through ds_bpermute, the Cholesky column is broadcast through a per-instance LDS
 //               vector, control flow is per-row predication with the loops running to the slowest of the four instances.
-// Applies to the sim3 switch-set family only (launch_tick_auto): Grip task or none, posture PREV / Tikhonov / static HYBRID, trunk
-// box + foot contacts, velocity bounds on, no CoM rows, nothing warm (the gripper's orientation reference is honoured). Instances with a rank-deficient
-// leg block go to the compact list and are redone by the one-instance kernels. Same arithmetic per instance as process_sim3.
+// Applies to the sim3 switch-set family only (launch_tick_auto): Grip task or none, optionally the trunk task (TRUNK variant), posture PREV /
+// Tikhonov / static HYBRID, trunk box + foot contacts, velocity bounds on, no CoM rows; working sets in and out on the WARM variant; the gripper's
+// orientation reference is honoured. A rank-deficient leg block is pivoted in place (the swap); instances with a
+// leg block of rank < 2 are redone on the general path by their own wave at the end of this kernel (the tail: tail_instance). Same arithmetic per
+// instance as process_sim3.
 // ================================================================================================
 constexpr int PLD = 14;                     // row stride of the matrices (even: rows are 16-byte aligned for ds_read_b128; 7 s mod 16 is a
                                             // permutation, so "lane = row" b128 reads of two instances interleave conflict-free)
@@ -4126,7 +4128,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       WSYNC();
     }
   }
-  // a row of the batch tail does nothing; an instance with a leg block of rank < 2 is left to the general kernel (compact list)
+  // a row of the batch tail does nothing; an instance with a leg block of rank < 2 is left to this kernel's tail (general path, same wave)
   PSTOP(3, h[0] + h[3] + g + clb + cub + lb + ub);
   const bool flagged = defer;
   bool live = valid && !flagged;

@@ -719,7 +719,7 @@ def test_rollout_parity(wx200, cfg_name, K, with_imu):
     ok = ref["status"] == 0
     assert ok.mean() > 0.8
     res = {}
-    for warm in (1, 0):      # default: every tick seeded with the previous tick's working set (f2); 0: cold, like the oracle's ticks
+    for warm in (1, 0):      # 1: every tick seeded with the previous tick's working set (f2; off by default); 0: cold, like the oracle's ticks
         bt.set_option("warm_start", warm)
         got = res[warm] = bt.rollout(d, DT, K, ee_target_step=step, trunk_target_step=tstep, imu=imu)
         if cfg_name in ("c3", "c3_hybrid"):
