@@ -351,3 +351,80 @@ def test_packed_warm_start_variant_reaches_the_same_optimum():
         assert s4 == 0 and np.abs(x4 - xr).max() < 1e-8 and sorted(ws4) == sorted(ws0)
     assert cold_it > 0 and own_it <= cold_it
     print("working-set changes: cold %d, seeded with the own set %d, with the previous tick's set %+d vs cold" % (cold_it, own_it, prev_d))
+
+
+def test_packed_orth_kernel_formulation_restated_in_numpy():
+    """What wbc_tick_orthp_kernel computes for BASELINE configs[1], in numpy from the oracle's A, b and contact rows:
+    G = -K^-1 B per foot, the Cholesky factor of M = I + G'G row by row (the cooperative form: a finished row and 1 / L_jj are broadcast),
+    S = L^-T by one forward substitution per column, Z = [S; G S]; then block by block (CoM first, then the EE tasks) H' += (A_blk Z)'(A_blk Z)
+    and g' -= (A_blk Z)'b_blk, H' += d^2 I; the 16 x 16 Cholesky sweep with the substitutions L y_s = e_s and — on the padding lane — L z = g';
+    y = -L^-T z as a dot product per variable; qd = Z y. Same answer as the oracle's full-size solve with its 12 equality rows."""
+    wx, px = common.models()
+    for model in (wx, px):
+        cfg = common.config("c2", model)
+        B = 16
+        d = common.tick_inputs(model, cfg, B, seed=9)
+        qp = oracle.assemble([model], [cfg], d, DT, B)
+        ref = oracle.tick([model], [cfg], d, DT, B)
+        nv = model.nv
+        for b in range(B):
+            A, bv, Cm = qp["A"][b][:, :nv], qp["b"][b], qp["C"][b][:, :nv]
+            mcart = A.shape[0] - 26
+            feet = [list(range(3 * f, 3 * f + 3)) for f in range(4)]
+            legd = [[j for j in range(6, 18) if np.any(Cm[rows][:, j] != 0)] for rows in feet]
+            bl = list(range(6)) + [j for l in legd for j in l]
+            rest = [j for j in range(nv) if j not in bl]
+            G = np.vstack([-np.linalg.solve(Cm[np.ix_(rows, l)], Cm[rows][:, :6]) for rows, l in zip(feet, legd)])
+            # cooperative Cholesky of M = I + G'G: lane r keeps row r, step j finalises row j and the rows below take their column j
+            M = np.eye(6) + G.T @ G
+            L = M.copy()
+            rinv = np.zeros(6)
+            for j in range(6):
+                v = L[j, j] - L[j, :j] @ L[j, :j]
+                rinv[j] = 1.0 / np.sqrt(v)
+                L[j, j] = v * rinv[j]
+                for r in range(j + 1, 6):
+                    L[r, j] = (L[r, j] - L[r, :j] @ L[j, :j]) * rinv[j]
+            L = np.tril(L)
+            S = np.zeros((6, 6))
+            for c in range(6):                     # column c of L^-1 = row c of S
+                x = np.zeros(6)
+                for i in range(c, 6):
+                    x[i] = ((1.0 if i == c else 0.0) - L[i, :i] @ x[:i]) * rinv[i]
+                S[c] = x
+            Zbl = np.vstack([S, G @ S])
+            assert np.abs(Zbl.T @ Zbl - np.eye(6)).max() < 1e-7 and np.abs(Cm[:, bl] @ Zbl).max() < 1e-9 * np.abs(Cm).max()
+            n = 6 + len(rest)
+            assert n <= 15
+            Z = np.zeros((nv, n))
+            Z[np.ix_(bl, range(6))] = Zbl
+            for k, j in enumerate(rest):
+                Z[j, 6 + k] = 1.0
+            dpost = A[mcart + 7, 7]                # the posture block's diagonal
+            H = np.zeros((16, 16))
+            g = np.zeros(16)
+            blocks = [range(30, 33)] + [range(6 * e, 6 * e + 6) for e in range(5)]      # CoM first, then FR, FL, RR, RL, Grip
+            for rows in blocks:
+                AZ = A[list(rows)] @ Z
+                H[:n, :n] += AZ.T @ AZ
+                g[:n] -= AZ.T @ bv[list(rows)]
+            H[:n, :n] += dpost * dpost * np.eye(n)
+            for k in range(n, 16):
+                H[k, k] = 1.0
+            # the sweep: right-looking Cholesky, every "lane" s carries its row of H and the right-hand side e_s; lane 15 carries g'
+            Hs, Y = H.copy(), np.eye(16)
+            Y[15] = g
+            for j in range(16):
+                pj = Hs[j, j]
+                assert pj > 0
+                rj = 1.0 / np.sqrt(pj)
+                col = Hs[:, j].copy()
+                for s in range(16):
+                    th, ty = Hs[s, j] / pj, Y[s, j] / pj
+                    Hs[s, j + 1:] -= th * col[j + 1:]
+                    Y[s, j + 1:] -= ty * col[j + 1:]
+                    Y[s, j] = Y[s, j] * rj
+            z = Y[15]                               # L^-1 g'
+            y = -(Y[:n] @ z)                        # row s of L^-T against it
+            qd = Z @ y
+            assert np.abs(qd - ref["qdot"][b][:nv]).max() < 1e-6, np.abs(qd - ref["qdot"][b][:nv]).max()
