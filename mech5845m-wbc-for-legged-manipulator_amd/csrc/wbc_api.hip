@@ -423,7 +423,11 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
   const bool trunk_is_root = M.frame_joint[WBC_FR_TRUNK] == 1 && M.frame_p[WBC_FR_TRUNK][0] == 0 && M.frame_p[WBC_FR_TRUNK][1] == 0 && M.frame_p[WBC_FR_TRUNK][2] == 0;
   bool ok = c.use_bounds && !(c.task_trunk && !trunk_is_root) && !c.task_com && !c.con_com && !c.con_ee[4] && p_keep == (c.con_trunk ? 4 : 0) &&
             n_red <= 12 && (P->task_ee_mask & ~16u) == 0 && P->legrows == 0 &&
-            (c.task_joint == WBC_JOINT_TIKHONOV || c.task_joint == WBC_JOINT_PREV || (c.task_joint >= WBC_JOINT_MANI && c.task_joint <= WBC_JOINT_HYBRID && P->post_static && !P->post_fk2));
+            true;
+  // the posture modes the packed kernel forms itself; any other (MANI / HYBRID with sweeps that matter, CUSTOM) runs on its QCON variant with
+  // the posture kernel's (or the caller's) posture_u / q_con — without the trunk task
+  const bool own_mode = c.task_joint == WBC_JOINT_TIKHONOV || c.task_joint == WBC_JOINT_PREV ||
+                        (c.task_joint >= WBC_JOINT_MANI && c.task_joint <= WBC_JOINT_HYBRID && P->post_static && !P->post_fk2);
   int need_depth = 0;
   for (int k = 0; k < n_red; ++k) if (M.depth[M.col_joint[P->Fd[k]]] > need_depth) need_depth = M.depth[M.col_joint[P->Fd[k]]];
   for (int l = 0; l < 3 * nelim; ++l) if (M.depth[M.col_joint[P->legd[l]]] > need_depth) need_depth = M.depth[M.col_joint[P->legd[l]]];
@@ -457,8 +461,9 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
       r.dq_idx = c.damper_qidx[d]; r.d_lo = c.damper_lo[d]; r.d_hi = c.damper_hi[d]; r.d_vm = c.damper_vmax[d];
     }
   }
-  P->packed_ok = ok ? 1 : 0;
-  bool upd = ok && !c.task_trunk;   // (the packed state update advances no trunk reference state)
+  P->packed_ok = (ok && own_mode) ? 1 : 0;
+  P->packed_ok_pu = (ok && !c.task_trunk) ? 1 : 0;
+  bool upd = ok && own_mode && !c.task_trunk;   // (the packed state update advances no trunk reference state)
   for (int e = 0; e < 5; ++e) if (M.depth[M.frame_joint[WBC_FR_EE0 + e]] > need_depth) upd = false;
   if (M.depth[M.frame_joint[WBC_FR_TRUNK]] > need_depth) upd = false;
   P->pk_update_ok = upd ? 1 : 0;
@@ -723,9 +728,10 @@ static int launch_update_auto(WbcBatch* b, UpdateArgs& u, int B, void* stream) {
   return packed ? launch_update_packed(u, stream) : launch_update(u, B, stream);
 }
 static bool packed_eligible(const WbcBatch* b, const KernelArgs& a) {
-  bool packed = b->packed_kernel && !a.in.q_con && !a.in.posture_u &&
+  const bool qcon = a.in.q_con || a.in.posture_u;     // the QCON variant (second kinematics pass at q_con, posture target from posture_u)
+  bool packed = b->packed_kernel &&
                 !b->count_pivoted && !(b->dbg_stop > 0 && b->dbg_stop < 100) && !b->dbg_alias;   // (dbg_stop 101.. cuts the packed kernel)
-  for (int i = 0; i < b->n_models && packed; ++i) packed = b->plan_host[i].packed_ok != 0;
+  for (int i = 0; i < b->n_models && packed; ++i) packed = qcon ? (b->plan_host[i].packed_ok_pu != 0) : (b->plan_host[i].packed_ok != 0);
   return packed;
 }
 static bool sim3_eligible(const WbcBatch* b, const KernelArgs& a) {

@@ -38,6 +38,7 @@ struct DevPlan {
   int32_t enabled, nelim, n_red, p_keep;
   int32_t nlock;                     // DoF locked at 0 by the velocity box (>= lock_from, use_bounds): left out of the reduced problem
   int32_t packed_ok;                 // the packed kernel (four instances per wavefront) can run this (model, configuration)
+  int32_t packed_ok_pu;              // ... its QCON variant can, given posture_u (and q_con) from the posture kernel or the caller
   int32_t orth;                      // tasks touch the stance legs: contact elimination through an orthonormal null-space basis (contact_presolve_orth)
   int32_t pk_update_ok;              // the packed FK schedule reaches every frame wbc_update_packed_kernel reads, and no trunk task is on
   // packed kernel (wbc_tick_sim3p_kernel): everything a lane needs, one record per role, so that no load depends on another

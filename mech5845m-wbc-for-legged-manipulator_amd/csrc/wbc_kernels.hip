@@ -3597,7 +3597,10 @@ __device__ __forceinline__ unsigned long long ror16(unsigned long long v) {   //
 // TRUNK: the variant that carries the trunk task (trunkA / calcTargetVelTrunk2, Robot_Wrapper4.py:487-490, 948-1015): six more task rows on
 // the base columns; its inputs and parameters are staged in vectors that are free until the contact stage, so the common variant's
 // register allocation is untouched.
-template <bool WARM, bool TRUNK = false>
+// QCON: the variant for a caller's (or wbc_posture_par_kernel's) posture target `posture_u` and constraint state `q_con` — qpJointb "MANI" / literal
+// "HYBRID" with sweeps that matter (Robot_Wrapper4.py:1220-1260): the tasks are formed at q, then the kinematics are redone at
+// q_con and the contact rows, the trunk box, the damper bounds and the integration see THAT state (a second FK pass, as in process_instance).
+template <bool WARM, bool TRUNK = false, bool QCON = false>
 __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                                const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   // (the general kernel's layout shares the allocation: an instance this kernel cannot reduce — a stance-leg block of rank < 2 — is
@@ -3855,16 +3858,22 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   }
 #pragma unroll
   for (int rr = 0; rr < 6; rr += 2) sts2(At + s * 6 + rr, a[rr], a[rr + 1]);
-  if (s < nl) { Kb[4 * s] = lin1[0]; Kb[4 * s + 1] = lin1[1]; Kb[4 * s + 2] = lin1[2]; }
-  if (s < 6) { Bb[4 * s] = lin0[0]; Bb[4 * s + 1] = lin0[1]; Bb[4 * s + 2] = lin0[2]; }
+  if (!QCON) {   // (QCON: the contact rows belong to the constraint state, see the second pass below)
+    if (s < nl) { Kb[4 * s] = lin1[0]; Kb[4 * s + 1] = lin1[1]; Kb[4 * s + 2] = lin1[2]; }
+    if (s < 6) { Bb[4 * s] = lin0[0]; Bb[4 * s + 1] = lin0[1]; Bb[4 * s + 2] = lin0[2]; }
+  }
   // posture rows (qpJointA / qpJointb, :1199-1268) of reduced variable s and of leg DoF s
   const double dpost = (1.0 / nv) * joint_w;
   double g1 = 0.0;                          // posture term of leg DoF s in g
   {
     const bool prev0 = (c_task_joint == WBC_JOINT_PREV) || (c_task_joint >= WBC_JOINT_MANI && !((P.post_zero >> dof0) & 1u));
     const bool prev1 = (c_task_joint == WBC_JOINT_PREV) || (c_task_joint >= WBC_JOINT_MANI && !((P.post_zero >> dof1) & 1u));
-    const double u0 = (prev0 && s < n) ? qv[dof0 < 6 ? dof0 : dof0 + 1] : 0.0;
-    const double u1 = (prev1 && s < nl) ? qv[dof1 < 6 ? dof1 : dof1 + 1] : 0.0;
+    double u0 = (prev0 && s < n) ? qv[dof0 < 6 ? dof0 : dof0 + 1] : 0.0;
+    double u1 = (prev1 && s < nl) ? qv[dof1 < 6 ? dof1 : dof1 + 1] : 0.0;
+    if (QCON && A.in.posture_u) {           // the posture kernel's (or the caller's) target, by DoF
+      u0 = (s < n) ? A.in.posture_u[(size_t)b * NV + dof0] : 0.0;
+      u1 = (s < nl) ? A.in.posture_u[(size_t)b * NV + dof1] : 0.0;
+    }
     if (s < n) g = fma(-dpost, (1.0 / nv) * u0 * joint_w, g);
     if (s < nl) g1 = -dpost * ((1.0 / nv) * u1 * joint_w);
   }
@@ -3894,6 +3903,85 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     }
   }
   PSTOP(2, h[0] + h[5] + h[11] + g);
+  if (QCON && A.in.q_con) {
+    // ---- the second pass: findConstraints, velDamperJointConstraints and the integration see q_con (the state qpJointb leaves behind); the task
+    // image has been consumed (h, g), so M1 / M2 are free for the kinematics again. Same code as the first pass.
+    WSYNC();
+    {
+      const double* qg = A.in.q_con + (size_t)b * NQ;
+      const double c0 = qg[s], c1 = (16 + s < NQ) ? qg[16 + s] : 0.0;
+      V.in[s] = c0;
+      if (16 + s < 28) V.in[16 + s] = c1;
+    }
+    fkn = P.pk_fk[0][s];
+    WSYNC();
+  {
+    if (scq0 >= 0) { const SinCos t = sincos_cw(qv[scq0]); sc[2 * (2 + s)] = t.s; sc[2 * (2 + s) + 1] = t.c; }
+    if (scq1 >= 0) { const SinCos t = sincos_cw(qv[scq1]); sc[2 * (18 + s)] = t.s; sc[2 * (18 + s) + 1] = t.c; }
+    // root free-flyer (joint 1): R from the quaternion exactly as Eigen's toRotationMatrix, p = xyz; R column-major then p
+    if (s == 0) {
+      double Rt[9];
+      quat_to_R(qv + 3, Rt);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) oMi[12 + 3 * c + rr] = Rt[3 * rr + c];
+      oMi[12 + 9] = qv[0]; oMi[12 + 10] = qv[1]; oMi[12 + 11] = qv[2];
+    }
+  }
+    WSYNC();
+#pragma unroll 1
+  for (int L = 0; L < 5; ++L) {   // (second pass)
+    const DevPlan::PkJoint fk = fkn;
+    if (L + 1 < 5) fkn = P.pk_fk[L + 1][s];          // next level's record is on its way while this level is computed
+    const int j = fk.joint;
+    if (j >= 0) {
+      const bool rev = fk.rev != 0;
+      const int a0 = fk.a0, a1 = fk.a1, a2 = fk.a2;
+      const double* Pp = oMi + 12 * fk.parent;
+      const double sn = rev ? sc[2 * j] : 0.0, cs = rev ? sc[2 * j + 1] : 1.0;
+      const double pris = rev ? 0.0 : qv[fk.q_idx];
+      double Av[3], Bv[3], Cv[3], Pv[3];
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) { Av[rr] = Pp[a0 + rr]; Bv[rr] = Pp[a1 + rr]; Cv[rr] = Pp[a2 + rr]; Pv[rr] = Pp[9 + rr]; }
+      double* Po = oMi + 12 * j;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        Po[a0 + rr] = Av[rr];
+        Po[a1 + rr] = cs * Bv[rr] + sn * Cv[rr];
+        Po[a2 + rr] = cs * Cv[rr] - sn * Bv[rr];
+        Po[9 + rr] = Pv[rr] + Av[rr] * (fk.t0 + pris) + Bv[rr] * fk.t1 + Cv[rr] * fk.t2;
+      }
+    }
+    WSYNC();
+  }
+    lin0[0] = lin0[1] = lin0[2] = 0.0; ang0[0] = ang0[1] = ang0[2] = 0.0; lin1[0] = lin1[1] = lin1[2] = 0.0;
+    if (s < n) {
+      const double* Pj = oMi + 12 * c0_joint;
+      const double pj[3] = {Pj[9], Pj[10], Pj[11]};
+      if (c0_ang >= 0) { ang0[0] = Pj[3 * c0_ang]; ang0[1] = Pj[3 * c0_ang + 1]; ang0[2] = Pj[3 * c0_ang + 2]; cross3(pj, ang0, lin0); }
+      if (c0_lin >= 0) { lin0[0] = Pj[3 * c0_lin]; lin0[1] = Pj[3 * c0_lin + 1]; lin0[2] = Pj[3 * c0_lin + 2]; }
+    }
+    if (s < nl) {
+      const double* Pj = oMi + 12 * c1_joint;
+      const double pj[3] = {Pj[9], Pj[10], Pj[11]};
+      if (c1_ang >= 0) { const double a1[3] = {Pj[3 * c1_ang], Pj[3 * c1_ang + 1], Pj[3 * c1_ang + 2]}; cross3(pj, a1, lin1); }
+      if (c1_lin >= 0) { lin1[0] = Pj[3 * c1_lin]; lin1[1] = Pj[3 * c1_lin + 1]; lin1[2] = Pj[3 * c1_lin + 2]; }
+    }
+    {
+      const double* Pr = oMi + 12 * M.frame_joint[WBC_FR_TRUNK];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) Rtr[3 * rr + c] = Pr[3 * c + rr];
+      ptr[0] = Pr[9]; ptr[1] = Pr[10]; ptr[2] = Pr[11];
+    }
+    WSYNC();   // oMi is dead again
+  }
+  if (QCON) {
+    if (s < nl) { Kb[4 * s] = lin1[0]; Kb[4 * s + 1] = lin1[1]; Kb[4 * s + 2] = lin1[2]; }
+    if (s < 6) { Bb[4 * s] = lin0[0]; Bb[4 * s + 1] = lin0[1]; Bb[4 * s + 2] = lin0[2]; }
+  }
 
   // ---- constraint rows that stay: trunk box (trunkConstraint, :707-754) on the base columns; bounds on the row's own lane
   double clb = 0.0, cub = 0.0;
@@ -4635,6 +4723,8 @@ template __global__ void wbc_tick_sim3p_kernel<false, false>(const KernelArgs, c
 template __global__ void wbc_tick_sim3p_kernel<true, false>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
 template __global__ void wbc_tick_sim3p_kernel<false, true>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
 template __global__ void wbc_tick_sim3p_kernel<true, true>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
+template __global__ void wbc_tick_sim3p_kernel<false, false, true>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
+template __global__ void wbc_tick_sim3p_kernel<true, false, true>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
 
 // ------------------------------------------------------------------------------------------------
 // wbc_update_kernel for four instances per wavefront (same lane layout and FK records as the packed tick kernel): the one-instance
@@ -5364,9 +5454,11 @@ int launch_tick_deferred(const KernelArgs& a, void* stream) {
   return check_launch("tick_deferred");
 }
 int launch_tick_sim3p(const KernelArgs& a, void* stream) {
-  const bool warm = a.ws_in || a.ws_out, trunk = a.in.trunk_target && a.packed_trunk;
+  const bool warm = a.ws_in || a.ws_out, trunk = a.in.trunk_target && a.packed_trunk, qcon = a.in.q_con || a.in.posture_u;
   const dim3 grid((a.B + 3) / 4);
-  if (warm && trunk) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<true, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  if (qcon && warm) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<true, false, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  else if (qcon) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<false, false, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  else if (warm && trunk) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<true, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   else if (trunk) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<false, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   else if (warm) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<true, false>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   else hipLaunchKernelGGL((wbc_tick_sim3p_kernel<false, false>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);

@@ -195,11 +195,20 @@ def test_tick_parity_posture_modes(wx200, cfg_name, B):
     bt = WbcBatch(wx200, B)
     bt.configure(cfg)
     got = bt.tick(d, DT, want_q_next=True)
+    # HYBRID as sim3.py sets it: the packed kernel forms the (static) target itself; MANI: wbc_posture_par_kernel + the packed kernel's QCON variant
+    # (tasks at q, constraints / bounds / integration at the perturbed state); Grip contact + CoM box: the general kernel
+    assert bt.stat("last_path") == (0 if cfg_name == "hybrid_grip_com" else 2)
     assert (got["status"] == ref["status"]).all()
     ok = ref["status"] == 0
     assert ok.mean() > 0.9
     err = np.abs(got["qdot"] - ref["qdot"])[ok].max()
     print("%s: qdot max-abs err %.3e" % (cfg_name, err))
+    if cfg_name == "c3_mani":                       # ... and the one-instance compact kernel agrees
+        bt.set_option("packed_kernel", 0)
+        one = bt.tick(d, DT, want_q_next=True)
+        assert bt.stat("last_path") == 1 and (one["status"] == ref["status"]).all()
+        assert np.abs(one["qdot"] - got["qdot"])[ok].max() < 1e-6 and np.abs(one["q_next"] - got["q_next"])[ok].max() < 1e-9
+        bt.set_option("packed_kernel", 1)
     assert err < QDOT_TOL
     assert np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
     a, ar = bt.assemble(d, DT), oracle.assemble([wx200], [cfg], d, DT, B)
