@@ -315,7 +315,8 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          references run on the compact wbc_tick_sim3_kernel (+ a second pass of the general kernel over the
  *                          instances whose leg blocks it could not eliminate); 0: the general kernel does the elimination.
  *   "packed_kernel"    [1] batches of the sim3 switch-set family itself (Grip task or none, optionally the trunk task, trunk box + foot
- *                          contacts, velocity bounds, posture PREV / Tikhonov / static HYBRID; the gripper's orientation reference is
+ *                          contacts, velocity bounds, posture PREV / Tikhonov / static HYBRID — or any mode with posture_u / q_con
+ *                          supplied by the posture kernel or the caller: the QCON variant; the gripper's orientation reference is
  *                          honoured; working sets in and out are taken: the WARM variant) run FOUR instances per wavefront
  *                          (wbc_tick_sim3p_kernel: ONE kernel per tick — an instance it cannot reduce, a stance-leg block of rank < 2, is
  *                          redone by its own wave on the general path at the end of the same kernel); 0: one instance per wavefront
