@@ -463,7 +463,7 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
   }
   P->packed_ok = (ok && own_mode) ? 1 : 0;
   P->packed_ok_pu = (ok && !c.task_trunk) ? 1 : 0;
-  bool upd = ok && own_mode && !c.task_trunk;   // (the packed state update advances no trunk reference state)
+  bool upd = ok;   // (any posture mode: the state update does not depend on it; the trunk reference state is advanced too since round 3)   // (the packed state update advances no trunk reference state)
   for (int e = 0; e < 5; ++e) if (M.depth[M.frame_joint[WBC_FR_EE0 + e]] > need_depth) upd = false;
   if (M.depth[M.frame_joint[WBC_FR_TRUNK]] > need_depth) upd = false;
   P->pk_update_ok = upd ? 1 : 0;

@@ -4771,6 +4771,7 @@ __global__ void __launch_bounds__(64) wbc_update_packed_kernel(const UpdateArgs 
   }
   const double tt = (A.trunk_target && s < 3) ? A.trunk_target[b * 3 + s] : 0.0;
   const double tts = (A.trunk_target && A.trunk_step && s < 3) ? A.trunk_step[b * 3 + s] : 0.0;
+  const double ter = (A.trunk_prev_rot && A.trunk_ref_euler && s < 3) ? A.trunk_ref_euler[b * 3 + s] : 0.0;
   int st = 0, stm = 0, it = 0, its = 0;
   if (s == 0) {
     if (A.status_max) { st = A.status[b]; stm = A.status_max[b]; }
@@ -4874,7 +4875,21 @@ __global__ void __launch_bounds__(64) wbc_update_packed_kernel(const UpdateArgs 
     if (cfg.task_trunk && A.prev_trunk_target) A.prev_trunk_target[b * 3 + s] = tt;   // prev_trunk_ref = target (:995)
     if (A.trunk_step) A.trunk_target[b * 3 + s] = tt + tts;
   }
-  // (old_ref_trunk_rot_matrix, :996, only moves with the trunk task on — which pk_update_ok excludes)
+  if (A.trunk_prev_rot && A.trunk_ref_euler && __ballot(cfg.task_trunk != 0)) {      // old_ref_trunk_rot_matrix = R* (:996), with the trunk task on
+    const SinCos t = sincos_cw(ter);          // lanes 0..2 of the row: roll, pitch, yaw of the reference
+    const int rb = lane & 48;
+    const double sa = bperm(t.s, rb), ca = bperm(t.c, rb), sb = bperm(t.s, rb + 1), cb = bperm(t.c, rb + 1), sc_ = bperm(t.s, rb + 2), cc = bperm(t.c, rb + 2);
+    double Rs[9];
+    Rs[0] = cc * cb; Rs[1] = cc * sb * sa - sc_ * ca; Rs[2] = cc * sb * ca + sc_ * sa;
+    Rs[3] = sc_ * cb; Rs[4] = sc_ * sb * sa + cc * ca; Rs[5] = sc_ * sb * ca - cc * sa;
+    Rs[6] = -sb;      Rs[7] = cb * sa;                 Rs[8] = cb * ca;
+    if (valid && cfg.task_trunk && s < 9) {
+      double v = Rs[0];
+#pragma unroll
+      for (int i = 1; i < 9; ++i) v = (s == i) ? Rs[i] : v;
+      A.trunk_prev_rot[b * 9 + s] = v;
+    }
+  }
 }
 
 // ================================================================================================

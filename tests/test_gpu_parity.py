@@ -709,13 +709,14 @@ def test_update_state_parity(wx200, px100, B):
     bt.close()
 
 
-@pytest.mark.parametrize("cfg_name,K,with_imu", [("c3", 12, True), ("c3", 5, False), ("c3_hybrid", 6, True), ("everything", 6, True)])
+@pytest.mark.parametrize("cfg_name,K,with_imu", [("c3", 12, True), ("c3", 5, False), ("c3_hybrid", 6, True), ("everything", 6, True), ("c3_trunk_task", 8, True),
+                                                  ("c3_mani", 4, True)])
 def test_rollout_parity(wx200, cfg_name, K, with_imu):
     """K closed-loop ticks on the device against the oracle's tick / update_state / state-advance loop:
     state, targets, worst status, iteration total and the gripper trace."""
     B = 192
     cfg = common.config(cfg_name, wx200)
-    d = common.tick_inputs(wx200, cfg, B, seed=37, with_rot=(cfg_name == "everything"))
+    d = common.tick_inputs(wx200, cfg, B, seed=37, with_rot=(cfg_name in ("everything", "c3_trunk_task")))
     rng = np.random.default_rng(2)
     step = np.zeros((B, 5, 3))
     step[:, 4] = rng.normal(0, 1e-4, (B, 3))
@@ -731,8 +732,9 @@ def test_rollout_parity(wx200, cfg_name, K, with_imu):
     for warm in (1, 0):      # 1: every tick seeded with the previous tick's working set (f2; off by default); 0: cold, like the oracle's ticks
         bt.set_option("warm_start", warm)
         got = res[warm] = bt.rollout(d, DT, K, ee_target_step=step, trunk_target_step=tstep, imu=imu)
-        if cfg_name in ("c3", "c3_hybrid"):
-            assert bt.stat("last_path") == 2, warm                  # warm or cold, the roll-out stays on the packed kernel
+        if cfg_name in ("c3", "c3_hybrid", "c3_trunk_task", "c3_mani"):
+            assert bt.stat("last_path") == 2, warm                  # warm or cold, the roll-out stays on the packed kernel (TRUNK / QCON variants included)
+            assert bt.stat("last_update_packed") == 1               # ... and so does its state update (trunk reference state included)
         assert all((d[k] == before[k]).all() for k in d)            # in0 is only read
         assert (got["status"] == ref["status"]).all(), warm
         # one tick agrees to ~1e-6 in qdot (cond(H) ~ 3e9); K ticks of dt = 2 ms integrate that into ~1e-8 of state
