@@ -3202,9 +3202,9 @@ __global__ void __launch_bounds__(64) wbc_posture_kernel(const PostureArgs A, co
 // wavefront, lane e = 2 k + side evaluates f = sqrt(det(J J')) of sweep k's joint at q + d e_i (side 0) or (q + d e_i) - 2 d e_i (side 1).
 // The reference's loop is sequential only in appearance: in literal mode the perturbations accumulate, but the state sweep k
 // sees is known up front — q0 with the entries of the earlier sweeps at (q + d) - 2 d (DevPlan.mp_prev) — so all 2 x mp_n (<= 52) points
-// are independent. A lane walks the ancestor chain of its joint twice in registers (no cross-lane traffic): pass 1 the joint's origin,
-// pass 2 the LOCAL_WORLD_ALIGNED Jacobian columns (six of the free-flyer + one per chain joint) accumulated straight into G = J J'
-// (21 entries), then det by the elimination of wbc_posture_kernel. sin / cos of every joint angle in its three possible states (q, q + d,
+// are independent. A lane walks the ancestor chain of its joint once in registers (no cross-lane traffic), forms the WORLD-frame Jacobian
+// columns on the way (six of the free-flyer + one per chain joint; det(J J') is the same in every frame the columns may be expressed in)
+// and accumulates them straight into G = J J' (21 entries), then det by the elimination of wbc_posture_kernel. sin / cos of every joint angle in its three possible states (q, q + d,
 // (q + d) - 2 d) are computed once, one per lane, and shared through LDS. Sweeps that cannot change f (DevPlan: not in the list) are u = 0.
 // wbc_posture_kernel (52 sequential whole-tree sweeps per instance) stays as the fallback and as the cross-check in the tests.
 // ------------------------------------------------------------------------------------------------
@@ -3263,8 +3263,6 @@ __global__ void __launch_bounds__(64) wbc_posture_par_kernel(const PostureArgs A
     const double qq[4] = {value_of(3), value_of(4), value_of(5), value_of(6)};
     double R1[9];
     quat_to_R(qq, R1);                                  // row-major
-    const double p1[3] = {value_of(0), value_of(1), value_of(2)};
-    double pJ[3] = {p1[0], p1[1], p1[2]};
     double G[21];
 #pragma unroll
     for (int i = 0; i < 21; ++i) G[i] = 0.0;
@@ -3275,22 +3273,22 @@ __global__ void __launch_bounds__(64) wbc_posture_par_kernel(const PostureArgs A
 #pragma unroll
         for (int bb = a; bb < 6; ++bb) { G[t] = fma(c[a], c[bb], G[t]); ++t; }
     };
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
+    // ONE walk down the chain with the columns expressed at the BASE origin ((p - p_base) x axis, axis): the reference's LOCAL_WORLD_ALIGNED
+    // Jacobian at the joint's origin pJ is X J_base with X = [I, -[pJ - p_base]x; 0, I], det X = 1, so det(J J') — all that f is — does not
+    // depend on where the columns are expressed, and the joint's origin need not be known before the columns are formed (the first version
+    // walked the chain twice for it). Origins relative to the base: the base position drops out of the arithmetic altogether, so its three
+    // sweeps give f1 == f2 bit for bit and u = 0 exactly, as the reference's (and the sequential kernel's) LOCAL_WORLD_ALIGNED form does.
+    {
       double X[3] = {R1[0], R1[3], R1[6]}, Y[3] = {R1[1], R1[4], R1[7]}, Z[3] = {R1[2], R1[5], R1[8]};   // columns of the parent's rotation
-      double p[3] = {p1[0], p1[1], p1[2]};
-      if (pass == 1) {   // free-flyer columns (LOCAL_WORLD_ALIGNED at the joint's origin): linear DoF (R e_i, 0), angular DoF (R e_i x (pJ - p1), R e_i)
-        const double dd[3] = {pJ[0] - p1[0], pJ[1] - p1[1], pJ[2] - p1[2]};
+      double p[3] = {0.0, 0.0, 0.0};                    // origins relative to the base
+      // free-flyer columns at its own origin: linear DoF (R e_i, 0), angular DoF (0, R e_i)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const double* ax = (i == 0) ? X : ((i == 1) ? Y : Z);
-          const double cl[6] = {ax[0], ax[1], ax[2], 0.0, 0.0, 0.0};
-          add_col(cl);
-          double cr[3];
-          cross3(ax, dd, cr);
-          const double ca[6] = {cr[0], cr[1], cr[2], ax[0], ax[1], ax[2]};
-          add_col(ca);
-        }
+      for (int i = 0; i < 3; ++i) {
+        const double* ax = (i == 0) ? X : ((i == 1) ? Y : Z);
+        const double cl[6] = {ax[0], ax[1], ax[2], 0.0, 0.0, 0.0};
+        add_col(cl);
+        const double ca[6] = {0.0, 0.0, 0.0, ax[0], ax[1], ax[2]};
+        add_col(ca);
       }
 #pragma unroll 1
       for (int c = 0; c < 8; ++c) {
@@ -3324,18 +3322,14 @@ __global__ void __launch_bounds__(64) wbc_posture_par_kernel(const PostureArgs A
           Y[rr] = (a == 0) ? nb : ((a == 1) ? na : nc);
           Z[rr] = (a == 0) ? nc : ((a == 1) ? nb : na);
         }
-        if (pass == 1) {   // this joint's column: revolute (axis x (pJ - p), axis), prismatic (axis, 0)
-          double col[6];
-          if (rev) {
-            const double dd[3] = {pJ[0] - p[0], pJ[1] - p[1], pJ[2] - p[2]};
-            double cr[3];
-            cross3(Av, dd, cr);
-            col[0] = cr[0]; col[1] = cr[1]; col[2] = cr[2]; col[3] = Av[0]; col[4] = Av[1]; col[5] = Av[2];
-          } else { col[0] = Av[0]; col[1] = Av[1]; col[2] = Av[2]; col[3] = 0.0; col[4] = 0.0; col[5] = 0.0; }
-          add_col(col);
-        }
+        double col[6];                                  // this joint's column: revolute (p x axis, axis), prismatic (axis, 0)
+        if (rev) {
+          double cr[3];
+          cross3(p, Av, cr);
+          col[0] = cr[0]; col[1] = cr[1]; col[2] = cr[2]; col[3] = Av[0]; col[4] = Av[1]; col[5] = Av[2];
+        } else { col[0] = Av[0]; col[1] = Av[1]; col[2] = Av[2]; col[3] = 0.0; col[4] = 0.0; col[5] = 0.0; }
+        add_col(col);
       }
-      if (pass == 0) { pJ[0] = p[0]; pJ[1] = p[1]; pJ[2] = p[2]; }
     }
     // det of the symmetric positive semi-definite G by elimination without pivoting (det6_spd, on the packed upper triangle)
     double m[6][6];
