@@ -4909,6 +4909,7 @@ struct __attribute__((aligned(16))) QInst {
   double W[136];            // sin / cos [22][2] @0, m c [22][4] @44 -> Z [18][6] @0
   double in[64];            // q [27] @0, ee_target [15] @28, prev_ee_target [15] @43, com_target [3] @58, com_target_vel [3] @61
   double pf[16];            // EE frame origins [5][3]
+  double ow[16];            // the EE tasks' reference angular velocities [5][3] (zero without orientation references)
   double cl[32], yv[32];    // the configuration's task weights and gains (wt [96], staged at the top: no global load inside the task loop) ->
   double zv[16], xv[16];    //   Cholesky column pair (entries 16..31 zero); g' -> L^-1 g';  y -> base twist * dt
   double gp[32];            // posture part of g by DoF -> qdot by DoF
@@ -4950,6 +4951,19 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     if (16 + s < 28) I.in[16 + s] = q1;
     if (s < 15) { I.in[28 + s] = et; I.in[43 + s] = ep; }
     if (s < 6) I.in[58 + s] = cm;
+    // calcTargetVelEE3's orientation feed-forward (Robot_Wrapper4.py:1125-1133): omega = vee(((R* - R*_prev) / dt) R*^T), one component per lane
+    // (EE s / 3, component s % 3), straight from the caller's [B][5][9] references; zero when none are passed
+    {
+      double om = 0.0;
+      if (A.in.ee_ref_rot && s < 15) {
+        const int e = s / 3, i = s - 3 * e;
+        const double* Rs = A.in.ee_ref_rot + (size_t)b * 45 + 9 * e;
+        const double* Rp = A.in.ee_prev_rot + (size_t)b * 45 + 9 * e;
+        const int ra = (i == 0) ? 6 : ((i == 1) ? 0 : 3), rb = (i == 0) ? 3 : ((i == 1) ? 6 : 0);   // S[2][1] = D row 2 . R row 1; S[0][2]; S[1][0]
+        om = ((Rs[ra] - Rp[ra]) * inv_dt) * Rs[rb] + ((Rs[ra + 1] - Rp[ra + 1]) * inv_dt) * Rs[rb + 1] + ((Rs[ra + 2] - Rp[ra + 2]) * inv_dt) * Rs[rb + 2];
+      }
+      I.ow[s] = om;
+    }
     // the configuration's weights and gains: 85 contiguous doubles of WbcConfig, six per lane, parked in wt (= cl | yv | zv | xv)
     const double* cw = &cfg.ee_W[0][0];
 #pragma unroll
@@ -5285,7 +5299,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     const double* xt = I.in + 28 + 3 * e;
     const double* xp = I.in + 43 + 3 * e;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) br[i] = ((xt[i] - xp[i]) * inv_dt + Gd[i] * ((xt[i] - pfe[i]) * inv_dt)) * w;
+    for (int i = 0; i < 3; ++i) { br[i] = ((xt[i] - xp[i]) * inv_dt + Gd[i] * ((xt[i] - pfe[i]) * inv_dt)) * w; br[3 + i] = I.ow[3 * e + i] * w; }
     int ef = efoot[0];
 #pragma unroll
     for (int i = 1; i < 5; ++i) ef = (e == i) ? efoot[i] : ef;

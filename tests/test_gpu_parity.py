@@ -903,7 +903,8 @@ def test_packed_orth_kernel_variants_and_non_finite_inputs(wx200, px100, posture
     cfgs = [wbc_model.make_config(m, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=(True if posture == "TIKHONOV" else "PREV"), task_com=True,
                                   cFR=True, cFL=True, cRR=True, cRL=True, use_bounds=False) for m in models]
     mid = (np.arange(B) % 2).astype(np.int32)
-    parts = [common.tick_inputs(m, c, B, seed=31 + i) for i, (m, c) in enumerate(zip(models, cfgs))]
+    # (PREV: also with MOVING orientation references for the five EE tasks — calcTargetVelEE3's omega feed-forward, RW4:1125-1133)
+    parts = [common.tick_inputs(m, c, B, seed=31 + i, with_rot=(posture == "PREV")) for i, (m, c) in enumerate(zip(models, cfgs))]
     d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
     d["model_id"] = mid
     d["q"] = d["q"].copy()
