@@ -291,6 +291,29 @@ static void build_posture_plan(const DevModel& M, const WbcConfig& c, DevPlan* P
   P->post_fk2 = dep ? 1 : 0;
 }
 
+// The packed FK schedule shared by wbc_tick_sim3p_kernel and wbc_update_packed_kernel: the joints of tree depth 2 + L (L < 5) up to need_depth,
+// one per lane-in-instance, and the q index of every revolute joint it reaches. Returns false if a level holds more than 16 joints.
+static bool build_pk_fk(const DevModel& M, int need_depth, DevPlan* P) {
+  for (int i = 0; i < 32; ++i) P->pk_scq[i] = -1;
+  for (int L = 0; L < 5; ++L) {
+    int cnt = 0;
+    for (int i = 0; i < 16; ++i) { memset(&P->pk_fk[L][i], 0, sizeof P->pk_fk[L][i]); P->pk_fk[L][i].joint = -1; }
+    for (int j = 2; j < M.njoints; ++j)
+      if (M.depth[j] == L + 2 && M.depth[j] <= need_depth) {
+        if (cnt < 16) {
+          DevPlan::PkJoint& r = P->pk_fk[L][cnt];
+          const bool rev = M.jtype[j] >= WBC_JT_RX && M.jtype[j] <= WBC_JT_RZ;
+          r.joint = j; r.parent = M.parent[j]; r.a0 = 3 * M.ax0[j]; r.a1 = 3 * M.ax1[j]; r.a2 = 3 * M.ax2[j];
+          r.rev = rev ? 1 : 0; r.q_idx = M.idx_q[j]; r.t0 = M.tp[j][0]; r.t1 = M.tp[j][1]; r.t2 = M.tp[j][2];
+          if (rev && j < 32) P->pk_scq[j] = M.idx_q[j];
+        }
+        ++cnt;
+      }
+    if (cnt > 16) return false;
+  }
+  return true;
+}
+
 // The packed orth kernel's plan (wbc_tick_orthp_kernel): equality-only task problems — the only constraints are the eliminated stance
 // feet's contact rows (no trunk / CoM box, no velocity box), tasks = any EE tasks + optionally the CoM task + posture Tikhonov / PREV.
 static void build_orthp_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) {
@@ -361,6 +384,10 @@ static void build_orthp_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) 
     }
   }
   P->q_ok = 1;
+  // roll-outs of these configurations update their state on wbc_update_packed_kernel too: its FK schedule down to the deepest frame the estimator reads
+  int need = M.depth[M.frame_joint[WBC_FR_TRUNK]];
+  for (int e = 0; e < 5; ++e) if (M.depth[M.frame_joint[WBC_FR_EE0 + e]] > need) need = M.depth[M.frame_joint[WBC_FR_EE0 + e]];
+  P->pk_update_ok = (need <= 6 && build_pk_fk(M, need, P)) ? 1 : 0;
 }
 
 static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan* P) {
@@ -434,22 +461,7 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
   if (M.depth[M.frame_joint[WBC_FR_EE0 + 4]] > need_depth) need_depth = M.depth[M.frame_joint[WBC_FR_EE0 + 4]];
   if (need_depth > 6) ok = false;
   for (int i = 0; i < 32; ++i) P->pk_scq[i] = -1;
-  for (int L = 0; L < 5 && ok; ++L) {
-    int cnt = 0;
-    for (int i = 0; i < 16; ++i) { memset(&P->pk_fk[L][i], 0, sizeof P->pk_fk[L][i]); P->pk_fk[L][i].joint = -1; }
-    for (int j = 2; j < M.njoints; ++j)
-      if (M.depth[j] == L + 2 && M.depth[j] <= need_depth) {
-        if (cnt < 16) {
-          DevPlan::PkJoint& r = P->pk_fk[L][cnt];
-          const bool rev = M.jtype[j] >= WBC_JT_RX && M.jtype[j] <= WBC_JT_RZ;
-          r.joint = j; r.parent = M.parent[j]; r.a0 = 3 * M.ax0[j]; r.a1 = 3 * M.ax1[j]; r.a2 = 3 * M.ax2[j];
-          r.rev = rev ? 1 : 0; r.q_idx = M.idx_q[j]; r.t0 = M.tp[j][0]; r.t1 = M.tp[j][1]; r.t2 = M.tp[j][2];
-          if (rev && j < 32) P->pk_scq[j] = M.idx_q[j];
-        }
-        ++cnt;
-      }
-    if (cnt > 16) ok = false;
-  }
+  if (ok && !build_pk_fk(M, need_depth, P)) ok = false;
   for (int i = 0; i < 16; ++i) {
     memset(&P->pk_var[i], 0, sizeof P->pk_var[i]);
     memset(&P->pk_leg[i], 0, sizeof P->pk_leg[i]);
@@ -463,7 +475,7 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
   }
   P->packed_ok = (ok && own_mode) ? 1 : 0;
   P->packed_ok_pu = (ok && !c.task_trunk) ? 1 : 0;
-  bool upd = ok;   // (any posture mode: the state update does not depend on it; the trunk reference state is advanced too since round 3)   // (the packed state update advances no trunk reference state)
+  bool upd = ok;   // (any posture mode: the state update does not depend on it; the trunk reference state is advanced too since round 3)
   for (int e = 0; e < 5; ++e) if (M.depth[M.frame_joint[WBC_FR_EE0 + e]] > need_depth) upd = false;
   if (M.depth[M.frame_joint[WBC_FR_TRUNK]] > need_depth) upd = false;
   P->pk_update_ok = upd ? 1 : 0;

@@ -710,7 +710,7 @@ def test_update_state_parity(wx200, px100, B):
 
 
 @pytest.mark.parametrize("cfg_name,K,with_imu", [("c3", 12, True), ("c3", 5, False), ("c3_hybrid", 6, True), ("everything", 6, True), ("c3_trunk_task", 8, True),
-                                                  ("c3_mani", 4, True)])
+                                                  ("c3_mani", 4, True), ("c2", 5, True)])
 def test_rollout_parity(wx200, cfg_name, K, with_imu):
     """K closed-loop ticks on the device against the oracle's tick / update_state / state-advance loop:
     state, targets, worst status, iteration total and the gripper trace."""
@@ -735,6 +735,8 @@ def test_rollout_parity(wx200, cfg_name, K, with_imu):
         if cfg_name in ("c3", "c3_hybrid", "c3_trunk_task", "c3_mani"):
             assert bt.stat("last_path") == 2, warm                  # warm or cold, the roll-out stays on the packed kernel (TRUNK / QCON variants included)
             assert bt.stat("last_update_packed") == 1               # ... and so does its state update (trunk reference state included)
+        if cfg_name == "c2":
+            assert bt.stat("last_update_packed") == 1               # (configs[1]: the state update is packed whatever kernel the tick ran on)
         assert all((d[k] == before[k]).all() for k in d)            # in0 is only read
         assert (got["status"] == ref["status"]).all(), warm
         # one tick agrees to ~1e-6 in qdot (cond(H) ~ 3e9); K ticks of dt = 2 ms integrate that into ~1e-8 of state
