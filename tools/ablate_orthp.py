@@ -17,6 +17,7 @@ model = wbc_model.load_model("a1_wx200")
 cfg = wbc_model.equality_only_config(model)
 bt = WbcBatch(model, B)
 bt.configure(cfg)
+bt.set_option("packed_orth", 2)      # (also below the batch-size policy's threshold: B = 1024 shows one wave's latency, stage by stage)
 
 class FK:
     def __call__(_, q):
