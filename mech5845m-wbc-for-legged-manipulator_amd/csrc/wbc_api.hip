@@ -49,6 +49,7 @@ struct WbcBatch {
   int count_pivoted, force_defer;   // diagnostics of the sim3 kernel's pivoted elimination / second pass
   int packed_kernel;     // 1 (default): eligible batches run four instances per wavefront (wbc_tick_sim3p_kernel)
   int posture_par, last_posture_par;   // option [1]: MANI / HYBRID posture targets on wbc_posture_par_kernel (every finite-difference point on its own lane); what the last one ran on
+  int packed_box;        // 1 (default): task problems without constraint rows (the warm-up problem) run four instances per wavefront (wbc_tick_boxp_kernel)
   int packed_orth;       // 1 (default): equality-only task problems run four instances per wavefront (wbc_tick_orthp_kernel)
   int warm_start;        // 1: wbc_rollout carries each instance's working set from tick to tick (default 0: measured slower)
   int32_t* d_defer;      // [1 + max_batch]: count + compact list of the instances the sim3 kernel deferred (lazy)
@@ -56,7 +57,7 @@ struct WbcBatch {
   uint32_t tick_seq;
   int packed_update, last_update_packed;   // option: wbc_update_packed_kernel where every plan allows it [1]; what the last update ran on
   int last_orth;         // the last general-kernel tick ran the variant with the orthonormal contact presolve
-  int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass), 2 packed sim3, 3 packed orth
+  int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass), 2 packed sim3, 3 packed orth, 4 packed box
   int max_nj, max_nf;    // FK output strides: the largest model's joint / frame counts
   unsigned long long* d_prof;
   double *d_pu, *d_pq;   // qpJointb MANI/HYBRID results: u [max_batch][26], q_after [max_batch][27] (lazy)
@@ -152,7 +153,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
   b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->presolve_orth = 1; b->packed_update = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
-  b->jtj_mfma = -1; b->warm_start = 0; b->packed_kernel = 1; b->packed_orth = 1; b->posture_par = 1;
+  b->jtj_mfma = -1; b->warm_start = 0; b->packed_kernel = 1; b->packed_orth = 1; b->packed_box = 1; b->posture_par = 1;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
@@ -314,25 +315,18 @@ static bool build_pk_fk(const DevModel& M, int need_depth, DevPlan* P) {
   return true;
 }
 
-// The packed orth kernel's plan (wbc_tick_orthp_kernel): equality-only task problems — the only constraints are the eliminated stance
-// feet's contact rows (no trunk / CoM box, no velocity box), tasks = any EE tasks + optionally the CoM task + posture Tikhonov / PREV.
-static void build_orthp_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) {
-  P->q_ok = 0;
-  const int nelim = P->nelim, nl = 3 * nelim;
-  if (!P->orth || c.use_bounds || c.con_trunk || c.con_com || c.task_trunk || P->p_keep != 0 || nelim < 1 || nelim > 4) return;
-  if (c.task_joint != WBC_JOINT_TIKHONOV && c.task_joint != WBC_JOINT_PREV) return;
-  if (M.njoints > 22 || M.maxdepth > 7 || P->n_red > 15) return;
+// Tables the packed orth and the packed box kernels share: the FK schedule over EVERY joint (tree depth 2 + L, L < 6, one joint per
+// lane-in-instance), the revolute joints' q indices, body masses / centres, and per DoF its Jacobian column, the EE frames it moves and
+// (need_subtree: the CoM Jacobian) the contiguous joint range of its subtree. Returns false if the model does not fit the layout.
+static bool build_q_tables(const DevModel& M, DevPlan* P, bool need_subtree) {
+  if (M.njoints > 22 || M.maxdepth > 7) return false;
   for (int i = 0; i < 32; ++i) { P->q_scq[i] = -1; memset(&P->q_dof[i], 0, sizeof P->q_dof[i]); P->q_dof[i].bl = P->q_dof[i].red = -1; memset(&P->q_jm[i], 0, sizeof P->q_jm[i]); }
-  for (int i = 0; i < 18; ++i) P->q_bl2dof[i] = 0;
-  for (int i = 0; i < 16; ++i) P->q_red2dof[i] = 0;
-  for (int e = 0; e < 8; ++e) P->q_efoot[e] = -1;
-  // FK schedule: every joint of depth 2 .. 7
   for (int L = 0; L < 6; ++L) {
     int cnt = 0;
     for (int i = 0; i < 16; ++i) { memset(&P->q_fk[L][i], 0, sizeof P->q_fk[L][i]); P->q_fk[L][i].joint = -1; }
     for (int j = 2; j < M.njoints; ++j)
       if (M.depth[j] == L + 2) {
-        if (cnt >= 16) return;
+        if (cnt >= 16) return false;
         DevPlan::PkJoint& r = P->q_fk[L][cnt++];
         const bool rev = M.jtype[j] >= WBC_JT_RX && M.jtype[j] <= WBC_JT_RZ;
         r.joint = j; r.parent = M.parent[j]; r.a0 = 3 * M.ax0[j]; r.a1 = 3 * M.ax1[j]; r.a2 = 3 * M.ax2[j];
@@ -341,24 +335,44 @@ static void build_orthp_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) 
       }
   }
   for (int j = 1; j < M.njoints; ++j) { P->q_jm[j].m = M.mass[j]; P->q_jm[j].c0 = M.com[j][0]; P->q_jm[j].c1 = M.com[j][1]; P->q_jm[j].c2 = M.com[j][2]; }
+  for (int d = 0; d < M.nv; ++d) {
+    DevPlan::QDof& r = P->q_dof[d];
+    const int j = M.col_joint[d];
+    r.joint = j; r.lin = M.col_lin[d]; r.ang = M.col_ang[d];
+    const uint32_t sub = M.col_subtree[d];
+    int lo = -1, hi = -1, cntj = 0;
+    for (int k = 1; k < M.njoints; ++k) if ((sub >> k) & 1u) { if (lo < 0) lo = k; hi = k; ++cntj; }
+    if (need_subtree) {
+      if (lo < 0 || hi - lo + 1 != cntj) return false;                    // not contiguous
+      if (j != 1 && cntj > 8) return false;                               // the kernel's sub-tree loop
+    }
+    r.sub_lo = lo; r.sub_hi = hi;
+    for (int e = 0; e < WBC_NEE; ++e) if ((M.frame_support[WBC_FR_EE0 + e] >> d) & 1u) r.supmask |= 1u << e;
+  }
+  return true;
+}
+
+// The packed orth kernel's plan (wbc_tick_orthp_kernel): equality-only task problems — the only constraints are the eliminated stance
+// feet's contact rows (no trunk / CoM box, no velocity box), tasks = any EE tasks + optionally the CoM task + posture Tikhonov / PREV.
+static void build_orthp_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) {
+  P->q_ok = 0;
+  const int nelim = P->nelim, nl = 3 * nelim;
+  if (!P->orth || c.use_bounds || c.con_trunk || c.con_com || c.task_trunk || P->p_keep != 0 || nelim < 1 || nelim > 4) return;
+  if (c.task_joint != WBC_JOINT_TIKHONOV && c.task_joint != WBC_JOINT_PREV) return;
+  if (P->n_red > 15) return;
+  if (!build_q_tables(M, P, true)) return;
+  for (int i = 0; i < 18; ++i) P->q_bl2dof[i] = 0;
+  for (int i = 0; i < 16; ++i) P->q_red2dof[i] = 0;
+  for (int e = 0; e < 8; ++e) P->q_efoot[e] = -1;
   // DoF records: [base; eliminated legs] positions, reduced (free) variables 6.., subtree = a contiguous joint range (depth-first numbering)
   int nred = 6;
   uint32_t freemask = 0;
   for (int d = 0; d < M.nv; ++d) {
     DevPlan::QDof& r = P->q_dof[d];
-    const int j = M.col_joint[d];
-    r.joint = j; r.lin = M.col_lin[d]; r.ang = M.col_ang[d];
     if (d < 6) r.bl = d;
     else if (P->lidx[d] >= 0) r.bl = 6 + P->lidx[d];
     else { if (nred >= 15) return; r.red = nred; P->q_red2dof[nred++] = d; freemask |= 1u << d; }
     if (r.bl >= 0) P->q_bl2dof[r.bl] = d;
-    const uint32_t sub = M.col_subtree[d];
-    int lo = -1, hi = -1, cntj = 0;
-    for (int k = 1; k < M.njoints; ++k) if ((sub >> k) & 1u) { if (lo < 0) lo = k; hi = k; ++cntj; }
-    if (lo < 0 || hi - lo + 1 != cntj) return;                    // not contiguous
-    if (j != 1 && cntj > 8) return;                               // the kernel's sub-tree loop
-    r.sub_lo = lo; r.sub_hi = hi;
-    for (int e = 0; e < WBC_NEE; ++e) if ((M.frame_support[WBC_FR_EE0 + e] >> d) & 1u) r.supmask |= 1u << e;
   }
   if (nred != P->n_red) return;
   P->q_nred = nred;
@@ -390,6 +404,67 @@ static void build_orthp_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) 
   P->pk_update_ok = (need <= 6 && build_pk_fk(M, need, P)) ? 1 : 0;
 }
 
+// The packed box kernel's plan (wbc_tick_boxp_kernel): task problems without a single constraint row (the warm-up problem of setInitialState,
+// Robot_Wrapper4.py:196-351): trunk task (trunk frame = the free-flyer's placement) and / or EE tasks + posture Tikhonov / PREV, velocity box on.
+// Eliminated: the six base DoF and, if more than 16 bounded DoF remain, those with the widest box (position range x velocity limit of the damper
+// entry the DoF looks at): their bounds are checked after the solve, a violation sends the instance to the general path. Every limb DoF must
+// move at most ONE active task's frame (the block-arrow structure of H).
+static void build_boxp_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan* P) {
+  P->x_ok = 0;
+  if (prows != 0 || !c.use_bounds || c.task_com) return;
+  if (c.task_joint != WBC_JOINT_TIKHONOV && c.task_joint != WBC_JOINT_PREV) return;
+  const bool trunk_is_root = M.frame_joint[WBC_FR_TRUNK] == 1 && M.frame_p[WBC_FR_TRUNK][0] == 0 && M.frame_p[WBC_FR_TRUNK][1] == 0 && M.frame_p[WBC_FR_TRUNK][2] == 0;
+  if (c.task_trunk && !trunk_is_root) return;
+  if (M.nv > 26 || !build_q_tables(M, P, false)) return;
+  for (int d = 0; d < M.nv; ++d) if (M.col_joint[d] == 1 ? d >= 6 : (M.col_q[d] < 0 || M.col_q[d] >= M.nq)) return;   // one free-flyer + 1-DoF joints
+  for (int e = 0; e < WBC_NEE; ++e) if (c.task_ee[e] && M.depth[M.frame_joint[WBC_FR_EE0 + e]] > 7) return;
+  uint32_t lockmask = 0, tmask = 0;
+  for (int d = c.lock_from; d < M.nv; ++d) if (d >= 6) lockmask |= 1u << d;
+  for (int e = 0; e < WBC_NEE; ++e) if (c.task_ee[e]) tmask |= 1u << e;
+  int freed[32], nfree = 0;
+  for (int d = 6; d < M.nv; ++d) {
+    if ((lockmask >> d) & 1u) continue;
+    if (__builtin_popcount(P->q_dof[d].supmask & tmask) > 1) return;
+    freed[nfree++] = d;
+  }
+  int extra = nfree - 16;
+  if (extra > 2) return;
+  for (int i = 0; i < 32; ++i) P->x_role[i] = -1;
+  for (int i = 0; i < 16; ++i) { memset(&P->x_kept[i], 0, sizeof P->x_kept[i]); P->x_kept[i].task = -1; P->x_limb[i] = 1u << i; }
+  for (int i = 0; i < 8; ++i) { memset(&P->x_elim[i], 0, sizeof P->x_elim[i]); P->x_elim[i].task = -1; }
+  auto fill = [&](DevPlan::XVar& v, int d) {
+    v.dof = d; v.dq_idx = c.damper_qidx[d]; v.d_lo = c.damper_lo[d]; v.d_hi = c.damper_hi[d]; v.d_vm = c.damper_vmax[d];
+    const uint32_t tk = P->q_dof[d].supmask & tmask;
+    v.task = (d >= 6 && tk) ? __builtin_ctz(tk) : -1;
+  };
+  int ne = 6;
+  for (int d = 0; d < 6; ++d) { P->x_role[d] = d; fill(P->x_elim[d], d); }
+  uint32_t elim_extra = 0;
+  for (; extra > 0; --extra) {
+    int best = -1; double bs = -1.0;
+    for (int i = 0; i < nfree; ++i) {
+      const int d = freed[i];
+      if ((elim_extra >> d) & 1u) continue;
+      const double sc = (c.damper_hi[d] - c.damper_lo[d]) * c.damper_vmax[d];
+      if (sc > bs) { bs = sc; best = d; }
+    }
+    if (best < 0) return;
+    elim_extra |= 1u << best;
+    P->x_role[best] = ne; fill(P->x_elim[ne], best); ++ne;
+  }
+  int nk = 0;
+  for (int i = 0; i < nfree; ++i) {
+    const int d = freed[i];
+    if ((elim_extra >> d) & 1u) continue;
+    P->x_role[d] = 16 + nk; fill(P->x_kept[nk], d); ++nk;
+  }
+  for (int k = 0; k < nk; ++k)
+    for (int k2 = 0; k2 < nk; ++k2)
+      if (P->x_kept[k].task >= 0 && P->x_kept[k].task == P->x_kept[k2].task) P->x_limb[k] |= 1u << k2;
+  P->x_ne = ne; P->x_nk = nk; P->x_nlock = __builtin_popcount(lockmask);
+  P->x_ok = 1;
+}
+
 static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan* P) {
   memset(P, 0, sizeof *P);
   build_posture_plan(M, c, P);
@@ -408,6 +483,7 @@ static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan
     for (int d = 0; d < M.nv; ++d) if ((legs >> d) & 1u) { P->lidx[d] = l; P->legd[l++] = d; }
     prow += 3;
   }
+  if (!nelim && c.task_joint) build_boxp_plan(M, c, prows, P);
   if (!nelim || !c.task_joint) return;
   // `clean`: no task touches the stance legs (H_ll = d^2 I, H_lf = 0): the explicit G = -K^-1 B costs no accuracy (contact_presolve,
   // the sim3 kernels). Otherwise the elimination goes through an orthonormal null-space basis (contact_presolve_orth).
@@ -522,6 +598,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
   if (!strcmp(name, "packed_kernel")) { b->packed_kernel = value; return WBC_OK; }
   if (!strcmp(name, "packed_orth")) { b->packed_orth = value; return WBC_OK; }
+  if (!strcmp(name, "packed_box")) { b->packed_box = value; return WBC_OK; }
   if (!strcmp(name, "posture_par")) { b->posture_par = value; return WBC_OK; }
   if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
   if (!strcmp(name, "warm_start")) { b->warm_start = value != 0; return WBC_OK; }
@@ -771,7 +848,33 @@ static bool orthp_eligible(const WbcBatch* b, const KernelArgs& a) {
   for (int i = 0; i < b->n_models; ++i) if (!b->plan_host[i].q_ok) return false;
   return true;
 }
+// the packed box kernel: every plan x_ok, nothing passed that it does not read; packed_box: 1 (default) from WBC_BOXP_MIN_BATCH instances on, 2: always
+constexpr int WBC_BOXP_MIN_BATCH = 4608;
+static bool boxp_eligible(const WbcBatch* b, const KernelArgs& a) {
+  if (b->packed_box == 1 && a.B < WBC_BOXP_MIN_BATCH) return false;
+  if (!b->packed_box || !b->packed_kernel || !b->presolve || b->n_models < 1 || b->jtj_mfma > 0 || b->prows != 0) return false;
+  if (a.ws_in || a.ws_out || a.in.q_con || a.in.posture_u || b->dbg_alias || (b->dbg_stop > 0 && b->dbg_stop < 300)) return false;   // (dbg_stop 301.. cuts this kernel)
+  for (int i = 0; i < b->n_models; ++i) if (!b->plan_host[i].x_ok) return false;
+  return true;
+}
 static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
+  if (boxp_eligible(b, a)) {    // ONE kernel per tick; last_path 4
+    b->last_path = 4;
+    b->last_orth = 0;
+    if (!a.out.status) {
+      if (!b->d_status) HIP_TRY(hipMalloc((void**)&b->d_status, sizeof(int32_t) * (size_t)b->max_batch));
+      a.out.status = b->d_status;
+    }
+    if (!b->d_dstat) {
+      HIP_TRY(hipMalloc((void**)&b->d_dstat, sizeof(unsigned long long)));
+      HIP_TRY(hipMemsetAsync(b->d_dstat, 0, sizeof(unsigned long long), (hipStream_t)stream));
+    }
+    a.defer_stat = b->d_dstat;
+    a.tick_seq = ++b->tick_seq;
+    if (!b->tick_seq) a.tick_seq = ++b->tick_seq;
+    if (int e = launch_tick_boxp(a, stream)) return fail(WBC_E_HIP, "packed box tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    return WBC_OK;
+  }
   if (orthp_eligible(b, a)) {   // ONE kernel per tick; last_path 3
     b->last_path = 3;
     b->last_orth = 1;

@@ -58,6 +58,14 @@ struct DevPlan {
   QJnt q_jm[32];
   int32_t q_bl2dof[18], q_red2dof[16];
   int32_t q_efoot[8];                // EE e: index of its leg among the eliminated feet (-1: not an eliminated foot)
+  // packed box kernel (wbc_tick_boxp_kernel, round 3): task problems WITHOUT constraint rows (the warm-up problem of setInitialState), four
+  // instances per wavefront. The base and (where 16 lanes do not hold the rest) the limb DoF with the widest box are eliminated by a Schur
+  // complement; DoF locked at 0 are left out. Shares q_fk / q_scq / q_dof (joint, lin, ang, supmask) with the packed orth kernel.
+  int32_t x_ok, x_ne, x_nk, x_nlock;  // eligible; eliminated DoF (6..8), kept (bounded) variables (<= 16), DoF locked at 0
+  struct XVar { int32_t dof, dq_idx, task, pad_; double d_lo, d_hi, d_vm; };   // DoF, its velocity-damper entries, the EE task that moves with it (-1: none / base)
+  XVar x_kept[16], x_elim[8];
+  int32_t x_role[32];                // DoF d: 0..7 eliminated slot, 16 + k kept variable k, -1 locked / absent
+  uint32_t x_limb[16];               // kept variable k: bit k2 = kept variable k2 moves the same task's frame (the limb block of H_KK)
   uint32_t elimrows;                 // bit i: constraint row i belongs to an eliminated foot
   uint32_t legrows;                  // bit i: kept constraint row i has support on eliminated leg DoF (needs C Z)
   // qpJointb "MANI"/"HYBRID" when EVERY finite difference is structurally zero (the perturbed joint is not a proper ancestor
@@ -174,6 +182,7 @@ struct UpdateArgs {
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream);
 int launch_tick_sim3(const KernelArgs& a, int grid, void* stream);
 int launch_tick_sim3p(const KernelArgs& a, void* stream);      // packed: four instances per wavefront, grid = ceil(B / 4)
+int launch_tick_boxp(const KernelArgs& a, void* stream);       // packed box kernel (task problems without constraint rows), grid = ceil(B / 4)
 int launch_tick_orthp(const KernelArgs& a, void* stream);      // packed orth kernel (equality-only task problems), grid = ceil(B / 4)
 int orthp_lds_bytes();
 int sim3p_lds_bytes();
