@@ -463,6 +463,10 @@ static void build_boxp_plan(const DevModel& M, const WbcConfig& c, int prows, De
       if (P->x_kept[k].task >= 0 && P->x_kept[k].task == P->x_kept[k2].task) P->x_limb[k] |= 1u << k2;
   P->x_ne = ne; P->x_nk = nk; P->x_nlock = __builtin_popcount(lockmask);
   P->x_ok = 1;
+  // the warm-up roll-out (mode WBC_ROLLOUT_WARMUP) updates its state on wbc_update_packed_kernel too: its FK schedule down to the deepest frame it reads
+  int need = M.depth[M.frame_joint[WBC_FR_TRUNK]];
+  for (int e = 0; e < 5; ++e) if (M.depth[M.frame_joint[WBC_FR_EE0 + e]] > need) need = M.depth[M.frame_joint[WBC_FR_EE0 + e]];
+  P->pk_update_ok = (need <= 6 && build_pk_fk(M, need, P)) ? 1 : 0;
 }
 
 static void build_plan(const DevModel& M, const WbcConfig& c, int prows, DevPlan* P) {

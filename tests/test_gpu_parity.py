@@ -936,6 +936,100 @@ def test_packed_orth_kernel_variants_and_non_finite_inputs(wx200, px100, posture
     bt.close()
 
 
+@pytest.mark.parametrize("variant", ["warm_up", "prev_no_trunk", "three_tasks"])
+def test_packed_box_kernel_variants_and_non_finite_inputs(wx200, px100, variant):
+    """wbc_tick_boxp_kernel (task problems without constraint rows, four per wavefront, base + one thigh eliminated by a Schur complement):
+    the warm-up problem of setInitialState (Robot_Wrapper4.py:196-351: six Cartesian tasks + Tikhonov) with moving orientation references,
+    the PREV posture without the trunk task, and a stack in which two legs and the arm carry no task at all (their DoF see the posture row
+    only) — each on a mixed wx200 / px100 batch at a size the default policy sends to it, ragged tail, q_next, working-set changes equal to
+    the oracle's (the reduced problem's dual iterates ARE the full problem's), and non-finite inputs contained to their own instance."""
+    B = 4610
+    models = [wx200, px100]
+    kw = dict(warm_up=dict(Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=True),
+              prev_no_trunk=dict(FR=True, FL=True, RR=True, RL=True, Grip=True, Joint="PREV"),
+              three_tasks=dict(Trunk=True, FR=True, RR=True, Joint=True))[variant]
+    cfgs = [wbc_model.make_config(m, **kw) for m in models]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=91 + i, with_rot=(variant != "three_tasks")) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    d["q"] = d["q"].copy()
+    d["q"][6, 2] = np.nan                       # the base height
+    d["q"][1001, 4] = np.inf                    # a quaternion component
+    d["ee_target"] = d["ee_target"].copy()
+    d["ee_target"][2007, 0, 1] = np.nan         # the FR foot's target
+    ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
+    bad = np.zeros(B, bool)
+    bad[[6, 1001, 2007]] = True
+    assert (ref["status"][bad] != 0).all() and (ref["status"][~bad] == 0).mean() > 0.99
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    assert bt.constraint_rows == 0
+    got = bt.tick(d, DT, want_q_next=True)
+    assert bt.stat("last_path") == 4                                   # the default policy: packed from 4608 instances on
+    ok = ref["status"] == 0
+    # the tail takes exactly the instances whose optimum holds an ELIMINATED DoF (base; wx200: + the first thigh) at its velocity bound: none in the
+    # warm-up problem (the trunk task pins the base), a handful without the trunk task
+    asm = oracle.assemble(models, cfgs, d, DT, B)
+    elim = np.zeros((B, 26), bool)
+    elim[:, :6] = True
+    elim[mid == 0, 7] = True
+    held = ((np.abs(ref["qdot"] - asm["lb"]) < 1e-9 * np.maximum(1, np.abs(asm["lb"]))) | (np.abs(ref["qdot"] - asm["ub"]) < 1e-9 * np.maximum(1, np.abs(asm["ub"])))) & elim
+    expect = int((held.any(axis=1) & ok).sum())
+    nd = bt.stat("deferred_last")
+    print("   instances redone in the tail: %d (oracle: %d with an eliminated DoF at its bound)" % (nd, expect))
+    assert abs(nd - expect) <= 2 and nd <= 0.02 * B and (variant != "warm_up" or nd == 0)
+    assert ((got["status"] != 0) == (ref["status"] != 0)).all()
+    assert (got["qdot"][~ok] == 0).all() and np.isfinite(got["qdot"]).all()
+    err = np.abs(got["qdot"] - ref["qdot"])[ok].max()
+    print("packed box kernel, %s, mixed batch: qdot max-abs err %.3e, working-set changes %.2f (oracle %.2f)" % (
+        variant, err, got["iters"][ok].mean(), ref["iters"][ok].mean()))
+    assert err < (1e-8 if nd == 0 else QDOT_TOL) and np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-8    # (cond(H') ~ 1e3: far inside QDOT_TOL)
+    assert (got["iters"] == ref["iters"])[ok & (mid == 0)].mean() > 0.99
+    assert (got["iters"] + 1 == ref["iters"])[ok & (mid == 1)].mean() > 0.99   # (the oracle also counts px100's padded 26th DoF, a locked bound)
+    bt.set_option("packed_box", 0)
+    one = bt.tick(d, DT)
+    assert bt.stat("last_path") == 0 and np.abs(one["qdot"] - got["qdot"])[ok].max() < 1e-8 and (one["status"] == got["status"]).all()
+    bt.close()
+
+
+@pytest.mark.parametrize("case", ["base_bound", "many_bounds"])
+def test_packed_box_kernel_redoes_what_its_reduction_does_not_cover(wx200, case):
+    """The packed box kernel eliminates DoF whose velocity bounds it only CHECKS afterwards, and holds at most 12 active bounds: an instance
+    whose optimum needs an eliminated DoF at its bound (here: the base box shrunk to 0.05 — vel_lim[0:6] = 5 in the reference never binds)
+    or more active bounds than that (every leg / arm limit shrunk to 0.02) is redone by its own wave on the general path — same answer as
+    the oracle, statistic "deferred_last" counts them, the other instances of the wavefront are untouched."""
+    B = 515
+    cfg = common.config("full", wx200)
+    if case == "base_bound":
+        for i in range(6):
+            cfg.damper_vmax[i] = 0.05
+    else:
+        for i in range(6, 23):
+            cfg.damper_vmax[i] = 0.02
+    d = common.tick_inputs(wx200, cfg, B, seed=93, with_rot=True)
+    ref = oracle.tick([wx200], [cfg], d, DT, B, nthreads=8)
+    ok = ref["status"] == 0
+    assert ok.mean() > 0.95
+    lim = 0.05 if case == "base_bound" else 0.02
+    at_bound = (np.abs(np.abs(ref["qdot"][:, :6] if case == "base_bound" else ref["qdot"][:, 6:23]) - lim) < 1e-12).sum(axis=1)
+    expect = (at_bound > 0) if case == "base_bound" else (at_bound > 12)
+    assert 0.1 < expect[ok].mean()
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    bt.set_option("packed_box", 2)
+    got = bt.tick(d, DT, want_q_next=True)
+    assert bt.stat("last_path") == 4
+    nd = bt.stat("deferred_last")
+    print("%s: %d of %d instances took the tail (oracle: %d with %s)" % (case, nd, B, expect[ok].sum(), "a base DoF at its bound" if case == "base_bound" else "more than 12 active bounds"))
+    assert nd >= expect[ok].sum() and (case == "many_bounds" or nd == expect[ok].sum())
+    assert (got["status"] == ref["status"]).all()
+    assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL and np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    assert (got["iters"] == ref["iters"])[ok].mean() > 0.98
+    bt.close()
+
+
 def test_rollouts_are_deterministic_and_survive_unsolvable_ticks(wx200):
     """Run-to-run bit equality of a long roll-out in which some instances run into unsolvable QPs on the way (they hold
     still from then on instead of integrating a partial iterate into garbage — found with tools/determinism.py)."""
@@ -957,7 +1051,8 @@ def test_rollouts_are_deterministic_and_survive_unsolvable_ticks(wx200):
 
 
 @pytest.mark.parametrize("cfg_name,with_rot,model_name", [("c3", False, "wx200"), ("c3", False, "px100"), ("c2", False, "wx200"),
-                                                          ("everything", True, "wx200"), ("hybrid_grip_com", False, "wx200")])
+                                                          ("everything", True, "wx200"), ("hybrid_grip_com", False, "wx200"),
+                                                          ("full", True, "wx200"), ("full", True, "px100")])
 def test_gpu_solution_against_the_exact_optimum(wx200, px100, cfg_name, with_rot, model_name):
     """The device's q̇ against the EXACT (rational-arithmetic) optimum of the double-precision QP data it assembled itself: no oracle
     in between (tests/common.py exact_optimum: Gaussian elimination in fractions on the active set the answer shows, optimality
@@ -977,6 +1072,7 @@ def test_gpu_solution_against_the_exact_optimum(wx200, px100, cfg_name, with_rot
         for name, v in zip(("presolve", "presolve_orth", "sim3_kernel", "packed_kernel"), key):
             bt.set_option(name, v)
         bt.set_option("packed_orth", 2)      # (small batch: 1 would keep config 2 on the one-instance kernel)
+        bt.set_option("packed_box", 2 if key[3] else 0)
         got = bt.tick(d, DT)
         path = (bt.stat("last_path"), bt.stat("last_orth"))
         # an instance is solved on every kernel path or on none: a path that fails where another succeeds must not go unnoticed
@@ -1003,6 +1099,9 @@ def test_gpu_solution_against_the_exact_optimum(wx200, px100, cfg_name, with_rot
         assert {(0, 1), (0, 0)} <= paths                  # orthonormal presolve, full size
     if cfg_name == "c2":
         assert (3, 1) in paths                            # the packed orth kernel
+    if cfg_name == "full":
+        assert {(4, 0), (0, 0)} <= paths                  # the packed box kernel, full size
+        assert worst[((1, 1, 1, 1), (4, 0))] < 1e-9      # cond(H') ~ 1e3 after the Schur complement: the packed path is the MOST accurate one
     bt.close()
 
 
@@ -1218,6 +1317,12 @@ def test_batched_warm_up_matches_the_oracle(wx200, px100):
     # working-set changes: equal for wx200; the oracle also counts px100's padded 26th DoF (a locked bound) once per tick
     assert np.abs(short["iters"] - ref["iters"])[mid == 0].max() <= 4
     assert np.abs(short["iters"] + 100 - ref["iters"])[mid == 1].max() <= 4
+    # the same warm-up with every tick on the packed box kernel (the default policy takes it from 4608 robots on) and the packed state update
+    bt.set_option("packed_box", 2)
+    packed = bt.warm_up(q0, mid, DT, 50, foot_radius=fr)
+    assert bt.stat("last_path") == 4 and bt.stat("last_update_packed") == 1
+    assert (packed["status"] == ref["status"]).all() and np.abs(packed["q"] - ref["q"]).max() < 1e-6
+    assert np.abs(packed["iters"] - ref["iters"])[mid == 0].max() <= 4
     bt.close()
 
 
