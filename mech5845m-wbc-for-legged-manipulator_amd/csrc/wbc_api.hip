@@ -852,8 +852,10 @@ static bool orthp_eligible(const WbcBatch* b, const KernelArgs& a) {
   for (int i = 0; i < b->n_models; ++i) if (!b->plan_host[i].q_ok) return false;
   return true;
 }
-// the packed box kernel: every plan x_ok, nothing passed that it does not read; packed_box: 1 (default) from WBC_BOXP_MIN_BATCH instances on, 2: always
-constexpr int WBC_BOXP_MIN_BATCH = 4608;
+// the packed box kernel: every plan x_ok, nothing passed that it does not read; packed_box: 1 (default) from WBC_BOXP_MIN_BATCH instances on, 2: always.
+// Unlike the packed orth kernel it wins at every batch size (measured on MI355X, tools/small_batch_boxp.py: 28.1 vs 29.3 us at B = 1, 39.9 vs 46.4 us
+// at 1024, 46 vs 104 us at 4096): the one-instance kernel's chain through a 23-wide Cholesky and ~5 working-set changes is the longer one.
+constexpr int WBC_BOXP_MIN_BATCH = 1;
 static bool boxp_eligible(const WbcBatch* b, const KernelArgs& a) {
   if (b->packed_box == 1 && a.B < WBC_BOXP_MIN_BATCH) return false;
   if (!b->packed_box || !b->packed_kernel || !b->presolve || b->n_models < 1 || b->jtj_mfma > 0 || b->prows != 0) return false;

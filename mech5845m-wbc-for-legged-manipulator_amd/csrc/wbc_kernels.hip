@@ -5537,6 +5537,19 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_boxp_kernel(const KernelArgs A
 #pragma unroll
     for (int i = 0; i < 6; ++i) wt[s + 16 * i] = (s + 16 * i < 85) ? cw[s + 16 * i] : 0.0;
   }
+  const int nv = M.nv, nq = M.nq, nk = P.x_nk, ne = P.x_ne;
+  const DevPlan::QDof D0 = P.q_dof[s], D1 = P.q_dof[16 + s];
+  const int role0 = P.x_role[s], role1 = P.x_role[16 + s];
+  const DevPlan::XVar kv = P.x_kept[s], ev = P.x_elim[s & 7];
+  const unsigned limb = P.x_limb[s];
+  DevPlan::PkJoint fkn = P.q_fk[0][s];
+  const int scq0 = P.q_scq[(2 + s) & 31], scq1 = P.q_scq[(18 + s) & 31];
+  const bool has1 = 16 + s < nv;
+  const int c_task_joint = cfg.task_joint;
+  const double dcoef = cfg.damper_coef, dqi = cfg.damper_qi, dqs = cfg.damper_qs;
+  const int fjoint = (s < 5) ? M.frame_joint[WBC_FR_EE0 + s] : 1;
+  const double fp0 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][0] : 0.0, fp1 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][1] : 0.0,
+               fp2 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][2] : 0.0;
   WSYNC();
   const double* const qv = I.in;
   if (__ballot(c_trunk)) {
@@ -5582,21 +5595,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_boxp_kernel(const KernelArgs A
       for (int i = 0; i < 6; ++i) tin[i] = vel[i] * trunk_w;
     }
     WSYNC();
-    __builtin_amdgcn_sched_barrier(0);      // (the per-lane records below are fetched after this block)
   }
-  const int nv = M.nv, nq = M.nq, nk = P.x_nk, ne = P.x_ne;
-  const DevPlan::QDof D0 = P.q_dof[s], D1 = P.q_dof[16 + s];
-  const int role0 = P.x_role[s], role1 = P.x_role[16 + s];
-  const DevPlan::XVar kv = P.x_kept[s], ev = P.x_elim[s & 7];
-  const unsigned limb = P.x_limb[s];
-  DevPlan::PkJoint fkn = P.q_fk[0][s];
-  const int scq0 = P.q_scq[(2 + s) & 31], scq1 = P.q_scq[(18 + s) & 31];
-  const bool has1 = 16 + s < nv;
-  const int c_task_joint = cfg.task_joint;
-  const double dcoef = cfg.damper_coef, dqi = cfg.damper_qi, dqs = cfg.damper_qs;
-  const int fjoint = (s < 5) ? M.frame_joint[WBC_FR_EE0 + s] : 1;
-  const double fp0 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][0] : 0.0, fp1 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][1] : 0.0,
-               fp2 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][2] : 0.0;
   double* const oMi = I.X;                   // [22][12]
   double* const sc = I.W;                    // sin / cos of joint j at 2 j
   {

@@ -10,7 +10,7 @@ wx, px = common.models()
 dev = torch.device("cuda", 0)
 only = sys.argv[1:]          # optional: configuration names to time (default: all)
 for name, B, mixed in (("c2", 1024, False), ("c2", 4096, False), ("c2", 65536, False), ("c3", 1024, False), ("c3", 4096, False), ("c3", 65536, False),
-                       ("c3", 65536, True), ("c3_trunk_task", 65536, False), ("c3_mani", 65536, False), ("everything", 65536, False), ("full", 65536, False),
+                       ("c3", 65536, True), ("c3_trunk_task", 65536, False), ("c3_mani", 65536, False), ("everything", 65536, False), ("full", 1024, False), ("full", 4096, False), ("full", 65536, False),
                        ("hybrid_grip_com", 65536, False)):
     if only and name not in only:
         continue
