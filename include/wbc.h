@@ -326,8 +326,15 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          (orthonormal contact presolve, unconstrained reduced problem) from 4608 instances on — below that one round
  *                          of waves covers the batch and the one-instance kernel's shorter dependent chain wins (25 vs 55 us at
  *                          B = 1024, equal at 4096, 0.29 vs 0.78 ms at 65536); 2: at every batch size; 0: never.
- *   "posture_par"      [1] qpJointb "MANI" / "HYBRID" targets on wbc_posture_par_kernel (every finite-difference point on a lane of
- *                          its own, statistic "last_posture_par"); 0: the sequential whole-tree kernel (52 sweeps per instance).
+ *   "packed_box"       [1] the task problems WITHOUT constraint rows (the warm-up problem of setInitialState, Robot_Wrapper4.py:196-351:
+ *                          trunk / EE tasks + posture Tikhonov / PREV, velocity box only) run FOUR instances per wavefront on
+ *                          wbc_tick_boxp_kernel: the base and, where 16 lanes do not hold the rest, the limb DoF with the widest box are
+ *                          eliminated by a Schur complement, the dual method works on <= 16 bounded unknowns, and an instance whose
+ *                          optimum holds an eliminated DoF at its own velocity bound (or more than 12 active bounds) is redone by
+ *                          its wave on the general path. At every batch size (28 vs 29 us at B = 1, 40 vs 46 us at 1024, 0.38 vs
+ *                          1.23 ms at 65536); 0: never (general kernel).
+ *   "posture_par"      [1] qpJointb "MANI" / "HYBRID" targets on the parallel posture kernel, wbc_posture_par_kernel: every finite-difference
+ *                          point on a lane of its own (statistic "last_posture_par"); 0: the sequential whole-tree kernel (52 sweeps per instance).
  *   "packed_update"    [1] wbc_update_state / the roll-out's state update run four instances per wavefront where every model's
  *                          configuration is of the packed kernel's family (statistic "last_update_packed"); 0: one per wavefront.
  *   "presolve_tol_exp" [7] a stance-leg 3 x 3 block K with |det K| <= 10^-value (sum |K_ij|)^3 is treated as rank deficient: the
@@ -350,15 +357,16 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          (wbc_tick is warm exactly when WbcTickIn.working_set is passed.)
  *   "grid"                 workgroups of the grid-stride kernels (wbc_qp_solve*, wbc_integrate); default = what fills the chip.
  *   "dbg_alias_inputs" [0] diagnostic: every instance reads instance 0's inputs (isolates input latency in timings).
- *   "dbg_stop"         [0] diagnostic: the sim3 kernel stops after stage k (1..7, see wbc_kernels.hip) — outputs are garbage,
- *                          only the run time means something (tools/ablate_sim3.py). */
+ *   "dbg_stop"         [0] diagnostic (ablation build of the library only): the sim3 kernel stops after stage k (1..7, see wbc_kernels.hip;
+ *                          101.. the packed sim3 kernel, 201.. the packed orth kernel, 301.. the packed box kernel) — outputs are garbage,
+ *                          only the run time means something (tools/ablate_sim3.py, ablate_orthp.py, ablate_boxp.py). */
 int wbc_batch_set_option(WbcBatch* b, const char* name, int value);
 
 /* Read-only statistics of a handle: "last_path" (kernel the last tick ran on: 0 general, 1 compact sim3 + second pass, 2 packed
- * compact sim3 — four instances per wavefront, one kernel —, 3 packed orth kernel), "last_orth" (1: that tick ran with the
+ * compact sim3 — four instances per wavefront, one kernel —, 3 packed orth kernel, 4 packed box kernel), "last_orth" (1: that tick ran with the
  * orthonormal contact presolve, option "presolve_orth": the general kernel's ORTH variant or the packed orth kernel),
  * "last_update_packed" (1: the last state update ran on the packed kernel), "last_posture_par" (1: the last MANI / HYBRID posture target
- * ran on wbc_posture_par_kernel), "deferred_last" (instances the last tick's kernel could not reduce itself: redone in the packed kernels'
+ * ran on the parallel posture kernel), "deferred_last" (instances the last tick's kernel could not reduce itself: redone in the packed kernels'
  * tail or left to the one-instance kernel's second pass; waits for `stream`), "pivoted_last" (instances that took the pivoted
  * elimination, with option "count_pivoted"), "sim3_lds_bytes" / "tick_lds_bytes" / "orthp_lds_bytes" (LDS per workgroup of the tick kernels). */
 int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, int64_t* out);
