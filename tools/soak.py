@@ -11,9 +11,9 @@ seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 wx, px = common.models()
 threads = min(32, len(os.sched_getaffinity(0)))   # (the box's CPU share: 32 threads beat 256, bench.py's sweep)
 worst = 0.0
-for cfg_name in ("c3", "c3_hybrid", "c3_trunk_task", "c3_mani", "c2", "everything"):
+for cfg_name in ("c3", "c3_hybrid", "c3_trunk_task", "c3_mani", "c2", "full", "everything"):
     for mixed in (False, True):
-        if mixed and cfg_name != "c3":
+        if mixed and cfg_name not in ("c3", "full"):
             continue
         models = [wx, px] if mixed else [wx]
         cfgs = [common.config(cfg_name, m) for m in models]
@@ -24,11 +24,11 @@ for cfg_name in ("c3", "c3_hybrid", "c3_trunk_task", "c3_mani", "c2", "everythin
             n = B if cfg_name in ("c3", "c3_hybrid") else B // 8      # (B // 8 = 32768 by default: config 2 runs on the packed orth kernel)
             if mixed:
                 mid = (np.arange(n) % 2).astype(np.int32)
-                parts = [common.tick_inputs(m, c, n, 1000 + seed + 17 * k) for k, (m, c) in enumerate(zip(models, cfgs))]
+                parts = [common.tick_inputs(m, c, n, 1000 + seed + 17 * k, with_rot=(cfg_name == "full")) for k, (m, c) in enumerate(zip(models, cfgs))]
                 d = {k: np.where(mid.reshape((n,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
                 d["model_id"] = mid
             else:
-                d = common.tick_inputs(wx, cfgs[0], n, 1000 + seed, with_rot=(cfg_name == "everything"))
+                d = common.tick_inputs(wx, cfgs[0], n, 1000 + seed, with_rot=(cfg_name in ("everything", "full")))
             t0 = time.perf_counter()
             ref = oracle.tick(models, cfgs, d, 0.002, n, nthreads=threads, want_q_next=False)
             t1 = time.perf_counter()
@@ -40,7 +40,8 @@ for cfg_name in ("c3", "c3_hybrid", "c3_trunk_task", "c3_mani", "c2", "everythin
             bad = int((~np.isfinite(got["qdot"])).any(axis=1).sum())
             worst = max(worst, err[ok].max())
             print("%-11s mixed=%d seed %d n=%d: status agree %.6f (optimal %.4f, infeasible %.4f), qdot err max %.2e p99.9 %.2e, "
-                  "non-finite rows %d, oracle %.1f s, kernel path %d" % (cfg_name, mixed, seed, n, agree, (ref["status"] == 0).mean(),
-                                                          (ref["status"] == 2).mean(), err[ok].max(), np.quantile(err[ok], 0.999), bad, t1 - t0, path), flush=True)
+                  "non-finite rows %d, oracle %.1f s, kernel path %d, redone in the tail %d" % (cfg_name, mixed, seed, n, agree, (ref["status"] == 0).mean(),
+                                                          (ref["status"] == 2).mean(), err[ok].max(), np.quantile(err[ok], 0.999), bad, t1 - t0, path,
+                                                          bt.stat("deferred_last") if path >= 2 else 0), flush=True)
         bt.close()
 print("worst qdot error over all optimal instances: %.3e" % worst)
