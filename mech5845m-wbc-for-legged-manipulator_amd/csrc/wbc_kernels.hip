@@ -3651,7 +3651,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     WSYNC();                               // (the staged inputs are visible)
     const double* const qv = V.in;
     // calcTargetVelTrunk2 (Robot_Wrapper4.py:948-1015) / TrunkB (:914-920): the trunk frame is the free-flyer's own placement (the plan checks
-    // it), so the target velocity depends on the inputs alone — formed here, where hardly anything is live, and parked in V.xv[9..14]
+    // it), so the target velocity depends on the inputs alone — formed here, where hardly anything is live
     const double* tw = V.xv + 2;           // trunk_W [0..5], trunk_w [6], trunk_gain [7..12]
     const double* xt = V.tv;
     const double* xp = V.tv + 3;
@@ -3687,10 +3687,40 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     vel[4] = (D[0] * Rs[2] + D[1] * Rs[5] + D[2] * Rs[8]) + tw[11] * qe1;
     vel[5] = (D[3] * Rs[0] + D[4] * Rs[3] + D[5] * Rs[6]) + tw[12] * qe2;
     const double trunk_w = tw[6];
-    WSYNC();                               // (everyone has read the gains)
-    if (s == 0) {
+    // trunkA (Robot_Wrapper4.py:487-490, WORLD): the task's rows live on the six base columns, and the free-flyer's own Jacobian columns are its
+    // placement (linear DoF c: column c of R; angular DoF c: p x column c, column c) — so the task's WHOLE contribution, the 6 x 6 block of H'
+    // and its part of g, is formed here, where hardly anything is live, and parked in Cq [0..41] (free until the constraint stage). In the task
+    // stage it used to keep 30 values alive across the Grip block: ~55 spill instructions in the hot path, 0.14 ms per 65536 ticks.
+    double at[6] = {0, 0, 0, 0, 0, 0};
+    {
+      const int c = s < 3 ? s : (s < 6 ? s - 3 : 0);
+      const double col[3] = {Rt_[c], Rt_[3 + c], Rt_[6 + c]};
+      const double pr[3] = {qv[0], qv[1], qv[2]};
+      double lin[3] = {col[0], col[1], col[2]}, ang[3] = {0, 0, 0};
+      if (s >= 3) { ang[0] = col[0]; ang[1] = col[1]; ang[2] = col[2]; cross3(pr, ang, lin); }
 #pragma unroll
-      for (int i = 0; i < 6; ++i) V.xv[9 + i] = vel[i] * trunk_w;
+      for (int rr = 0; rr < 3; ++rr) {
+        at[rr] = (s < 6) ? (tw[rr] * lin[rr]) * trunk_w : 0.0;
+        at[3 + rr] = (s < 6) ? (tw[3 + rr] * ang[rr]) * trunk_w : 0.0;
+      }
+    }
+    double* const At2 = I.M1;              // [6][6] (free until the FK)
+    WSYNC();                               // (everyone has read the gains)
+    if (s < 6) {
+#pragma unroll
+      for (int rr = 0; rr < 6; rr += 2) sts2(At2 + s * 6 + rr, at[rr], at[rr + 1]);
+    }
+    WSYNC();
+    if (s < 6) {
+      double gs = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) gs = fma(-at[rr], vel[rr] * trunk_w, gs);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const double2a t0 = lds2(At2 + k * 6), t1 = lds2(At2 + k * 6 + 2), t2 = lds2(At2 + k * 6 + 4);
+        I.Cq[s * 6 + k] = fma(at[0], t0.x, fma(at[1], t0.y, fma(at[2], t1.x, fma(at[3], t1.y, fma(at[4], t2.x, at[5] * t2.y)))));
+      }
+      I.Cq[36 + s] = gs;
     }
     WSYNC();
     __builtin_amdgcn_sched_barrier(0);    // (the per-lane records below are fetched after this block: live across it they spilled 110 VGPRs)
@@ -3832,24 +3862,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       g = fma(-a[3], w3 * ee_w, g); g = fma(-a[4], w4 * ee_w, g); g = fma(-a[5], w5 * ee_w, g);
     }
   }
-  double at[6] = {0, 0, 0, 0, 0, 0};       // trunk task rows of reduced variable s
-  double* const At2 = I.M1 + 48;           // [6][6] (M1 beyond Ex is free between the FK and the Cholesky sweep)
-  if (TRUNK) {   // trunkA (Robot_Wrapper4.py:487-490, WORLD); the target velocity was formed at the top (V.xv[9..14])
-    const double* tw = V.xv + 2;           // trunk_W [0..5], trunk_w [6]
-    const double trunk_w = tw[6];
-    const bool sup = (s < n) && ((P.redsup[WBC_FR_TRUNK] >> s) & 1u);
-#pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {
-      at[rr] = sup ? (tw[rr] * lin0[rr]) * trunk_w : 0.0;
-      at[3 + rr] = sup ? (tw[3 + rr] * ang0[rr]) * trunk_w : 0.0;
-    }
-#pragma unroll
-    for (int rr = 0; rr < 6; ++rr) g = fma(-at[rr], V.xv[9 + rr], g);
-    if (s < 6) {
-#pragma unroll
-      for (int rr = 0; rr < 6; rr += 2) sts2(At2 + s * 6 + rr, at[rr], at[rr + 1]);
-    }
-  }
+  if (TRUNK && s < 6) g += I.Cq[36 + s];    // the trunk task's part (formed at the top)
 #pragma unroll
   for (int rr = 0; rr < 6; rr += 2) sts2(At + s * 6 + rr, a[rr], a[rr + 1]);
   if (!QCON) {   // (QCON: the contact rows belong to the constraint state, see the second pass below)
@@ -3888,12 +3901,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     }
 #pragma unroll
     for (int k = 0; k < PV; ++k) if (k == s) h[k] += (s < n) ? dpost * dpost : 1.0;   // (lanes >= PV carry an all-zero row: harmless)
-    if (TRUNK) {   // the trunk rows: support on the six base columns
+    if (TRUNK && s < 6) {   // the trunk task's 6 x 6 block on the base columns (formed at the top)
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const double2a t0 = lds2(At2 + k * 6), t1 = lds2(At2 + k * 6 + 2), t2 = lds2(At2 + k * 6 + 4);
-        h[k] += fma(at[0], t0.x, fma(at[1], t0.y, fma(at[2], t1.x, fma(at[3], t1.y, fma(at[4], t2.x, at[5] * t2.y)))));
-      }
+      for (int k = 0; k < 6; k += 2) { const double2a v = lds2(I.Cq + s * 6 + k); h[k] += v.x; h[k + 1] += v.y; }
     }
   }
   PSTOP(2, h[0] + h[5] + h[11] + g);
