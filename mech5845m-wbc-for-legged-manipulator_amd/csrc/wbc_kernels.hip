@@ -4424,13 +4424,14 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     const double vv = 2.0 * hv;
     const double w = (zr.z - delta * zr.jq) * ((vv > 0.0) ? frcp(hv) : 0.0);
     if (add && has_b && vv > 0.0) {
+      // J2 <- J2 - w v', v = d2 - delta e_q: the sweep runs on d2 alone (yv = d for k >= q, else 0) and entry q is then stored with its own term —
+      // the same arithmetic as selecting v_k inside the loop, without two compares and four selects per pair
 #pragma unroll
       for (int k = 0; k < PV; k += 2) {
-        const double2a j2 = lds2(J + s * PLD + k); const double2a y2 = lds2(V.yv + k);   // yv = d for k >= q, else 0
-        const double v0 = (k == q) ? y2.x - delta : y2.x;
-        const double v1 = (k + 1 == q) ? y2.y - delta : y2.y;
-        sts2(J + s * PLD + k, fma(-w, v0, j2.x), fma(-w, v1, j2.y));
+        const double2a j2 = lds2(J + s * PLD + k); const double2a y2 = lds2(V.yv + k);
+        sts2(J + s * PLD + k, fma(-w, y2.x, j2.x), fma(-w, y2.y, j2.y));
       }
+      J[s * PLD + q] = fma(-w, zr.dq - delta, zr.jq);
     }
     if (add) {
       const double idel = (zr.dq >= 0.0) ? -rsz : rsz;
@@ -6041,14 +6042,13 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_boxp_kernel(const KernelArgs A
     const double hv = zn - delta * zr.dq;               // v'v / 2
     const double vv = 2.0 * hv;
     const double w = (zr.z - delta * zr.jq) * ((vv > 0.0) ? frcp(hv) : 0.0);
-    if (add && has_b && vv > 0.0) {
+    if (add && has_b && vv > 0.0) {   // J2 <- J2 - w v', v = d2 - delta e_q (entry q stored with its own term after the sweep on d2)
 #pragma unroll
       for (int k = 0; k < 16; k += 2) {
         const double2a j2 = lds2(J + s * XLD + k); const double2a y2 = lds2(yv + k);   // yv = d for k >= q, else 0
-        const double v0 = (k == q) ? y2.x - delta : y2.x;
-        const double v1 = (k + 1 == q) ? y2.y - delta : y2.y;
-        sts2(J + s * XLD + k, fma(-w, v0, j2.x), fma(-w, v1, j2.y));
+        sts2(J + s * XLD + k, fma(-w, y2.x, j2.x), fma(-w, y2.y, j2.y));
       }
+      J[s * XLD + q] = fma(-w, zr.dq - delta, zr.jq);
     }
     if (add) {
       const double idel = (zr.dq >= 0.0) ? -rsz : rsz;
