@@ -5478,15 +5478,20 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
 constexpr int XLD = 18;                     // row stride of J (9 s mod 16 is a permutation: "lane = row" b128 reads are conflict-free)
 constexpr int XTLD = 14, XTC = 12;          // T = R^-1: at most XTC active bounds, row stride XTLD
 constexpr int DPP_ROR8 = 0x128;             // row_ror:8 — lane s <-> lane s ^ 8 of the 16-lane row
+// R's length sets the distance between the four instances' blocks. 188 made it 5120 B = a multiple of the 256-byte bank row: every broadcast read
+// (all lanes of an instance on one address, four instances on four) and every "lane = element" access of two instances then met in the same banks —
+// 33 % of the LDS-active cycles were conflicts. 176 / 180 / 184 (5024 / 5056 / 5088 B: the instances 160 / 192 / 224 B apart mod 256) all measure
+// 0.373 ms per 65536 ticks against 0.386.
+constexpr int XRN = 176;
 struct __attribute__((aligned(16))) XInst {
   double X[288];            // oMi [22][12] -> Ab [6][6][8]: base (+ eliminated limb DoF) columns of every task block -> J [16][XLD]
   double W[136];            // sin / cos [22][2] -> Ac [6][16] @0, g by DoF [32] @96 -> W~ [8][16] -> sweep / QP vectors: cl [32] @0, yv [32] @32 (yv | tv), xv @64, dv @80
   double in[28];            // q [27]
-  double R[188];            // ee_target [15] @0, prev_ee_target [15] @15, trunk inputs [18] @30, pf [16] @48, ow [16] @64, wt [96] @80
+  double R[XRN];             // ee_target [15] @0, prev_ee_target [15] @15, trunk inputs [18] @30, pf [16] @48, ow [16] @64, wt [96] @80
                             //   -> L [8][8] @0, 1 / L_jj [8] @64, L^-1 g_E [8] @72 -> T [XTC][XTLD]
 };
 static_assert(sizeof(XInst) * 4 <= 20480, "8 waves per CU");
-static_assert(sizeof(XInst) % 256 == 0, "instance blocks a multiple of the 256-byte bank row apart");
+static_assert(XRN >= 176, "R holds the staged inputs [176] and T [168] + L^-1 g_E [8]");
 struct XIntegrate { const double* in; const double* xv; };   // what integrate_ff reads
 
 #ifdef WBC_ABLATE   // timing cuts 301.. (tools/ablate_boxp.py): the kernel returns after stage k with garbage
