@@ -3536,7 +3536,7 @@ struct __attribute__((aligned(16))) PInst {
   double M2[PV * PLD];                      // ... sin / cos table in its tail during FK; then At [16][6], K / B scratch -> J
   double Cq[PN * 6];                        // reduced constraint rows x base columns (all the reduced rows touch the base only);
                                             // rows p_keep + l are the rows of G (eliminated leg DoF l x base DoF)
-  double pad_[16];
+  double pad_[8];
 };
 struct __attribute__((aligned(16))) PVec {
   double in[40];                            // q [27], gripper target [3] @28, previous [3] @31, trunk box centre [4] @34
@@ -3544,10 +3544,13 @@ struct __attribute__((aligned(16))) PVec {
   double cl[32];                            // row-bound staging -> Cholesky column broadcast (entries 12..31 zero) -> qdot by DoF
   double pad_[8];
 };
-// Bank placement (ds_read_b64 / b128 bank = dword address mod 64; instances r and r + 1 share a lane group): the matrices'
-// "lane = row" b128 reads interleave conflict-free when the instances sit a multiple of 256 B apart; the vectors are read as
-// broadcasts or "lane = element" b64, which collide at that distance and are conflict-free 128 B (mod 256) apart.
-static_assert(sizeof(PInst) % 256 == 0, "matrix blocks: a multiple of the 256-byte bank row apart");
+// Bank placement (ds_read_b64 / b128 bank = dword address mod 64; the four instances of a wave issue every access together): the vectors are read
+// as broadcasts or "lane = element" b64, which collide when the instances sit a multiple of the 256-byte bank row apart and are conflict-free
+// 128 B (mod 256) apart. The matrix blocks sat a multiple of 256 B apart in round 2 (measured best for the "lane = row" b128 reads then);
+// with the broadcast row reads the kernel has since (At / Cq rows in the H' accumulation, the violation scan and normal_d: all lanes of an
+// instance on one address, four instances on four) that distance made all four meet in one bank group — 192 B (mod 256) apart measures
+// +1.3 % on the benchmark (same-box A/B, four rounds: 330.1 vs 325.9 M ticks/s; 160 B apart +0.6 %).
+static_assert(sizeof(PInst) % 256 == 192, "matrix blocks: 192 B (mod the 256-byte bank row) apart");
 static_assert(sizeof(PVec) % 256 == 128, "vector blocks: half a bank row apart (mod 256 B)");
 struct __attribute__((aligned(16))) SmemP { PInst I[4]; PVec V[4]; };
 
