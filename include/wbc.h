@@ -331,8 +331,8 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          wbc_tick_boxp_kernel: the base and, where 16 lanes do not hold the rest, the limb DoF with the widest box are
  *                          eliminated by a Schur complement, the dual method works on <= 16 bounded unknowns, and an instance whose
  *                          optimum holds an eliminated DoF at its own velocity bound (or more than 12 active bounds) is redone by
- *                          its wave on the general path. At every batch size (28 vs 29 us at B = 1, 40 vs 46 us at 1024, 0.38 vs
- *                          1.23 ms at 65536); 0: never (general kernel).
+ *                          its wave on the general path. Working sets in / out: its WARM variant. At every batch size (28 vs 29 us at
+ *                          B = 1, 40 vs 46 us at 1024, 0.37 vs 1.23 ms at 65536); 0: never (general kernel).
  *   "posture_par"      [1] qpJointb "MANI" / "HYBRID" targets on the parallel posture kernel, wbc_posture_par_kernel: every finite-difference
  *                          point on a lane of its own (statistic "last_posture_par"); 0: the sequential whole-tree kernel (52 sweeps per instance).
  *   "packed_update"    [1] wbc_update_state / the roll-out's state update run four instances per wavefront where every model's

@@ -859,7 +859,7 @@ constexpr int WBC_BOXP_MIN_BATCH = 1;
 static bool boxp_eligible(const WbcBatch* b, const KernelArgs& a) {
   if (b->packed_box == 1 && a.B < WBC_BOXP_MIN_BATCH) return false;
   if (!b->packed_box || !b->packed_kernel || !b->presolve || b->n_models < 1 || b->jtj_mfma > 0 || b->prows != 0) return false;
-  if (a.ws_in || a.ws_out || a.in.q_con || a.in.posture_u || b->dbg_alias || (b->dbg_stop > 0 && b->dbg_stop < 300)) return false;   // (dbg_stop 301.. cuts this kernel)
+  if (a.in.q_con || a.in.posture_u || b->dbg_alias || (b->dbg_stop > 0 && b->dbg_stop < 300)) return false;   // (dbg_stop 301.. cuts this kernel; working sets: its WARM variant)
   for (int i = 0; i < b->n_models; ++i) if (!b->plan_host[i].x_ok) return false;
   return true;
 }

@@ -5502,6 +5502,9 @@ struct XIntegrate { const double* in; const double* xv; };   // what integrate_f
 #else
 #define XSTOP(k, val) do { } while (0)
 #endif
+// WARM: the variant that takes / returns working sets (KernelArgs.ws_in / ws_out, word 0: velocity bounds by DoF) — the packed sim3 kernel's scheme
+// (seeds through the add step, x / u rebuilt from the factors, restoration) on the kept variables; eliminated and locked DoF carry no seed.
+template <bool WARM>
 __global__ void __launch_bounds__(64, 2) wbc_tick_boxp_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                               const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   __shared__ union { XInst Q[4]; Smem G; } SU;
@@ -5530,7 +5533,11 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_boxp_kernel(const KernelArgs A
     const double e_t = (s < 15 && A.in.ee_target) ? A.in.ee_target[(size_t)b * 15 + s] : 0.0;
     const double e_p = (s < 15 && A.in.prev_ee_target) ? A.in.prev_ee_target[(size_t)b * 15 + s] : 0.0;
     I.in[s] = q0;
-    if (16 + s < 28) I.in[16 + s] = q1;
+    if (16 + s < (WARM ? 27 : 28)) I.in[16 + s] = q1;
+    if (WARM && s == 0) {                   // the carried working set's bound word, parked (as a bit pattern) in in[27]
+      const unsigned long long w = (A.ws_in && valid) ? A.ws_in[2 * (size_t)b] : 0ull;
+      I.in[27] = __longlong_as_double((long long)w);
+    }
     if (s < 15) { et[s] = e_t; ep[s] = e_p; }
     if (c_trunk) {
       auto tinv = [&](const int k) -> double {
@@ -6066,6 +6073,93 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_boxp_kernel(const KernelArgs A
       ++q;
     }
   };
+  if (WARM) {
+    const unsigned long long ws0 = (unsigned long long)__double_as_longlong(I.in[27]);
+    int sb = has_b ? (int)(((ws0 >> (kv.dof & 31)) & 1ull) | (((ws0 >> (32 + (kv.dof & 31))) & 1ull) << 1)) : 0;
+    if (sb == 3) sb = 0;
+    // a seed is taken only if the unconstrained minimiser x0 violates it or comes close to it (qp_core, solve_v3 `far`)
+    const double x0r = x;
+    const double near = 0.25 * fmax(1.0, -rmin16(has_b ? -fabs(x) : 0.0));
+    const double slb = (sb == 2) ? ub - x : x - lb;      // slack of the seeded side at x0
+    bool pend_b = live && has_b && ((sb == 1 && lb > -QP_INF) || (sb == 2 && ub < QP_INF)) && (slb <= near);
+    bool seeded = false;
+#pragma unroll 1
+    for (;;) {                              // one seed per row and pass, lowest index first
+      const unsigned mb = (unsigned)((__ballot(pend_b) >> rbase) & 0xFFFFull);
+      const bool seeding = mb != 0u;
+      if (!__ballot(seeding)) break;
+      const int idx = seeding ? __ffs((int)mb) - 1 : 0;
+      if (seeding && s == idx) pend_b = false;
+      const int c_side = (sb == 2) ? 256 : 0;
+      const int wc = (idx & 255) | bpermi(c_side, rbase + idx);
+      const int ip = wc & 255;
+      const double sgn = (wc >> 8) ? -1.0 : 1.0;
+      double d = sgn * J[(ip & 15) * XLD + s];
+      if (!has_b || !seeding) d = 0.0;
+      WSYNC();
+      dv[s] = d; yv[s] = (s >= q) ? d : 0.0;
+      WSYNC();
+      const double zn = rsum16(s >= q ? d * d : 0.0);
+      const Zr zr = products(__ballot(seeding && q > 0) != 0);
+      const bool add = seeding && (zn > 100.0 * nk * EPS2 * jf2) && q < XTC;      // (a dependent seed, or one more than T holds, is simply not taken)
+      if (__ballot(add)) {
+        add_step(add, zn, zr, wc, ip, 0.0);
+        if (add) { seeded = true; ++iters; }
+      }
+    }
+    // x, u from the factors: with s_j = b_j - n_j'x0 the slacks of the slots at x0:  w = T's,  x = x0 + J1 w,  u = T w
+    auto refresh = [&](const bool on) {
+      const int cc = a_code & 255;
+      const double sv_ = bperm(-slb, rbase + (cc & 15));     // (every lane takes part: ds_bpermute reads nothing from a lane that is switched off)
+      const double sj = (s < q) ? sv_ : 0.0;
+      WSYNC();
+      dv[s] = sj;
+      WSYNC();
+      double w = 0.0;
+#pragma unroll
+      for (int j = 0; j < XTC; ++j) w = fma(T[j * XTLD + sT], dv[j], w);        // column s of T (zero outside the slots)
+      WSYNC();
+      yv[s] = (s < q && s < XTC) ? w : 0.0;
+      WSYNC();
+      double xa = 0.0, ua = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; k += 2) { const double2a j2 = lds2(J + s * XLD + k), w2 = lds2(yv + k); xa = fma(j2.x, w2.x, fma(j2.y, w2.y, xa)); }
+#pragma unroll
+      for (int k = 0; k < XTC; k += 2) { const double2a t2 = lds2(T + sT * XTLD + k), w2 = lds2(yv + k); ua = fma(t2.x, w2.x, fma(t2.y, w2.y, ua)); }
+      if (on) { x = has_b ? x0r + xa : 0.0; u = (s < q) ? ua : 0.0; }
+    };
+    if (__ballot(seeded)) {
+      refresh(seeded);
+      // RESTORATION (as in the packed sim3 kernel): while a seeded multiplier is negative the most negative slot is dropped and the iterate moved to
+      // the minimiser on the remaining set; after any drop x, u are rebuilt once more from the factors
+      bool restoring = seeded, did = false, again = false;
+#pragma unroll 1
+      for (;;) {
+        const double um = rmin16((s < q) ? u : 0.0);
+        bool rest = restoring && (um < 0.0);
+        if (rest && ++iters > max_iter) { status = WBC_QP_MAX_ITER; rest = false; restoring = false; searching = false; }
+        if (!__ballot(rest)) {
+          if (!__ballot(restoring && did && !again)) break;
+          const bool on = restoring && did && !again;
+          refresh(on);
+          if (on) again = true;
+          continue;
+        }
+        const int l = rest ? __ffs((int)((__ballot(rest && s < q && u == um) >> rbase) & 0xFFFFull)) - 1 : 0;
+        const int lcode = bpermi(a_code, rbase + (l < 0 ? 0 : l));
+        drop_slot(rest, l < 0 ? 0 : l);
+        const int ip = lcode & 255;
+        double d = ((lcode >> 8) ? -1.0 : 1.0) * J[(ip & 15) * XLD + s];
+        if (!has_b || !rest) d = 0.0;
+        WSYNC();
+        dv[s] = d; yv[s] = (s >= q) ? d : 0.0;
+        WSYNC();
+        const Zr zr = products(__ballot(rest && q > 0) != 0);
+        if (rest) { x = fma(-um, zr.z, x); u = fma(um, zr.rv, u); did = true; }
+      }
+    }
+  }
+
 #pragma unroll 1
   for (;;) {
     // most violated inactive bound of each row
@@ -6170,6 +6264,14 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_boxp_kernel(const KernelArgs A
     flagged = ((fm >> rbase) & 0xFFFFull) != 0;
   }
   if (status != WBC_QP_OPTIMAL) { x = 0.0; xe = 0.0; }
+  if (WARM && A.ws_out) {   // the final working set in FULL-problem indexing (word 0: bounds by DoF); an unsolved QP carries nothing; a flagged instance's is the tail's
+    const int cc = a_code & 255, sd = (a_code >> 8) & 1;
+    const int dA = bpermi(kv.dof, rbase + (cc & 15));
+    unsigned long long w0 = 0ull;
+    if (status == WBC_QP_OPTIMAL && s < q) w0 = 1ull << (32 * sd + (dA & 31));
+    w0 = ror16(w0);
+    if (valid && !flagged && s == 0) { A.ws_out[2 * (size_t)b] = w0; A.ws_out[2 * (size_t)b + 1] = 0ull; }
+  }
   // ---- qdot by DoF through LDS, outputs
   WSYNC();
   cl[s] = 0.0; cl[16 + s] = 0.0;
@@ -6217,10 +6319,12 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_boxp_kernel(const KernelArgs A
 #pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
       if (!((tailm >> (16 * rr)) & 1ull)) continue;
-      tail_instance<false, false>(&SU.G, 4 * (int)blockIdx.x + rr, models, cfgs, plans);
+      tail_instance<WARM, false>(&SU.G, 4 * (int)blockIdx.x + rr, models, cfgs, plans);
     }
   }
 }
+template __global__ void wbc_tick_boxp_kernel<false>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
+template __global__ void wbc_tick_boxp_kernel<true>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
 
 static int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
@@ -6268,7 +6372,8 @@ int launch_tick_orthp(const KernelArgs& a, void* stream) {
 }
 int orthp_lds_bytes() { return (int)(4 * sizeof(QInst)); }
 int launch_tick_boxp(const KernelArgs& a, void* stream) {
-  hipLaunchKernelGGL(wbc_tick_boxp_kernel, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  if (a.ws_in || a.ws_out) hipLaunchKernelGGL(wbc_tick_boxp_kernel<true>, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  else hipLaunchKernelGGL(wbc_tick_boxp_kernel<false>, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   return check_launch("tick_boxp");
 }
 int sim3_lds_bytes() { return (int)sizeof(SmemC); }

@@ -710,13 +710,13 @@ def test_update_state_parity(wx200, px100, B):
 
 
 @pytest.mark.parametrize("cfg_name,K,with_imu", [("c3", 12, True), ("c3", 5, False), ("c3_hybrid", 6, True), ("everything", 6, True), ("c3_trunk_task", 8, True),
-                                                  ("c3_mani", 4, True), ("c2", 5, True)])
+                                                  ("c3_mani", 4, True), ("c2", 5, True), ("full", 5, True)])
 def test_rollout_parity(wx200, cfg_name, K, with_imu):
     """K closed-loop ticks on the device against the oracle's tick / update_state / state-advance loop:
     state, targets, worst status, iteration total and the gripper trace."""
     B = 192
     cfg = common.config(cfg_name, wx200)
-    d = common.tick_inputs(wx200, cfg, B, seed=37, with_rot=(cfg_name in ("everything", "c3_trunk_task")))
+    d = common.tick_inputs(wx200, cfg, B, seed=37, with_rot=(cfg_name in ("everything", "c3_trunk_task", "full")))
     rng = np.random.default_rng(2)
     step = np.zeros((B, 5, 3))
     step[:, 4] = rng.normal(0, 1e-4, (B, 3))
@@ -737,6 +737,8 @@ def test_rollout_parity(wx200, cfg_name, K, with_imu):
             assert bt.stat("last_update_packed") == 1               # ... and so does its state update (trunk reference state included)
         if cfg_name == "c2":
             assert bt.stat("last_update_packed") == 1               # (configs[1]: the state update is packed whatever kernel the tick ran on)
+        if cfg_name == "full":                                      # the warm-up problem: packed box kernel (its WARM variant when hot-started) + packed update
+            assert bt.stat("last_path") == 4 and bt.stat("last_update_packed") == 1, warm
         assert all((d[k] == before[k]).all() for k in d)            # in0 is only read
         assert (got["status"] == ref["status"]).all(), warm
         # one tick agrees to ~1e-6 in qdot (cond(H) ~ 3e9); K ticks of dt = 2 ms integrate that into ~1e-8 of state
@@ -1396,7 +1398,7 @@ def test_qp_entry_points_take_and_return_working_sets():
     bt.close()
 
 
-@pytest.mark.parametrize("cfg_name", ["c3", "everything", "c2"])
+@pytest.mark.parametrize("cfg_name", ["c3", "everything", "c2", "full"])
 def test_warm_started_tick_reaches_the_cold_optimum(wx200, px100, cfg_name):
     """SURVEY.md §8 f2 (QP_Wrapper.py:55-73, Robot_Wrapper4.py:1389-1394): a tick seeded with a working set — the previous
     tick's, its own, another kernel's, or garbage — returns the cold tick's q̇ and status (H > 0: one minimiser), and a good
@@ -1405,7 +1407,7 @@ def test_warm_started_tick_reaches_the_cold_optimum(wx200, px100, cfg_name):
     models = [wx200, px100]
     cfgs = [common.config(cfg_name, m) for m in models]
     mid = (np.arange(B) % 2).astype(np.int32)
-    parts = [common.tick_inputs(m, c, B, seed=91 + i, with_rot=(cfg_name == "everything")) for i, (m, c) in enumerate(zip(models, cfgs))]
+    parts = [common.tick_inputs(m, c, B, seed=91 + i, with_rot=(cfg_name in ("everything", "full"))) for i, (m, c) in enumerate(zip(models, cfgs))]
     d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
     d["model_id"] = mid
     ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
@@ -1457,6 +1459,21 @@ def test_warm_started_tick_reaches_the_cold_optimum(wx200, px100, cfg_name):
         its["general-path set into the compact kernel"] = back["iters"][ok].mean()
         same = (gen_cold["working_set"][ok] == cold["working_set"][ok]).all(axis=1).mean()
         assert same > 0.95, same                                           # both paths name the active constraints alike
+    if cfg_name == "full":
+        assert bt.stat("last_path") == 4                               # a working set was passed: the packed box kernel's WARM variant
+        bt.set_option("packed_box", 0)                                 # ... and the general kernel names the same bounds
+        gen = bt.tick(dict(d, working_set=cold["working_set"]), DT, want_working_set=True)
+        assert bt.stat("last_path") == 0
+        assert np.abs(gen["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL and (gen["status"] == ref["status"]).all()
+        gen_cold = bt.tick(d, DT, want_working_set=True)
+        bt.set_option("packed_box", 1)
+        back = bt.tick(dict(d, working_set=gen_cold["working_set"]), DT, want_working_set=True)
+        assert bt.stat("last_path") == 4 and np.abs(back["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+        its["general-path set into the box kernel"] = back["iters"][ok].mean()
+        # (the general path also names the DoF the box locks at 0 — equality bounds; the packed kernel leaves them out of its problem)
+        lock = np.where(mid == 0, (7 << 23) | (7 << (32 + 23)), (7 << 22) | (7 << (32 + 22)))
+        same = ((gen_cold["working_set"][ok][:, 0] & ~lock[ok]) == (cold["working_set"][ok][:, 0] & ~lock[ok])).mean()
+        assert same > 0.95, same
     print(cfg_name, "active inequalities per instance %.2f; working-set changes per tick:" % nact[ok].mean(),
           ", ".join("%s %.2f" % kv for kv in its.items()))
     assert its["own"] <= its["cold"] + 1e-9 and its["previous tick"] <= its["cold"] + 0.25
