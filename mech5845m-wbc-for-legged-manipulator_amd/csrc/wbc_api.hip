@@ -839,7 +839,7 @@ static bool sim3_eligible(const WbcBatch* b, const KernelArgs& a) {
   }
   return true;
 }
-// the packed orth kernel: every plan q_ok, nothing passed that it does not read (caller's posture target / constraint state, working sets),
+// the packed orth kernel: every plan q_ok, nothing passed that it does not read (caller's posture target / constraint state; working sets are accepted: no inequality to seed, an empty set out),
 // the orthonormal presolve on, no forced matrix-core contraction (the EE tasks' orientation references are honoured)
 // packed_orth: 1 (default) from WBC_ORTHP_MIN_BATCH instances on — below that a launch is a single round of waves and the one-instance
 // kernel's shorter dependent chain wins (measured on MI355X, tools/debug_orthp.py: 25 us vs 55 us at B = 1024, equal at 4096, 0.075 vs
@@ -848,7 +848,7 @@ constexpr int WBC_ORTHP_MIN_BATCH = 4608;
 static bool orthp_eligible(const WbcBatch* b, const KernelArgs& a) {
   if (b->packed_orth == 1 && a.B < WBC_ORTHP_MIN_BATCH) return false;
   if (!b->packed_orth || !b->packed_kernel || !b->presolve || !b->presolve_orth || b->n_models < 1 || b->jtj_mfma > 0) return false;
-  if (a.ws_in || a.ws_out || a.in.q_con || a.in.posture_u || b->dbg_alias || (b->dbg_stop > 0 && b->dbg_stop < 200)) return false;   // (dbg_stop 201.. cuts this kernel)
+  if (a.in.q_con || a.in.posture_u || b->dbg_alias || (b->dbg_stop > 0 && b->dbg_stop < 200)) return false;   // (dbg_stop 201.. cuts this kernel; working sets: nothing to seed, an empty set out)
   for (int i = 0; i < b->n_models; ++i) if (!b->plan_host[i].q_ok) return false;
   return true;
 }

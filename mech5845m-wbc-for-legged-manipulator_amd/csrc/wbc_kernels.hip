@@ -5427,6 +5427,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
       if (A.out.iters) A.out.iters[b] = nl;     // the eliminated equalities, so that `iters` keeps its meaning
     }
   }
+  // working sets (a hot-started tick / roll-out of these configurations stays on this kernel): the problem has no inequality, so a carried set
+  // seeds nothing and the set handed on is empty — as the general kernel reports it, tail instances included
+  if (A.ws_out && valid && s < 2) A.ws_out[2 * (size_t)b + s] = 0ull;
   if (A.out.q_next) {   // jointVelocitiestoConfig (Robot_Wrapper4.py:440-441)
     WSYNC();
     I.xv[s] = (s < 6) ? I.gp[s] * dt : 0.0;
