@@ -5474,7 +5474,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
 // and the dual active-set method of the packed sim3 kernel (same lambdas, no general rows) solves  min 1/2 x_K'H'x_K + g'x_K, lb <= x_K <= ub
 // on n' <= 16 bounded unknowns; DoF the box locks at 0 are left out. The dual iterates of the full problem ARE those of the reduced one
 // (the eliminated unknowns are unconstrained minimisers at every step), so the working-set sequence and the iteration count are the
-// oracle's; cond(H') ~ 1e3 where cond(H) ~ 1e9 (tests: 1e-12 against the oracle). The eliminated DoF's own velocity bounds are checked at the
+// oracle's; cond(H') <= cond(H), typically far below it (tests: 1e-12 against the oracle). The eliminated DoF's own velocity bounds are checked at the
 // end: an instance that violates one (or needs more than XTC = 12 active bounds) is redone by its own wave on the general path (the tail).
 // lane = 16 r + s: instance r; s = FK slot / DoF column s and 16 + s in the kinematics and task stage, eliminated slot s (< 8) and kept variable s
 // from the Schur stage on. Stages: FK and columns as in the packed orth kernel; every task block's base columns -> Ab [task][row][8], the limb
@@ -5976,7 +5976,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_boxp_kernel(const KernelArgs A
   bool act_b = false, overflow = false;
   double u = 0.0;
   int a_code = 0, q = 0, iters = 0;
-  const int max_iter = 10 * nk + 20;
+  const int max_iter = 10 * nv + 20;        // (the full problem's cap: n = nv unknowns, no rows — the oracle's count includes the locked DoF this kernel leaves out)
   bool searching = live;
   const int sT = s < XTC ? s : XTC - 1;      // (lanes beyond T's rows shadow its last row; they never write)
   // drop slot l of the rows `dr`: Givens sequence read off the removed row of T (rare path)

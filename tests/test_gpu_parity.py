@@ -987,7 +987,7 @@ def test_packed_box_kernel_variants_and_non_finite_inputs(wx200, px100, variant)
     err = np.abs(got["qdot"] - ref["qdot"])[ok].max()
     print("packed box kernel, %s, mixed batch: qdot max-abs err %.3e, working-set changes %.2f (oracle %.2f)" % (
         variant, err, got["iters"][ok].mean(), ref["iters"][ok].mean()))
-    assert err < (1e-8 if nd == 0 else QDOT_TOL) and np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-8    # (cond(H') ~ 1e3: far inside QDOT_TOL)
+    assert err < (1e-8 if nd == 0 else QDOT_TOL) and np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-8    # (the Schur complement conditions the problem: far inside QDOT_TOL)
     assert (got["iters"] == ref["iters"])[ok & (mid == 0)].mean() > 0.99
     assert (got["iters"] + 1 == ref["iters"])[ok & (mid == 1)].mean() > 0.99   # (the oracle also counts px100's padded 26th DoF, a locked bound)
     bt.set_option("packed_box", 0)
@@ -1103,7 +1103,7 @@ def test_gpu_solution_against_the_exact_optimum(wx200, px100, cfg_name, with_rot
         assert (3, 1) in paths                            # the packed orth kernel
     if cfg_name == "full":
         assert {(4, 0), (0, 0)} <= paths                  # the packed box kernel, full size
-        assert worst[((1, 1, 1, 1), (4, 0))] < 1e-9      # cond(H') ~ 1e3 after the Schur complement: the packed path is the MOST accurate one
+        assert worst[((1, 1, 1, 1), (4, 0))] < 1e-9      # the Schur complement conditions the problem: the packed path is the MOST accurate one
     bt.close()
 
 

@@ -428,3 +428,77 @@ def test_packed_orth_kernel_formulation_restated_in_numpy():
             y = -(Y[:n] @ z)                        # row s of L^-T against it
             qd = Z @ y
             assert np.abs(qd - ref["qdot"][b][:nv]).max() < 1e-6, np.abs(qd - ref["qdot"][b][:nv]).max()
+
+
+def test_packed_box_kernel_formulation_restated_in_numpy():
+    """What wbc_tick_boxp_kernel computes for the warm-up problem, in numpy from the oracle's A, b and velocity box: the block-arrow
+    structure it relies on (a limb DoF meets another limb only through the base), the eliminated set E = base (+ the DoF with the widest box where 16
+    lanes do not hold the rest), the cooperative Cholesky of H_EE with the forward substitutions of W~ = L^-1 H_EK and L^-1 g_E riding on it,
+    H' = (limb blocks of H_KK) - W~'W~, g' = g_K - W~'(L^-1 g_E), the dual active-set method on <= 16 bounded unknowns, x_E = -L^-T(L^-1 g_E + W~ x_K)
+    and the check of the eliminated DoF's own bounds. Same answer AND the same working-set changes as the oracle's solve of the full 26-unknown problem
+    (the reduced problem's dual iterates are the full problem's)."""
+    wx, px = common.models()
+    for model, cfg_kw in ((wx, dict(Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=True)),
+                          (px, dict(Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=True)),
+                          (wx, dict(FR=True, RL=True, Grip=True, Joint="PREV"))):
+        import wbc_model
+        cfg = wbc_model.make_config(model, **cfg_kw)
+        B = 24
+        d = common.tick_inputs(model, cfg, B, seed=19, with_rot=True)
+        qp = oracle.assemble([model], [cfg], d, DT, B)
+        ref = oracle.tick([model], [cfg], d, DT, B)
+        nv = model.nv
+        assert qp["C"].shape[1] == 0
+        lock = [k for k in range(6, nv) if k >= cfg.lock_from]
+        free = [k for k in range(6, nv) if k not in lock]
+        # the plan's choice of the extra eliminated DoF: widest box = position range x velocity limit of the damper entry the DoF looks at
+        extra = sorted(free, key=lambda k: (-(cfg.damper_hi[k] - cfg.damper_lo[k]) * cfg.damper_vmax[k], k))[:max(0, len(free) - 16)]
+        E = list(range(6)) + extra
+        K = [k for k in free if k not in extra]
+        assert len(K) <= 16 and len(E) <= 8
+        worst, conds = 0.0, []
+        for b in range(B):
+            if ref["status"][b] != 0:
+                continue
+            H, g, lb, ub = qp["H"][b][:nv, :nv], qp["g"][b][:nv], qp["lb"][b][:nv], qp["ub"][b][:nv]
+            assert (lb[lock] == 0).all() and (ub[lock] == 0).all()
+            # block-arrow: two kept DoF are coupled only inside a limb (here: |H_KK| vanishes between different task supports)
+            A = qp["A"][b][:, :nv]
+            mcart = A.shape[0] - 26
+            sup = [frozenset(np.nonzero(np.abs(A[:mcart, k]) > 0)[0] // 6) for k in K]
+            for i, ki in enumerate(K):
+                for j, kj in enumerate(K):
+                    if i != j and not (sup[i] & sup[j]):
+                        assert H[ki, kj] == 0.0
+            HEE, HEK, HKK = H[np.ix_(E, E)], H[np.ix_(E, K)], H[np.ix_(K, K)]
+            ne = len(E)
+            # cooperative Cholesky; step j's row of L also finishes entry j of W~ and of L^-1 g_E
+            L = HEE.copy(); rinv = np.zeros(ne); Wt = HEK.copy(); gt = g[E].copy()
+            for j in range(ne):
+                v = L[j, j] - L[j, :j] @ L[j, :j]
+                assert v > 0
+                rinv[j] = 1.0 / np.sqrt(v)
+                L[j, j] = v * rinv[j]
+                for r in range(j + 1, ne):
+                    L[r, j] = (L[r, j] - L[r, :j] @ L[j, :j]) * rinv[j]
+                Wt[j] = (Wt[j] - L[j, :j] @ Wt[:j]) * rinv[j]
+                gt[j] = (gt[j] - L[j, :j] @ gt[:j]) * rinv[j]
+            L = np.tril(L)
+            assert np.abs(L @ L.T - HEE).max() < 1e-9 * np.abs(HEE).max()
+            Hp = HKK - Wt.T @ Wt
+            gp = g[K] - Wt.T @ gt
+            conds.append(np.linalg.cond(Hp) / np.linalg.cond(H))
+            xK, st, it = gi_variant.solve(Hp, gp, lb=lb[K], ub=ub[K])[:3]
+            assert st == 0
+            xE = -np.linalg.solve(L.T, gt + Wt @ xK)
+            x = np.zeros(26)
+            x[K], x[E] = xK, xE
+            # the eliminated DoF's own bounds hold (else the kernel hands the instance to the general path)
+            held = ((xE < lb[E] - 1e-9 * np.maximum(1, np.abs(lb[E]))) | (xE > ub[E] + 1e-9 * np.maximum(1, np.abs(ub[E])))).any()
+            if held:
+                continue
+            worst = max(worst, np.abs(x - ref["qdot"][b]).max())
+            assert it + len(lock) + (26 - nv) == ref["iters"][b]      # (the oracle also counts the padded DoF of the smaller model as a locked bound)
+        assert worst < 1e-9, worst
+        print("%s %s: worst |x - oracle| %.2e, cond(H') / cond(H) median %.1e" % (model.name, sorted(cfg_kw), worst, float(np.median(conds))))
+        assert np.median(conds) < 1.0          # (never worse; 1e-3 on a typical wx200 warm-up instance: the locked DoF and the base leave the problem)
