@@ -333,7 +333,6 @@ int orc_constraint_rows(const WbcConfig* c) {
   return p;
 }
 
-static const double* opt_row(const double* base, int b, int k) { return base ? base + (size_t)b * k : 0; }
 
 /* One instance of the task stack and constraints. Outputs (any may be NULL):
  * A [m][NV], bv [m], C [p][NV], Clb/Cub [p], lb/ub [NV], H [NV][NV], g [NV].
@@ -876,10 +875,6 @@ void orc_update_state_batch(const WbcModelBlob* const* models, int B, const doub
 }
 
 /* ---------------------------------------------------------------- batched drivers (OpenMP) */
-
-static const WbcModelBlob* pick(const WbcModelBlob* const* models, const WbcTickIn* in, int b) {
-  return models[in->model_id ? in->model_id[b] : 0];
-}
 
 /* one runWBC tick per instance: assemble -> QP -> integrate (Robot_Wrapper4.py:1348-1397). cfgs[model]. */
 void orc_tick_batch(const WbcModelBlob* const* models, const WbcConfig* cfgs, int B, const WbcTickIn* in, double dt,
