@@ -786,14 +786,14 @@ def test_rollout_equals_tick_plus_update_state(wx200):
     bt.close()
 
 
-@pytest.mark.parametrize("cfg_name", ["c3", "c2"])
+@pytest.mark.parametrize("cfg_name", ["c3", "c2", "full"])
 def test_full_size_properties(wx200, cfg_name):
-    """BASELINE's full single-GPU size (B = 65536; config 3 on the packed kernel, config 2's switch set on the general kernel with
-    the orthonormal contact presolve): size-independent certificates on every instance (contact rows satisfied, bounds and box rows
-    respected) + oracle parity on a random subsample."""
+    """BASELINE's full single-GPU size (B = 65536; config 3 on the packed kernel, config 2's switch set on the packed orth kernel, the warm-up
+    problem on the packed box kernel): size-independent certificates on every instance (contact rows satisfied, bounds and box rows
+    respected; the warm-up problem: the KKT conditions of its bound-constrained QP from the device's own H and g) + oracle parity on a random subsample."""
     B = 65536
     cfg = common.config(cfg_name, wx200)
-    d = common.tick_inputs(wx200, cfg, B, seed=41)
+    d = common.tick_inputs(wx200, cfg, B, seed=41, with_rot=(cfg_name == "full"))
     bt = WbcBatch(wx200, B)
     bt.configure(cfg)
     got = bt.tick(d, DT)
@@ -804,9 +804,21 @@ def test_full_size_properties(wx200, cfg_name):
     Cx = np.einsum("bpn,bn->bp", a["C"], x)
     scale = 1 + np.abs(x).max(axis=1, keepdims=True)
     c0 = 4 if cfg_name == "c3" else 0                                            # (config 2 has no trunk box in front of the contact rows)
-    assert (np.abs(Cx[:, c0:])[ok] / scale[ok]).max() < 1e-8                     # 12 contact equalities
-    assert bt.stat("last_path") == (2 if cfg_name == "c3" else 3) and bt.stat("last_orth") == (0 if cfg_name == "c3" else 1)
-    assert ((a["Clb"] - Cx)[ok] / scale[ok]).max() < 1e-8 and ((Cx - a["Cub"])[ok] / scale[ok]).max() < 1e-8
+    if cfg_name != "full":
+        assert (np.abs(Cx[:, c0:])[ok] / scale[ok]).max() < 1e-8                 # 12 contact equalities
+    assert bt.stat("last_path") == {"c3": 2, "c2": 3, "full": 4}[cfg_name] and bt.stat("last_orth") == (1 if cfg_name == "c2" else 0)
+    if cfg_name == "full":
+        # stationarity of the bound-constrained QP on every instance: r = H x + g vanishes on the free DoF, points inwards on the held ones
+        assert a["C"].shape[1] == 0 and bt.stat("deferred_last") == 0
+        hg = bt.assemble(d, DT, want=("H", "g"))
+        r = np.einsum("bij,bj->bi", hg["H"], x) + hg["g"]
+        at_lb = np.abs(x - a["lb"]) <= 1e-9 * np.maximum(1, np.abs(a["lb"]))
+        at_ub = np.abs(x - a["ub"]) <= 1e-9 * np.maximum(1, np.abs(a["ub"]))
+        rs = np.abs(hg["H"]).max(axis=(1, 2))[:, None] * scale
+        assert (np.abs(r)[~(at_lb | at_ub) & ok[:, None]] / np.broadcast_to(rs, r.shape)[~(at_lb | at_ub) & ok[:, None]]).max() < 1e-9
+        assert ((-r / rs)[at_lb & ~at_ub & ok[:, None]]).max() < 1e-9 and ((r / rs)[at_ub & ~at_lb & ok[:, None]]).max() < 1e-9
+    if a["C"].shape[1]:
+        assert ((a["Clb"] - Cx)[ok] / scale[ok]).max() < 1e-8 and ((Cx - a["Cub"])[ok] / scale[ok]).max() < 1e-8
     assert ((a["lb"] - x)[ok]).max() < 1e-8 and ((x - a["ub"])[ok]).max() < 1e-8
     rng = np.random.default_rng(0)
     idx = rng.choice(B, 1024, replace=False)
