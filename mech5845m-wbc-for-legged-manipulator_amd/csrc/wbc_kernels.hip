@@ -5221,9 +5221,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
   QSTOP(4, Zm[s * 6 + 1] + lin0[0] + lin1[1] + jc0[2] + jc1[0]);
   // ---- the task stack, one block of six rows at a time
   const int hh = s >> 3, cc = s & 7;         // A Z: lane (hh, cc < 6) forms rows 3 hh .. 3 hh + 2 of the block for base-reduced variable cc
-  double Zc[18];
-#pragma unroll
-  for (int j = 0; j < 18; ++j) Zc[j] = (cc < 6) ? Zm[j * 6 + cc] : 0.0;
+  // (column cc of Z is re-read from LDS inside each block: kept in 36 registers across the task loop it pushed the row of H' out to scratch —
+  //  33 spill instructions per wave, 1.3 % of the step)
+  const double* const Zcol = Zm + (cc < 6 ? cc : 0);
+#define ZCJ(j) Zcol[(j) * 6]
   double h[16], gacc = 0.0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) h[k] = 0.0;
@@ -5250,10 +5251,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
         double acc = 0.0;
         if (dense) {
 #pragma unroll
-          for (int j = 0; j < 18; j += 2) { const double2a v = lds2(row + j); acc = fma(v.x, Zc[j], fma(v.y, Zc[j + 1], acc)); }
+          for (int j = 0; j < 18; j += 2) { const double2a v = lds2(row + j); acc = fma(v.x, ZCJ(j), fma(v.y, ZCJ(j + 1), acc)); }
         } else {
 #pragma unroll
-          for (int j = 0; j < 6; j += 2) { const double2a v = lds2(row + j); acc = fma(v.x, Zc[j], fma(v.y, Zc[j + 1], acc)); }
+          for (int j = 0; j < 6; j += 2) { const double2a v = lds2(row + j); acc = fma(v.x, ZCJ(j), fma(v.y, ZCJ(j + 1), acc)); }
           acc = fma(row[jl], zw[0], fma(row[jl + 1], zw[1], fma(row[jl + 2], zw[2], acc)));
         }
         AZ[(3 * hh + rr) * 16 + cc] = acc;
@@ -5331,7 +5332,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     WSYNC();
     if (s < 6) {
 #pragma unroll
-      for (int j = 0; j < 18; ++j) gacc = fma(Zc[j], I.gp[P.q_bl2dof[j] & 31], gacc);
+      for (int j = 0; j < 18; ++j) gacc = fma(ZCJ(j), I.gp[P.q_bl2dof[j] & 31], gacc);
     } else if (s < n) gacc += I.gp[P.q_red2dof[s] & 31];
   }
 #pragma unroll
