@@ -333,8 +333,10 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          optimum holds an eliminated DoF at its own velocity bound (or more than 12 active bounds) is redone by
  *                          its wave on the general path. Working sets in / out: its WARM variant. At every batch size (28 vs 29 us at
  *                          B = 1, 40 vs 46 us at 1024, 0.37 vs 1.23 ms at 65536); 0: never (general kernel).
- *   "posture_par"      [1] qpJointb "MANI" / "HYBRID" targets on the parallel posture kernel, wbc_posture_par_kernel: every finite-difference
- *                          point on a lane of its own (statistic "last_posture_par"); 0: the sequential whole-tree kernel (52 sweeps per instance).
+ *   "posture_par"      [1] qpJointb "MANI" / "HYBRID" targets on the parallel posture kernels: every sweep on a lane of its own (both sides of
+ *                          the central difference one after the other), three instances per wavefront, where no model has more than 21
+ *                          sweeps (statistic "last_posture_par" = 2), else every finite-difference point on a lane of its own, one instance
+ *                          per wavefront (= 1; value 3 forces this form); 0: the sequential whole-tree kernel (52 sweeps per instance).
  *   "packed_update"    [1] wbc_update_state / the roll-out's state update run four instances per wavefront where every model's
  *                          configuration is of the packed kernel's family (statistic "last_update_packed"); 0: one per wavefront.
  *   "presolve_tol_exp" [7] a stance-leg 3 x 3 block K with |det K| <= 10^-value (sum |K_ij|)^3 is treated as rank deficient: the
@@ -365,8 +367,8 @@ int wbc_batch_set_option(WbcBatch* b, const char* name, int value);
 /* Read-only statistics of a handle: "last_path" (kernel the last tick ran on: 0 general, 1 compact sim3 + second pass, 2 packed
  * compact sim3 — four instances per wavefront, one kernel —, 3 packed orth kernel, 4 packed box kernel), "last_orth" (1: that tick ran with the
  * orthonormal contact presolve, option "presolve_orth": the general kernel's ORTH variant or the packed orth kernel),
- * "last_update_packed" (1: the last state update ran on the packed kernel), "last_posture_par" (1: the last MANI / HYBRID posture target
- * ran on the parallel posture kernel), "deferred_last" (instances the last tick's kernel could not reduce itself: redone in the packed kernels'
+ * "last_update_packed" (1: the last state update ran on the packed kernel), "last_posture_par" (1 / 2: the last MANI / HYBRID posture target
+ * ran on the parallel posture kernel, one / three instances per wavefront), "deferred_last" (instances the last tick's kernel could not reduce itself: redone in the packed kernels'
  * tail or left to the one-instance kernel's second pass; waits for `stream`), "pivoted_last" (instances that took the pivoted
  * elimination, with option "count_pivoted"), "sim3_lds_bytes" / "tick_lds_bytes" / "orthp_lds_bytes" (LDS per workgroup of the tick kernels). */
 int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, int64_t* out);

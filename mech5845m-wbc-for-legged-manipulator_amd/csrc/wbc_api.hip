@@ -770,8 +770,10 @@ static int run_posture(WbcBatch* b, int B, const double* q, const int32_t* model
   pa.models = b->d_models; pa.cfgs = b->d_cfgs; pa.plans = b->d_plans; pa.B = B; pa.n_models = b->n_models; pa.q = q; pa.model_id = model_id; pa.u = u; pa.q_after = q_after;
   bool par = b->posture_par != 0;
   for (int i = 0; i < b->n_models && par; ++i) par = b->configured[i] && b->plan_host[i].mp_ok != 0;
-  b->last_posture_par = par;
-  if (int e = par ? launch_posture_par(pa, B, stream) : launch_posture(pa, B, stream)) return fail(WBC_E_HIP, "posture kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  bool three = par && b->posture_par != 3;                 // three instances per wavefront where every model has at most 21 sweeps (option value 3: one per wavefront)
+  for (int i = 0; i < b->n_models && three; ++i) three = b->plan_host[i].mp_n <= 21;
+  b->last_posture_par = par ? (three ? 2 : 1) : 0;
+  if (int e = par ? launch_posture_par(pa, B, stream, three) : launch_posture(pa, B, stream)) return fail(WBC_E_HIP, "posture kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return WBC_OK;
 }
 static int auto_posture(WbcBatch* b, KernelArgs& a, int B, void* stream) {

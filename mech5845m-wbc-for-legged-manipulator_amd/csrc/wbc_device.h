@@ -191,7 +191,7 @@ int sim3_lds_bytes();
 int launch_qp(const QpArgs& a, int grid, void* stream);
 int launch_integrate(const IntegrateArgs& a, int grid, void* stream);
 int launch_posture(const PostureArgs& a, int grid, void* stream);
-int launch_posture_par(const PostureArgs& a, int grid, void* stream);   // every finite-difference point on its own lane (DevPlan.mp_ok)
+int launch_posture_par(const PostureArgs& a, int grid, void* stream, int three);   // every finite-difference point on its own lane (DevPlan.mp_ok)
 int launch_update(const UpdateArgs& a, int grid, void* stream);
 int launch_update_packed(const UpdateArgs& a, void* stream);   // four instances per wavefront (every plan pk_update_ok)
 int tick_lds_bytes();

@@ -3375,6 +3375,188 @@ __global__ void __launch_bounds__(64) wbc_posture_par_kernel(const PostureArgs A
   }
 }
 
+// THREE instances per wavefront where no model of the batch has more than 21 sweeps (A1 + wx200 / px100 "MANI": 21 / 20): instance r = lane / 21,
+// sweep k = lane % 21, and the lane evaluates BOTH sides of its central difference one after the other — 63 of 64 lanes busy where the kernel above
+// keeps 42; the same arithmetic per evaluation (bit-identical u). Roles with more than 21 entries (configuration, sin / cos table, outputs) take
+// two or three rounds of the instance's 21 lanes.
+__global__ void __launch_bounds__(64) wbc_posture_par3_kernel(const PostureArgs A, const DevModel* __restrict__ models,
+                                                              const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
+  __shared__ MPSmem S3[3];
+  const int lane0 = threadIdx.x;
+  const bool grp = lane0 < 63;                             // (lane 63: no instance; it shadows instance 2's last lane and stores nothing)
+  const int r = grp ? lane0 / 21 : 2, lane = grp ? lane0 - 21 * r : 20;
+  MPSmem& S = S3[r];
+  const int b_raw = 3 * (int)blockIdx.x + r;
+  const bool valid = grp && b_raw < A.B;
+  const int b = b_raw < A.B ? b_raw : A.B - 1;
+  int mid = 0;
+  if (A.model_id) { mid = A.model_id[b]; mid = mid < 0 ? 0 : (mid >= A.n_models ? A.n_models - 1 : mid); }
+  const DevModel& M = models[mid];
+  const DevPlan& P = plans[mid];
+  const int nv = M.nv, nq = M.nq, nj = M.njoints;
+  const double dq = 0.0002;
+  if (grp) {
+    S.q[lane] = (lane < nq) ? A.q[(size_t)b * NQ + lane] : 0.0;
+    if (lane + 21 < 32) S.q[lane + 21] = (lane + 21 < nq) ? A.q[(size_t)b * NQ + lane + 21] : 0.0;
+  }
+  // this lane's sweep
+  const int k = lane;
+  const bool on = grp && k < P.mp_n;
+  const int kk = on ? k : 0;
+  const int my_i = P.mp_i[kk], my_qi = P.mp_qi[kk];
+  const unsigned my_prev = P.mp_prev[kk];
+  int chain[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) chain[c] = on ? P.mp_chain[kk][c] : -1;
+  WSYNC();
+  // sin / cos table: entry t < 3 (nj - 2): joint 2 + t / 3 in state t % 3; three rounds of 21 lanes
+#pragma unroll 1
+  for (int i = 0; i < 3; ++i) {
+    const int tt = lane + 21 * i;
+    const int j = 2 + tt / 3, st = tt - 3 * (tt / 3);
+    if (grp && j < nj) {
+      const int jt = M.jtype[j];
+      if (jt >= WBC_JT_RX && jt <= WBC_JT_RZ) {
+        const double a0 = S.q[M.idx_q[j]];
+        const double a = (st == 0) ? a0 : ((st == 1) ? a0 + dq : (a0 + dq) - (dq * 2));
+        const SinCos tsc = sincos_cw(a);
+        S.sc[6 * j + 2 * st] = tsc.s; S.sc[6 * j + 2 * st + 1] = tsc.c;
+      }
+    }
+  }
+  WSYNC();
+  double f1 = 0.0, f2 = 0.0;
+#pragma unroll 1
+  for (int side = 0; side < 2; ++side) {
+  // state of configuration entry e for this lane: 0 = q, 1 = q + d, 2 = (q + d) - 2 d
+  auto state_of = [&](const int e) -> int { return (e == my_qi) ? (side ? 2 : 1) : (((my_prev >> e) & 1u) ? 2 : 0); };
+  auto value_of = [&](const int e) -> double {
+    const double a0 = S.q[e];
+    const int st = state_of(e);
+    return (st == 0) ? a0 : ((st == 1) ? a0 + dq : (a0 + dq) - (dq * 2));
+  };
+  double f = 0.0;
+  {
+    // the free-flyer: R from the (possibly perturbed, not renormalised) quaternion exactly as the FK does, p = xyz
+    const double qq[4] = {value_of(3), value_of(4), value_of(5), value_of(6)};
+    double R1[9];
+    quat_to_R(qq, R1);                                  // row-major
+    double G[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) G[i] = 0.0;
+    auto add_col = [&](const double* c) {               // G += c c' (upper triangle, row-major packed)
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int bb = a; bb < 6; ++bb) { G[t] = fma(c[a], c[bb], G[t]); ++t; }
+    };
+    // ONE walk down the chain with the columns expressed at the BASE origin ((p - p_base) x axis, axis): the reference's LOCAL_WORLD_ALIGNED
+    // Jacobian at the joint's origin pJ is X J_base with X = [I, -[pJ - p_base]x; 0, I], det X = 1, so det(J J') — all that f is — does not
+    // depend on where the columns are expressed, and the joint's origin need not be known before the columns are formed (the first version
+    // walked the chain twice for it). Origins relative to the base: the base position drops out of the arithmetic altogether, so its three
+    // sweeps give f1 == f2 bit for bit and u = 0 exactly, as the reference's (and the sequential kernel's) LOCAL_WORLD_ALIGNED form does.
+    {
+      double X[3] = {R1[0], R1[3], R1[6]}, Y[3] = {R1[1], R1[4], R1[7]}, Z[3] = {R1[2], R1[5], R1[8]};   // columns of the parent's rotation
+      double p[3] = {0.0, 0.0, 0.0};                    // origins relative to the base
+      // free-flyer columns at its own origin: linear DoF (R e_i, 0), angular DoF (0, R e_i)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double* ax = (i == 0) ? X : ((i == 1) ? Y : Z);
+        const double cl[6] = {ax[0], ax[1], ax[2], 0.0, 0.0, 0.0};
+        add_col(cl);
+        const double ca[6] = {0.0, 0.0, 0.0, ax[0], ax[1], ax[2]};
+        add_col(ca);
+      }
+#pragma unroll 1
+      for (int c = 0; c < 8; ++c) {
+        const int j = chain[c];
+        if (j < 0) continue;
+        const int a = M.ax0[j], jt = M.jtype[j];
+        const bool rev = jt >= WBC_JT_RX && jt <= WBC_JT_RZ;
+        const double t0 = M.tp[j][0], t1 = M.tp[j][1], t2 = M.tp[j][2];
+        const int qe = M.idx_q[j];
+        const int st = state_of(qe);
+        const double sn = rev ? S.sc[6 * j + 2 * st] : 0.0, cs = rev ? S.sc[6 * j + 2 * st + 1] : 1.0;
+        const double pris = rev ? 0.0 : value_of(qe);
+        double Av[3], Bv[3], Cv[3];                     // the axis column of the parent's rotation and its cyclic successors
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          Av[rr] = (a == 0) ? X[rr] : ((a == 1) ? Y[rr] : Z[rr]);
+          Bv[rr] = (a == 0) ? Y[rr] : ((a == 1) ? Z[rr] : X[rr]);
+          Cv[rr] = (a == 0) ? Z[rr] : ((a == 1) ? X[rr] : Y[rr]);
+        }
+        double nB[3], nC[3];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          nB[rr] = cs * Bv[rr] + sn * Cv[rr];
+          nC[rr] = cs * Cv[rr] - sn * Bv[rr];
+          p[rr] = p[rr] + Av[rr] * (t0 + pris) + Bv[rr] * t1 + Cv[rr] * t2;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          const double na = Av[rr], nb = nB[rr], nc = nC[rr];
+          X[rr] = (a == 0) ? na : ((a == 1) ? nc : nb);
+          Y[rr] = (a == 0) ? nb : ((a == 1) ? na : nc);
+          Z[rr] = (a == 0) ? nc : ((a == 1) ? nb : na);
+        }
+        double col[6];                                  // this joint's column: revolute (p x axis, axis), prismatic (axis, 0)
+        if (rev) {
+          double cr[3];
+          cross3(p, Av, cr);
+          col[0] = cr[0]; col[1] = cr[1]; col[2] = cr[2]; col[3] = Av[0]; col[4] = Av[1]; col[5] = Av[2];
+        } else { col[0] = Av[0]; col[1] = Av[1]; col[2] = Av[2]; col[3] = 0.0; col[4] = 0.0; col[5] = 0.0; }
+        add_col(col);
+      }
+    }
+    // det of the symmetric positive semi-definite G by elimination without pivoting (det6_spd, on the packed upper triangle)
+    double m[6][6];
+    {
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int bb = a; bb < 6; ++bb) { m[a][bb] = G[t]; m[bb][a] = G[t]; ++t; }
+    }
+    double det = 1.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double piv = m[c][c];
+      det *= piv;
+      const double ip = (piv > 0.0) ? 1.0 / piv : 0.0;
+#pragma unroll
+      for (int rr = c + 1; rr < 6; ++rr) {
+        const double ff = m[rr][c] * ip;
+#pragma unroll
+        for (int kx = c + 1; kx < 6; ++kx) m[rr][kx] = fma(-ff, m[c][kx], m[rr][kx]);
+      }
+    }
+    f = sqrt(det > 0.0 ? det : 0.0);
+  }
+  if (side == 0) f1 = f; else f2 = f;
+  }
+  // u by DoF: the sweep's central difference, the PREV value where the loop skips the DoF (HYBRID), else 0
+  if (grp) { S.uo[lane] = 0.0; if (lane + 21 < 32) S.uo[lane + 21] = 0.0; S.f[lane] = 0.0; S.f[lane + 21] = 0.0; }
+  WSYNC();
+  if (on) { S.uo[my_i & 31] = 0.5 * (f1 - f2) / dq; S.f[my_i & 31] = 1.0; }      // (f [32]: flags "DoF swept" here)
+  WSYNC();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int d = lane + 21 * i;
+    if (!grp || d >= NQ) continue;
+    if (d < NV) {
+      double u = 0.0;
+      if (d < nv && ((P.mp_prevmode >> d) & 1u)) u = S.q[d < 6 ? d : d + 1];
+      if (d < nv && S.f[d & 31] != 0.0) u = S.uo[d & 31];
+      if (A.u && valid) A.u[(size_t)b * NV + d] = (d < nv) ? u : 0.0;
+    }
+    if (A.q_after && valid) {
+      const double a0 = S.q[d & 31];
+      A.q_after[(size_t)b * NQ + d] = (d < nq) ? (((P.mp_all >> d) & 1u) ? (a0 + dq) - (dq * 2) : a0) : 0.0;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The tail of runWBC: updateState(joint_config, base_config, running=True) (Robot_Wrapper4.py:1397-1399, 387-428) with
 // trunkWorldPos (:1297-1327). One instance per wave. In a rollout the same wave then applies the side effects qpb() has on
@@ -6402,8 +6584,9 @@ int launch_posture(const PostureArgs& a, int grid, void* stream) {
   hipLaunchKernelGGL(wbc_posture_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs);
   return check_launch("posture");
 }
-int launch_posture_par(const PostureArgs& a, int grid, void* stream) {
-  hipLaunchKernelGGL(wbc_posture_par_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+int launch_posture_par(const PostureArgs& a, int grid, void* stream, int three) {
+  if (three) hipLaunchKernelGGL(wbc_posture_par3_kernel, dim3((a.B + 2) / 3), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  else hipLaunchKernelGGL(wbc_posture_par_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   return check_launch("posture_par");
 }
 int launch_update(const UpdateArgs& a, int grid, void* stream) {

@@ -168,10 +168,15 @@ def test_posture_target_parity(wx200, px100, mode, literal):
     for i, c in enumerate(cfgs):
         bt.configure(c, i)
     u, qa = bt.posture_target(q, mid)
-    assert bt.stat("last_posture_par") == 1       # every finite-difference point on a lane of its own (wbc_posture_par_kernel)
+    assert bt.stat("last_posture_par") == 2       # every sweep on a lane of its own, three instances per wavefront (wbc_posture_par3_kernel: <= 21 sweeps)
     # f = sqrt(det(J J')) is O(1..10) and is differenced over 2e-4: rounding in f (1e-16 relative) shows as ~1e-11 in u
     assert np.abs(u - ur).max() < 1e-9
     assert (qa == qar).all()                      # same IEEE operations on q: bit-equal
+    bt.set_option("posture_par", 3)               # one instance per wavefront, every finite-difference POINT on a lane of its own (wbc_posture_par_kernel):
+    u3, qa3 = bt.posture_target(q[:B - 3], mid[:B - 3])     # the same arithmetic per evaluation — bit for bit (and a batch that is not a multiple of three)
+    assert bt.stat("last_posture_par") == 1
+    u2, qa2 = (bt.set_option("posture_par", 1), bt.posture_target(q[:B - 3], mid[:B - 3]))[1]
+    assert (u3 == u2).all() and (qa3 == qa2).all() and (u2 == u[:B - 3]).all()
     bt.set_option("posture_par", 0)               # the sequential whole-tree kernel (52 sweeps per instance) says the same
     u1, qa1 = bt.posture_target(q, mid)
     assert bt.stat("last_posture_par") == 0
