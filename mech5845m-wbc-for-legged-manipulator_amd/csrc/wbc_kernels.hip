@@ -5673,11 +5673,12 @@ constexpr int DPP_ROR8 = 0x128;             // row_ror:8 — lane s <-> lane s ^
 // 0.373 ms per 65536 ticks against 0.386.
 constexpr int XRN = 176;
 struct __attribute__((aligned(16))) XInst {
-  double X[288];            // oMi [22][12] -> Ab [6][6][8]: base (+ eliminated limb DoF) columns of every task block -> J [16][XLD]
-  double W[136];            // sin / cos [22][2] -> Ac [6][16] @0, g by DoF [32] @96 -> W~ [8][16] -> sweep / QP vectors: cl [32] @0, yv [32] @32 (yv | tv), xv @64, dv @80
-  double in[28];            // q [27]
-  double R[XRN];             // ee_target [15] @0, prev_ee_target [15] @15, trunk inputs [18] @30, pf [16] @48, ow [16] @64, wt [96] @80
-                            //   -> L [8][8] @0, 1 / L_jj [8] @64, L^-1 g_E [8] @72 -> T [XTC][XTLD]
+  double X[288];            // oMi [22][12] -> Ab [6][6][8]: base (+ eliminated limb DoF) columns of every task block -> W~ [8][16] -> J [16][XLD]
+  double W[136];            // sin / cos [22][2] -> Ac [6][16] @0, g by DoF [32] @96 -> sweep vectors cl [32] @0, yv [32] @32 -> QP vectors xv @0, dv @16,
+                            //   yv @32, tv @48 and, moved here from R before T is built, L [8][8] + 1 / L_jj [8] @64 -> qdot by DoF [32] @0
+  double in[28];            // q [27]; WARM: the carried working set's bound word @27
+  double R[XRN];            // ee_target [15] @0, prev_ee_target [15] @15, trunk inputs [18] @30, pf [16] @48, ow [16] @64, wt [96] @80
+                            //   -> L [8][8] @0, 1 / L_jj [8] @64, g_E -> L^-1 g_E [8] @72 -> T [XTC][XTLD] @0, L^-1 g_E [8] @168
 };
 static_assert(sizeof(XInst) * 4 <= 20480, "8 waves per CU");
 static_assert(XRN >= 176, "R holds the staged inputs [176] and T [168] + L^-1 g_E [8]");
