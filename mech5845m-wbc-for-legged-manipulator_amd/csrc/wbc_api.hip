@@ -357,9 +357,17 @@ static bool build_q_tables(const DevModel& M, DevPlan* P, bool need_subtree) {
 static void build_orthp_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) {
   P->q_ok = 0;
   const int nelim = P->nelim, nl = 3 * nelim;
-  if (!P->orth || c.use_bounds || c.con_trunk || c.con_com || c.task_trunk || P->p_keep != 0 || nelim < 1 || nelim > 4) return;
+  if (!P->orth || nelim < 1 || nelim > 4) return;
+  // INEQ: the kernel's variant with inequality rows (trunk box, CoM box, the velocity box of every DoF — in the reduced coordinates rows of Z) and a
+  // trunk task: everything beyond the equality-only family of BASELINE configs[1]
+  const bool ineq = c.use_bounds || c.con_trunk || c.con_com || c.task_trunk;
+  const bool trunk_is_root = M.frame_joint[WBC_FR_TRUNK] == 1 && M.frame_p[WBC_FR_TRUNK][0] == 0 && M.frame_p[WBC_FR_TRUNK][1] == 0 && M.frame_p[WBC_FR_TRUNK][2] == 0;
+  if (ineq && (!c.use_bounds || c.con_ee[4] || ((c.con_trunk || c.task_trunk) && !trunk_is_root) || P->n_red > 12)) return;
+  if (P->p_keep != (ineq ? (c.con_com ? 2 : 0) + (c.con_trunk ? 4 : 0) : 0)) return;
   if (c.task_joint != WBC_JOINT_TIKHONOV && c.task_joint != WBC_JOINT_PREV) return;
   if (P->n_red > 15) return;
+  uint32_t lockmask = 0;
+  if (c.use_bounds) for (int d = c.lock_from; d < M.nv; ++d) if (d >= 6 && P->lidx[d] < 0) lockmask |= 1u << d;
   if (!build_q_tables(M, P, true)) return;
   for (int i = 0; i < 18; ++i) P->q_bl2dof[i] = 0;
   for (int i = 0; i < 16; ++i) P->q_red2dof[i] = 0;
@@ -371,8 +379,12 @@ static void build_orthp_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) 
     DevPlan::QDof& r = P->q_dof[d];
     if (d < 6) r.bl = d;
     else if (P->lidx[d] >= 0) r.bl = 6 + P->lidx[d];
+    else if ((lockmask >> d) & 1u) { }                              // locked at 0 by the velocity box: its column leaves the problem
     else { if (nred >= 15) return; r.red = nred; P->q_red2dof[nred++] = d; freemask |= 1u << d; }
     if (r.bl >= 0) P->q_bl2dof[r.bl] = d;
+    DevPlan::XVar& v = P->q_dmp[d];
+    memset(&v, 0, sizeof v);
+    v.dof = d; v.dq_idx = c.damper_qidx[d]; v.d_lo = c.damper_lo[d]; v.d_hi = c.damper_hi[d]; v.d_vm = c.damper_vmax[d];
   }
   if (nred != P->n_red) return;
   P->q_nred = nred;
@@ -386,7 +398,7 @@ static void build_orthp_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) 
     if (M.depth[M.frame_joint[WBC_FR_EE0 + e]] > 7) return;
     if (sup & freemask) P->q_armsup |= 1u << e;
     const uint32_t legs = sup & legall;
-    if (sup & ~(0x3Fu | legall | freemask)) return;
+    if (sup & ~(0x3Fu | legall | freemask | lockmask)) return;
     if (legs) {
       int f = -1;
       for (int t = 0; t < nelim; ++t) {
@@ -397,7 +409,8 @@ static void build_orthp_plan(const DevModel& M, const WbcConfig& c, DevPlan* P) 
       P->q_efoot[e] = f;
     }
   }
-  P->q_ok = 1;
+  P->q_ok = ineq ? 2 : 1;
+  P->q_nlock = __builtin_popcount(lockmask);
   // roll-outs of these configurations update their state on wbc_update_packed_kernel too: its FK schedule down to the deepest frame the estimator reads
   int need = M.depth[M.frame_joint[WBC_FR_TRUNK]];
   for (int e = 0; e < 5; ++e) if (M.depth[M.frame_joint[WBC_FR_EE0 + e]] > need) need = M.depth[M.frame_joint[WBC_FR_EE0 + e]];
@@ -851,7 +864,8 @@ static bool orthp_eligible(const WbcBatch* b, const KernelArgs& a) {
   if (b->packed_orth == 1 && a.B < WBC_ORTHP_MIN_BATCH) return false;
   if (!b->packed_orth || !b->packed_kernel || !b->presolve || !b->presolve_orth || b->n_models < 1 || b->jtj_mfma > 0) return false;
   if (a.in.q_con || a.in.posture_u || b->dbg_alias || (b->dbg_stop > 0 && b->dbg_stop < 200)) return false;   // (dbg_stop 201.. cuts this kernel; working sets: nothing to seed, an empty set out)
-  for (int i = 0; i < b->n_models; ++i) if (!b->plan_host[i].q_ok) return false;
+  for (int i = 0; i < b->n_models; ++i) if (!b->plan_host[i].q_ok || b->plan_host[i].q_ok != b->plan_host[0].q_ok) return false;
+  if (b->plan_host[0].q_ok == 2 && (a.ws_in || a.ws_out)) return false;      // (the INEQ variant carries no working sets)
   return true;
 }
 // the packed box kernel: every plan x_ok, nothing passed that it does not read; packed_box: 1 (default) from WBC_BOXP_MIN_BATCH instances on, 2: always.
@@ -897,7 +911,7 @@ static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
     a.defer_stat = b->d_dstat;
     a.tick_seq = ++b->tick_seq;
     if (!b->tick_seq) a.tick_seq = ++b->tick_seq;
-    if (int e = launch_tick_orthp(a, stream)) return fail(WBC_E_HIP, "packed orth tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+    if (int e = launch_tick_orthp(a, stream, b->plan_host[0].q_ok == 2)) return fail(WBC_E_HIP, "packed orth tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return WBC_OK;
   }
   if (!sim3_eligible(b, a)) {

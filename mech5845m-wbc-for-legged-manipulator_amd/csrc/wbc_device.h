@@ -48,7 +48,8 @@ struct DevPlan {
   PkCol pk_var[16], pk_leg[16];      // reduced variable s / eliminated leg DoF s
   int32_t pk_scq[32];                // joint j (>= 2): q index of its angle if it is a revolute joint the FK needs, else -1
   // packed orth kernel (wbc_tick_orthp_kernel, round 3): the equality-only task problems (BASELINE configs[1]) four instances per wavefront
-  int32_t q_ok, q_nred, q_armsup, q_pad_;   // eligible; n' = 6 + free DoF outside base and stance legs (<= 15); bit e: EE task e touches a free (arm) variable
+  int32_t q_ok, q_nred, q_armsup, q_nlock;  // eligible (1: equality-only family; 2: INEQ variant — inequality rows, velocity box, trunk task); n' = 6 + free DoF outside
+                                            // base and stance legs (<= 15; INEQ: <= 12, locked DoF left out); bit e: EE task e touches a free (arm) variable; DoF locked at 0
   struct QDof { int32_t joint, lin, ang, bl, red, sub_lo, sub_hi, supmask; };   // DoF d: Jacobian column; position in [base; stance legs] (-1: none);
                                                                                 // reduced variable (>= 6, -1: none); joints of its subtree [lo, hi]; bit e: moves EE frame e
   struct QJnt { double m, c0, c1, c2; };    // joint j: mass and centre of mass of its body (joint frame)
@@ -58,11 +59,12 @@ struct DevPlan {
   QJnt q_jm[32];
   int32_t q_bl2dof[18], q_red2dof[16];
   int32_t q_efoot[8];                // EE e: index of its leg among the eliminated feet (-1: not an eliminated foot)
+  struct XVar { int32_t dof, dq_idx, task, pad_; double d_lo, d_hi, d_vm; };   // DoF, its velocity-damper entries, the EE task that moves with it (-1: none / base)
+  XVar q_dmp[32];                    // INEQ variant: the velocity-damper entries of DoF d
   // packed box kernel (wbc_tick_boxp_kernel, round 3): task problems WITHOUT constraint rows (the warm-up problem of setInitialState), four
   // instances per wavefront. The base and (where 16 lanes do not hold the rest) the limb DoF with the widest box are eliminated by a Schur
   // complement; DoF locked at 0 are left out. Shares q_fk / q_scq / q_dof (joint, lin, ang, supmask) with the packed orth kernel.
   int32_t x_ok, x_ne, x_nk, x_nlock;  // eligible; eliminated DoF (6..8), kept (bounded) variables (<= 16), DoF locked at 0
-  struct XVar { int32_t dof, dq_idx, task, pad_; double d_lo, d_hi, d_vm; };   // DoF, its velocity-damper entries, the EE task that moves with it (-1: none / base)
   XVar x_kept[16], x_elim[8];
   int32_t x_role[32];                // DoF d: 0..7 eliminated slot, 16 + k kept variable k, -1 locked / absent
   uint32_t x_limb[16];               // kept variable k: bit k2 = kept variable k2 moves the same task's frame (the limb block of H_KK)
@@ -183,7 +185,7 @@ int launch_tick(const KernelArgs& a, int mode, int grid, void* stream);
 int launch_tick_sim3(const KernelArgs& a, int grid, void* stream);
 int launch_tick_sim3p(const KernelArgs& a, void* stream);      // packed: four instances per wavefront, grid = ceil(B / 4)
 int launch_tick_boxp(const KernelArgs& a, void* stream);       // packed box kernel (task problems without constraint rows), grid = ceil(B / 4)
-int launch_tick_orthp(const KernelArgs& a, void* stream);      // packed orth kernel (equality-only task problems), grid = ceil(B / 4)
+int launch_tick_orthp(const KernelArgs& a, void* stream, int ineq);      // packed orth kernel (equality-only task problems), grid = ceil(B / 4)
 int orthp_lds_bytes();
 int sim3p_lds_bytes();
 int launch_tick_deferred(const KernelArgs& a, void* stream);   // general path for the instances the sim3 kernel deferred

@@ -5120,6 +5120,13 @@ constexpr int WT_W = 0, WT_w = 30, WT_G = 35, WT_CW = 78, WT_CG = 81;   // offse
 #else
 #define QSTOP(k, val) do { } while (0)
 #endif
+// INEQ: the variant for the task problems that keep INEQUALITY rows next to the eliminated contact equalities — trunk box (trunkConstraint,
+// Robot_Wrapper4.py:707-754), CoM box (CoMConstraint, :669-694), the velocity box of every DoF (:572-637) — and the trunk task (tests/common.py
+// "everything"). In the reduced coordinates y (qd = Z y) the velocity bounds of the base and the stance legs are the ROWS of Z (six columns each),
+// the trunk and CoM boxes six dense rows (formed with the task blocks' own A Z machinery), the arm's bounds stay simple bounds: <= 24 rows, two per
+// lane, and the packed sim3 kernel's dual active-set method on n' <= 12 unknowns. Cold starts only; an instance that needs more than 11 active
+// constraints goes to the tail with the flagged ones.
+template <bool INEQ>
 __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                                const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   __shared__ union { QInst Q[4]; Smem G; } SU;
@@ -5163,7 +5170,21 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     // the configuration's weights and gains: 85 contiguous doubles of WbcConfig, six per lane, parked in wt (= cl | yv | zv | xv)
     const double* cw = &cfg.ee_W[0][0];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) I.cl[s + 16 * i] = (s + 16 * i < 85) ? cw[s + 16 * i] : 0.0;
+    for (int i = 0; i < 6; ++i) I.cl[s + 16 * i] = (s + 16 * i < 89) ? cw[s + 16 * i] : 0.0;     // (+ trunk_box_z_frac, _ang, _scale, com_box_scale @85..88)
+    if (INEQ) {
+      const bool c_tr = cfg.task_trunk != 0;
+      double t0 = 0.0, t1 = 0.0;
+      if (c_tr) {
+        auto tinv = [&](const int k) -> double {
+          return (k < 3) ? A.in.trunk_target[(size_t)b * 3 + k] : (k < 6) ? A.in.prev_trunk_target[(size_t)b * 3 + (k - 3)]
+               : (k < 9) ? A.in.trunk_ref_euler[(size_t)b * 3 + (k - 6)] : A.in.trunk_prev_rot[(size_t)b * 9 + (k - 9)];
+        };
+        t0 = tinv(s); t1 = (s < 2) ? tinv(16 + s) : 0.0;
+      }
+      I.gp[s] = t0;
+      if (s < 2) I.gp[16 + s] = t1;
+      if (s >= 2 && s < 6) I.gp[16 + s] = (cfg.con_trunk && A.in.trunk_box_center) ? A.in.trunk_box_center[(size_t)b * 4 + (s - 2)] : 0.0;
+    }
   }
   const double* const wt = I.cl;
   const int nv = M.nv, nq = M.nq, nj = M.njoints, n = P.q_nred, nelim = P.nelim, nl = 3 * nelim;
@@ -5182,6 +5203,50 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
                fp2 = (s < 5) ? M.frame_p[WBC_FR_EE0 + s][2] : 0.0;
   WSYNC();
   const double* const qv = I.in;
+  const bool c_trunk = INEQ && cfg.task_trunk != 0, c_con_trunk = INEQ && cfg.con_trunk != 0, c_con_com = INEQ && cfg.con_com != 0;
+  if (INEQ && __ballot(c_trunk)) {
+    // calcTargetVelTrunk2 (Robot_Wrapper4.py:948-1015) / TrunkB (:914-920), as in the packed sim3 / box kernels: the trunk frame is the free-flyer's own
+    // placement (the plan checks it); the target velocity x trunk_w is parked in gp [24..29]
+    const double* tw = wt + 65;              // trunk_W [0..5], trunk_w [6], trunk_gain [7..12]
+    const double* tin = I.gp;
+    const double* xt = tin;
+    const double* xp = tin + 3;
+    const double* er = tin + 6;
+    double* const sh = I.X;                  // (free until the FK)
+    double Rt_[9], fq[4], rq[4], Rs[9], vel[6];
+    quat_to_R(qv + 3, Rt_);
+    R_to_quat(Rt_, fq);
+    {
+      const SinCos t = sincos_cw(s < 3 ? er[s < 3 ? s : 0] : 0.5 * er[(s < 6 ? s : 3) - 3]);
+      if (s < 6) { sh[2 * s] = t.s; sh[2 * s + 1] = t.c; }
+      WSYNC();
+      const double sa = sh[0], ca = sh[1], sb = sh[2], cb = sh[3], sc_ = sh[4], cc_ = sh[5];
+      Rs[0] = cc_ * cb; Rs[1] = cc_ * sb * sa - sc_ * ca; Rs[2] = cc_ * sb * ca + sc_ * sa;
+      Rs[3] = sc_ * cb; Rs[4] = sc_ * sb * sa + cc_ * ca; Rs[5] = sc_ * sb * ca - cc_ * sa;
+      Rs[6] = -sb;      Rs[7] = cb * sa;                  Rs[8] = cb * ca;
+      const double qx[4] = {sh[6], 0, 0, sh[7]}, qy[4] = {0, sh[8], 0, sh[9]}, qz[4] = {0, 0, sh[10], sh[11]};
+      double tq[4];
+      quat_mul(qy, qx, tq);
+      quat_mul(qz, tq, rq);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vel[i] = (xt[i] - xp[i]) * inv_dt + tw[7 + i] * ((xt[i] - qv[i]) * inv_dt);
+    const double qe0 = fq[3] * rq[0] - fq[0] * rq[3] + fq[1] * rq[2] - fq[2] * rq[1];   // :974
+    const double qe1 = fq[3] * rq[1] - fq[1] * rq[3] - fq[0] * rq[2] + fq[2] * rq[0];   // :975
+    const double qe2 = fq[3] * rq[2] - fq[3] * rq[2] + fq[0] * rq[1] - fq[1] * rq[0];   // :976 (sic)
+    double D[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) D[i] = (Rs[i] - tin[9 + i]) * inv_dt;
+    vel[3] = (D[6] * Rs[1] + D[7] * Rs[4] + D[8] * Rs[7]) + tw[10] * qe0;
+    vel[4] = (D[0] * Rs[2] + D[1] * Rs[5] + D[2] * Rs[8]) + tw[11] * qe1;
+    vel[5] = (D[3] * Rs[0] + D[4] * Rs[3] + D[5] * Rs[6]) + tw[12] * qe2;
+    const double trunk_w = tw[6];
+    if (s == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) I.gp[24 + i] = c_trunk ? vel[i] * trunk_w : 0.0;
+    }
+    WSYNC();
+  }
   double* const oMi = I.X;                   // [22][12]
   double* const sc = I.W;                    // sin / cos of joint j at 2 j
   double* const mc = I.W + 44;               // m_j c_j (world), m_j at 4 j
@@ -5266,7 +5331,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
   WSYNC();   // oMi is dead: X is free
   // ---- centre of mass and the CoM-Jacobian columns (pin.jacobianCenterOfMass): jc = (m_sub / M) (lin + ang x c_sub)
   double com[3] = {0, 0, 0}, jc0[3] = {0, 0, 0}, jc1[3] = {0, 0, 0};
-  if (__ballot(c_com)) {
+  if (__ballot(c_com || c_con_com)) {
     const double Mt = rsum16(ms_l);
     const double St[3] = {rsum16(sl[0]), rsum16(sl[1]), rsum16(sl[2])};
     com[0] = St[0] / Mt; com[1] = St[1] / Mt; com[2] = St[2] / Mt;
@@ -5412,7 +5477,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
   for (int k = 0; k < 16; ++k) h[k] = 0.0;
   double* const Ab = I.X;                    // [6][18]
   double* const AZ = I.X + 108;              // [6][16]
-  auto block = [&](const double* a0, const double* a1, const double* br, const int ef, const bool dense, const bool arm) {
+  auto block = [&](const double* a0, const double* a1, const double* br, const int ef, const bool dense, const bool arm, const bool acc_h = true) {
     WSYNC();                                 // the previous block's readers are done
 #pragma unroll
     for (int rr = 0; rr < 6; ++rr) {
@@ -5443,6 +5508,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
       }
     }
     WSYNC();
+    if (!acc_h) return;                      // (INEQ: the constraint rows' images stay in AZ)
     double own[6];
 #pragma unroll
     for (int rr = 0; rr < 6; ++rr) own[rr] = AZ[rr * 16 + s];
@@ -5501,6 +5567,87 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
 #pragma unroll
     for (int i = 1; i < 5; ++i) ef = (e == i) ? efoot[i] : ef;
     block(a0, a1, br, ef, false, (armsup >> e) & 1u);
+  }
+  // ---- INEQ: the trunk task (trunkA, Robot_Wrapper4.py:487-490, WORLD rows on the base columns), then the inequality rows and every bound
+  double lb = -QP_INF, ub = QP_INF, clb0 = -QP_INF, cub0 = QP_INF, clb1 = -QP_INF, cub1 = QP_INF;
+  double rowreg[6] = {0, 0, 0, 0, 0, 0};
+  if (INEQ) {
+    if (__ballot(c_trunk)) {
+      const double* tw = wt + 65;
+      const double trunk_w = tw[6];
+      const bool sup = c_trunk && D0.bl >= 0 && D0.bl < 6;
+      double at[6], a1[6] = {0, 0, 0, 0, 0, 0}, br[6];
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        at[rr] = sup ? (tw[rr] * lin0[rr]) * trunk_w : 0.0;
+        at[3 + rr] = sup ? (tw[3 + rr] * ang0[rr]) * trunk_w : 0.0;
+      }
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) br[rr] = c_trunk ? I.gp[24 + rr] : 0.0;
+      block(at, a1, br, -1, false, false);
+    }
+    // the six dense rows in reduced coordinates, through the blocks' A Z machinery: rows 0..3 trunk box (z, roll, pitch, yaw: LOCAL_WORLD_ALIGNED rows
+    // of the trunk frame = the free-flyer's placement, :707-754), rows 4, 5 CoM box (x, y rows of the CoM Jacobian, :669-694)
+    const double ptr[3] = {qv[0], qv[1], qv[2]};
+    {
+      double a0[6] = {0, 0, 0, 0, 0, 0}, a1[6] = {0, 0, 0, 0, 0, 0}, zr[6] = {0, 0, 0, 0, 0, 0};
+      if (c_con_trunk && D0.bl >= 0 && D0.bl < 6) {
+        double wxp[3];
+        cross3(ang0, ptr, wxp);
+        a0[0] = lin0[2] + wxp[2]; a0[1] = ang0[0]; a0[2] = ang0[1]; a0[3] = ang0[2];
+      }
+      if (c_con_com) { a0[4] = jc0[0]; a0[5] = jc0[1]; a1[4] = has1 ? jc1[0] : 0.0; a1[5] = has1 ? jc1[1] : 0.0; }
+      block(a0, a1, zr, -1, true, true, false);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) rowreg[i] = AZ[s + 16 * i];           // (kept in registers: X is the sweep's and then J's)
+    }
+    // bounds: the velocity damper of this lane's two DoF (:572-637) goes to its row of Z (base / stance leg) or to its reduced variable (arm); the
+    // trunk box's and the CoM box's sides to rows 0..5
+    double* const rbl = I.X + 204;            // row bounds [32] lower, [32] upper
+    double* const rbu = I.X + 236;
+    double* const vbl = I.pf;                 // simple bounds of the reduced variables [16] lower / upper (pf | ow are dead)
+    double* const vbu = I.ow;
+    double l0 = 0.0, u0 = 0.0, l1 = 0.0, u1 = 0.0, tl = -QP_INF, tu = QP_INF;
+    {
+      const double dcoef = cfg.damper_coef, dqi = cfg.damper_qi, dqs = cfg.damper_qs;
+      auto damper = [&](const DevPlan::XVar& v, double& l_, double& u_) {
+        const double qi = qv[v.dq_idx], lo = v.d_lo, hi = v.d_hi, vm = v.d_vm;
+        if (qi <= lo + dqi) { l_ = -dcoef * (qi - lo - dqs) / (dqi - dqs); if (l_ > vm) l_ = vm; if (l_ < -vm) l_ = -vm; } else l_ = -vm;
+        if (qi >= hi - dqi) { u_ = dcoef * (hi - qi - dqs) / (dqi - dqs); if (u_ < -vm) u_ = -vm; if (u_ > vm) u_ = vm; } else u_ = vm;
+        if (l_ > 0) l_ = -l_;
+        if (u_ < 0) u_ = -u_;
+      };
+      const DevPlan::XVar v0 = P.q_dmp[s], v1 = P.q_dmp[(16 + s) & 31];
+      damper(v0, l0, u0);
+      if (has1) damper(v1, l1, u1);
+      // trunk box (lanes 0..3) and CoM box (lanes 4, 5)
+      const double tb_z = wt[85], tb_a = wt[86], tb_s = wt[87], cb_s = wt[88];
+      double Rtr[9];
+      quat_to_R(qv + 3, Rtr);
+      const double ay = (s == 1) ? Rtr[7] : ((s == 2) ? -Rtr[6] : Rtr[3]);
+      const double ax = (s == 1) ? Rtr[8] : ((s == 2) ? sqrt(fma(Rtr[7], Rtr[7], Rtr[8] * Rtr[8])) : Rtr[0]);
+      const double eul = atan2(ay, ax);       // lanes 1, 2, 3 hold roll, pitch, yaw
+      const double* bc = I.gp + 18;
+      if (c_con_trunk && s < 4) {
+        const double cr = (s == 0) ? ptr[2] : eul;
+        const double vr = (s == 0) ? bc[0] * tb_z : tb_a;
+        tl = (((bc[s] - vr) - cr) * inv_dt) * tb_s;
+        tu = (((bc[s] + vr) - cr) * inv_dt) * tb_s;
+      }
+      if (c_con_com && (s == 4 || s == 5)) {  // EE_frame_pos[1] = FL, [2] = RR (:675-677)
+        const int r_ = s - 4;
+        tl = ((I.pf[3 * 2 + r_] - com[r_]) * inv_dt) * cb_s;
+        tu = ((I.pf[3 * 1 + r_] - com[r_]) * inv_dt) * cb_s;
+      }
+    }
+    WSYNC();                                 // (pf has been read)
+    rbl[s] = (s < 6) ? tl : -QP_INF; rbu[s] = (s < 6) ? tu : QP_INF; rbl[16 + s] = -QP_INF; rbu[16 + s] = QP_INF;
+    vbl[s] = -QP_INF; vbu[s] = QP_INF;
+    WSYNC();
+    if (D0.bl >= 0) { rbl[6 + D0.bl] = l0; rbu[6 + D0.bl] = u0; } else if (D0.red >= 6) { vbl[D0.red & 15] = l0; vbu[D0.red & 15] = u0; }
+    if (has1) { if (D1.bl >= 0) { rbl[6 + D1.bl] = l1; rbu[6 + D1.bl] = u1; } else if (D1.red >= 6) { vbl[D1.red & 15] = l1; vbu[D1.red & 15] = u1; } }
+    WSYNC();
+    lb = vbl[s]; ub = vbu[s]; clb0 = rbl[s]; cub0 = rbu[s]; clb1 = rbl[16 + s]; cub1 = rbu[16 + s];
   }
   QSTOP(5, h[0] + h[5] + h[13] + gacc);
   // posture rows (qpJointA / qpJointb, :1199-1268): Z'(d^2 I)Z = d^2 I; the target's part of g through Z
@@ -5578,6 +5725,267 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     for (int k = 0; k < 16; k += 2) { const double2a v2 = lds2(I.zv + k); xa = fma(y[k], v2.x, xa); xb = fma(y[k + 1], v2.y, xb); }
     x = (s < n) ? -(xa + xb) : 0.0;
   }
+  int iters = 0;
+  if (INEQ) {
+    // ================================ the QP (INEQ variant): the packed sim3 kernel's dual active-set method =====================================
+    // unknowns: the n' <= 12 reduced variables (lane s); simple bounds on the arm's; rows 0..5 dense (Cd [6][16]), rows 6 + j = row j of Z (six
+    // base-reduced columns): lane s owns rows s and 16 + s (< 24). Codes: bound of variable i = i, row rr = 32 + rr, upper side + 256.
+    constexpr int QPV = 12, QLD = 14, QTC = 11;
+    double* const J = I.X;                   // [12][14]
+    double* const Cd = I.X + 168;            // [6][16]
+    double* const T = I.in;                  // [11][14] (runs through in | pf | ow | cl | yv: all dead)
+    double* const qxv = I.zv;
+    double* const qdv = I.xv;
+    double* const qyv = I.gp;
+    double* const qtv = I.gp + 16;
+    WSYNC();
+    if (s < QPV) {
+#pragma unroll
+      for (int k = 0; k < QPV; k += 2) sts2(J + s * QLD + k, y[k], y[k + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Cd[s + 16 * i] = rowreg[i];
+    if (s < QTC) {
+#pragma unroll
+      for (int k = 0; k < QLD; k += 2) sts2(T + s * QLD + k, 0.0, 0.0);
+    }
+    double sq = 0.0;
+#pragma unroll
+    for (int k = 0; k < QPV; ++k) sq = fma(y[k], y[k], sq);
+    const double jf2 = rsum16(s < QPV ? sq : 0.0);
+    WSYNC();
+    auto row_dot = [&](const int rr, const double* v) -> double {      // row rr (0..23) times a vector of the reduced variables (LDS)
+      double a = 0.0;
+      if (rr < 6) {
+#pragma unroll
+        for (int k = 0; k < QPV; k += 2) { const double2a c = lds2(Cd + rr * 16 + k), w = lds2(v + k); a = fma(c.x, w.x, fma(c.y, w.y, a)); }
+      } else {
+        const double* z = Zm + (rr - 6) * 6;
+        const double2a c0 = lds2(z), c1 = lds2(z + 2), c2 = lds2(z + 4), w0 = lds2(v), w1 = lds2(v + 2), w2 = lds2(v + 4);
+        a = fma(c0.x, w0.x, fma(c0.y, w0.y, fma(c1.x, w1.x, fma(c1.y, w1.y, fma(c2.x, w2.x, c2.y * w2.y)))));
+      }
+      return a;
+    };
+    auto row_n2 = [&](const int rr) -> double {
+      double a = 0.0;
+      if (rr < 6) {
+#pragma unroll
+        for (int k = 0; k < QPV; ++k) { const double c = Cd[rr * 16 + k]; a = fma(c, c, a); }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const double c = Zm[(rr - 6) * 6 + k]; a = fma(c, c, a); }
+      }
+      return a;
+    };
+    const bool has_b = s < n, has_r1 = s < 8;
+    const double cn0 = row_n2(s), cn1 = has_r1 ? row_n2(16 + s) : 1.0;
+    if (live && ((has_b && ((lb != lb) || (ub != ub))) || (clb0 != clb0) || (cub0 != cub0) || (has_r1 && ((clb1 != clb1) || (cub1 != cub1))))) status = WBC_QP_NUMERICAL;
+    {
+      const unsigned long long nb = __ballot(status != WBC_QP_OPTIMAL);
+      if ((nb >> rbase) & 0xFFFFull) status = WBC_QP_NUMERICAL;
+    }
+    bool act_b = false, act0 = false, act1 = false, overflow = false;
+    double u = 0.0;
+    int a_code = 0, q = 0;
+    const int max_iter = 10 * (n + 24) + 20;
+    bool searching = live && status == WBC_QP_OPTIMAL;
+    const int sJ = s < QPV ? s : QPV - 1, sT = s < QTC ? s : QTC - 1;
+    auto normal_d = [&](const bool is_row, const int rr_, const int ip, const double sgn) -> double {
+      double d = 0.0;
+      if (is_row) {
+        if (rr_ < 6) {
+#pragma unroll
+          for (int k = 0; k < QPV; ++k) d = fma(J[k * QLD + sJ], Cd[rr_ * 16 + k], d);
+        } else {
+          const double* z = Zm + (rr_ - 6) * 6;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) d = fma(J[k * QLD + sJ], z[k], d);
+        }
+        d *= sgn;
+      } else d = sgn * J[(ip & 15) * QLD + sJ];
+      return d;
+    };
+    auto set_act = [&](const int code, const bool val) {
+      if (code >= 32) { const int rr = code - 32; if (s == (rr & 15)) { if (rr < 16) act0 = val; else act1 = val; } }
+      else if (s == code) act_b = val;
+    };
+    auto drop_slot = [&](const bool dr, const int l_) {
+      const int l = dr ? l_ : 0;
+      const int lc = bpermi(a_code, rbase + l) & 255;
+      if (dr) set_act(lc, false);
+      WSYNC();
+      qyv[s] = u; qtv[s] = (double)a_code;
+      WSYNC();
+      if (dr && s >= l && s < q - 1) { u = qyv[s + 1]; a_code = (int)qtv[s + 1]; }
+      if (dr && s == q - 1) { u = 0.0; a_code = 0; }
+      const int srow = (sT >= l) ? ((sT + 1 < QTC) ? sT + 1 : sT) : sT;
+      double tx = T[srow * QLD + l];
+      double jx = J[sJ * QLD + l];
+      double hrun = T[l * QLD + l];
+      const int kend = dr ? q - 1 : 0;
+#pragma unroll 1
+      for (int k0 = 0; k0 < QTC - 1; ++k0) {
+        const bool on = dr && (l + k0 < kend);
+        if (!__ballot(on)) break;
+        const int kk = on ? l + k0 : 0;
+        const double tb = T[l * QLD + kk + 1];
+        const double nrm2 = fma(hrun, hrun, tb * tb);
+        double c_ = 1.0, s_ = 0.0, rho = 0.0;
+        if (nrm2 > 0.0) { const double ri = rsqrt(nrm2); c_ = tb * ri; s_ = -hrun * ri; rho = nrm2 * ri; }
+        const double ty_ = T[srow * QLD + kk + 1];
+        const double jy = J[sJ * QLD + kk + 1];
+        WSYNC();
+        if (on) {
+          hrun = rho;
+          if (s < q - 1) T[s * QLD + kk] = fma(c_, tx, s_ * ty_);
+          if (has_b) J[s * QLD + kk] = fma(c_, jx, s_ * jy);
+          tx = fma(-s_, tx, c_ * ty_);
+          jx = fma(-s_, jx, c_ * jy);
+        }
+        WSYNC();
+      }
+      WSYNC();
+      if (dr) { if (s < q) T[s * QLD + q - 1] = 0.0; }
+      WSYNC();
+      if (dr) {
+        if (s < q) T[(q - 1) * QLD + s] = 0.0;
+        if (has_b) J[s * QLD + q - 1] = jx;
+        --q;
+      }
+      WSYNC();
+    };
+    struct Zr { double z, rv, dq, jq; };
+    auto products = [&](const bool want_r) -> Zr {
+      Zr o;
+      double z = 0.0, zb = 0.0, rv = 0.0, rvb = 0.0;
+      o.dq = qdv[q & 15];
+      o.jq = J[sJ * QLD + (q & 15)];
+#pragma unroll
+      for (int k = 0; k < QPV; k += 2) {
+        const double2a j2 = lds2(J + sJ * QLD + k); const double2a y2 = lds2(qyv + k);
+        z = fma(j2.x, y2.x, z); zb = fma(j2.y, y2.y, zb);
+      }
+      z += zb;
+      if (want_r) {
+#pragma unroll
+        for (int k = 0; k < QPV; k += 2) {
+          const double2a t2 = lds2(T + sT * QLD + k); const double2a d2_ = lds2(qdv + k);
+          rv = fma(t2.x, d2_.x, rv); rvb = fma(t2.y, d2_.y, rvb);
+        }
+        rv += rvb;
+      }
+      if (s >= q) rv = 0.0;
+      if (!has_b) z = 0.0;
+      o.z = z; o.rv = rv;
+      return o;
+    };
+    auto add_step = [&](const bool add, const double zn, const Zr& zr, const int wc, const double u_new) {
+      const double rsz = frsq(zn), sz = zn * rsz;
+      const double delta = (zr.dq >= 0.0) ? -sz : sz;
+      const double hv = zn - delta * zr.dq;
+      const double vv = 2.0 * hv;
+      const double w = (zr.z - delta * zr.jq) * ((vv > 0.0) ? frcp(hv) : 0.0);
+      if (add && has_b && vv > 0.0) {
+#pragma unroll
+        for (int k = 0; k < QPV; k += 2) {
+          const double2a j2 = lds2(J + s * QLD + k); const double2a y2 = lds2(qyv + k);
+          sts2(J + s * QLD + k, fma(-w, y2.x, j2.x), fma(-w, y2.y, j2.y));
+        }
+        J[s * QLD + q] = fma(-w, zr.dq - delta, zr.jq);
+      }
+      if (add) {
+        const double idel = (zr.dq >= 0.0) ? -rsz : rsz;
+        if (s < q) T[s * QLD + q] = -zr.rv * idel;
+        if (s == q) { T[s * QLD + q] = idel; u = u_new; a_code = wc; }
+        set_act(wc & 255, true);
+        ++q;
+      }
+    };
+#pragma unroll 1
+    for (;;) {
+      WSYNC();
+      qxv[s] = has_b ? x : 0.0;
+      WSYNC();
+      double best = 0.0; int code = -1;
+      double cand_b = 0.0, cand_n2 = 1.0;
+      if (has_b && !act_b) {
+        if (lb > -QP_INF) { const double sl = x - lb; if (sl < -1e-9 * fmax(1.0, fabs(lb)) && sl < best) { best = sl; code = s; cand_b = lb; } }
+        if (ub < QP_INF) { const double sl = ub - x; if (sl < -1e-9 * fmax(1.0, fabs(ub)) && sl < best) { best = sl; code = s | 256; cand_b = -ub; } }
+      }
+      if (!act0) {
+        const double v = row_dot(s, qxv);
+        if (clb0 > -QP_INF) { const double sl = v - clb0; if (sl < -1e-9 * fmax(1.0, fabs(clb0)) && sl < best) { best = sl; code = 32 + s; cand_b = clb0; cand_n2 = cn0; } }
+        if (cub0 < QP_INF) { const double sl = cub0 - v; if (sl < -1e-9 * fmax(1.0, fabs(cub0)) && sl < best) { best = sl; code = (32 + s) | 256; cand_b = -cub0; cand_n2 = cn0; } }
+      }
+      if (has_r1 && !act1) {
+        const double v = row_dot(16 + s, qxv);
+        if (clb1 > -QP_INF) { const double sl = v - clb1; if (sl < -1e-9 * fmax(1.0, fabs(clb1)) && sl < best) { best = sl; code = 48 + s; cand_b = clb1; cand_n2 = cn1; } }
+        if (cub1 < QP_INF) { const double sl = cub1 - v; if (sl < -1e-9 * fmax(1.0, fabs(cub1)) && sl < best) { best = sl; code = (48 + s) | 256; cand_b = -cub1; cand_n2 = cn1; } }
+      }
+      const double worst = rmin16(best);
+      if (searching && !(worst < 0.0)) searching = false;
+      if (!__ballot(searching)) break;
+      const unsigned long long wm = __ballot(searching && best == worst);
+      const int wl = __ffs((int)((wm >> rbase) & 0xFFFFull)) - 1;
+      const int wsrc = rbase + (wl < 0 ? 0 : wl);
+      const int wc = bpermi(code, wsrc);
+      const double b_ip = bperm(cand_b, wsrc);
+      const double np2 = bperm(cand_n2, wsrc);
+      const int ip = wc & 255, ip_side = (wc >> 8) & 1;
+      const bool is_row = ip >= 32;
+      const int rr_ = is_row ? ip - 32 : 0;
+      const double sgn = ip_side ? -1.0 : 1.0;
+      double s_ip = worst, u_ip = 0.0;
+      bool stepping = searching;
+      int drop_l = -1;
+#pragma unroll 1
+      for (;;) {
+        if (stepping && ++iters > max_iter) { status = WBC_QP_MAX_ITER; stepping = false; searching = false; }
+        if (__ballot(stepping && drop_l >= 0)) {
+          const bool dr = stepping && drop_l >= 0;
+          drop_slot(dr, drop_l);
+          qxv[s] = has_b ? x : 0.0;
+          WSYNC();
+          const double v = is_row ? row_dot(rr_, qxv) : qxv[ip & 15];
+          if (dr) { s_ip = sgn * v - b_ip; drop_l = -1; }
+        }
+        if (!__ballot(stepping)) break;
+        double d = normal_d(is_row, rr_, ip, sgn);
+        if (!has_b || !stepping) d = 0.0;
+        WSYNC();
+        qdv[s] = d; qyv[s] = (s >= q) ? d : 0.0;
+        WSYNC();
+        const double zn = rsum16(s >= q ? d * d : 0.0);
+        const Zr zr = products(__ballot(stepping && q > 0) != 0);
+        const double z = zr.z, rv = zr.rv;
+        const bool have_step = zn > 100.0 * n * EPS2 * jf2 * np2;
+        const bool cand = (s < q) && (rv > 2.2250738585072014e-308);
+        const double ratio = cand ? u * frcp(rv) : INFINITY;
+        const double t1 = rmin16(ratio);
+        const unsigned long long lm = __ballot(cand && ratio == t1);
+        const int l = (t1 < INFINITY) ? __ffs((int)((lm >> rbase) & 0xFFFFull)) - 1 : -1;
+        const double t2 = have_step ? -s_ip * frcp(zn) : INFINITY;
+        const double tt = fmin(t1, t2);
+        if (stepping && !(tt < INFINITY)) { status = WBC_QP_INFEASIBLE; stepping = false; searching = false; }
+        if (stepping) {
+          if (have_step) x = fma(tt, z, x);
+          u = fma(-tt, rv, u);
+          u_ip += tt;
+        }
+        bool add = stepping && have_step && tt == t2;
+        if (add && q >= QTC) { overflow = true; add = false; stepping = false; searching = false; }
+        if (__ballot(add)) {
+          add_step(add, zn, zr, wc, u_ip);
+          if (add) stepping = false;
+        }
+        if (stepping) drop_l = l;
+      }
+    }
+    {   // more active constraints than T holds: the instance goes to the tail with the flagged ones
+      const unsigned long long om = __ballot(valid && overflow);
+      if ((om >> rbase) & 0xFFFFull) { defer = true; live = false; }
+    }
+  }
   if (status == WBC_QP_OPTIMAL) {
     const unsigned long long bad = __ballot(s < n && !(fabs(x) <= 1.7976931348623157e308));
     if ((bad >> rbase) & 0xFFFFull) status = WBC_QP_NUMERICAL;
@@ -5607,7 +6015,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     if (16 + s < NV) qo[16 + s] = I.gp[16 + s];
     if (s == 0) {
       A.out.status[b] = status;
-      if (A.out.iters) A.out.iters[b] = nl;     // the eliminated equalities, so that `iters` keeps its meaning
+      if (A.out.iters) A.out.iters[b] = nl + (INEQ ? iters + P.q_nlock : 0);     // (+ the eliminated equalities and the locked DoF, so that `iters` keeps its meaning)
     }
   }
   // working sets (a hot-started tick / roll-out of these configurations stays on this kernel): the problem has no inequality, so a carried set
@@ -5615,6 +6023,11 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
   if (A.ws_out && valid && s < 2) A.ws_out[2 * (size_t)b + s] = 0ull;
   if (A.out.q_next) {   // jointVelocitiestoConfig (Robot_Wrapper4.py:440-441)
     WSYNC();
+    if (INEQ) {                              // (the QP's T took the staged configuration's place)
+      const double* qg = A.in.q + (size_t)b * NQ;
+      I.in[s] = qg[s];
+      if (16 + s < 28) I.in[16 + s] = (16 + s < NQ) ? qg[16 + s] : 0.0;
+    }
     I.xv[s] = (s < 6) ? I.gp[s] * dt : 0.0;
     WSYNC();
     double* qn = A.out.q_next + (size_t)b * NQ;
@@ -5646,6 +6059,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     }
   }
 }
+template __global__ void wbc_tick_orthp_kernel<false>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
+template __global__ void wbc_tick_orthp_kernel<true>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
 
 // ================================================================================================
 // The PACKED BOX kernel (round 3): FOUR instances per wavefront for the task problems WITHOUT constraint rows — the warm-up problem of
@@ -6553,8 +6968,9 @@ int launch_tick_sim3p(const KernelArgs& a, void* stream) {
   else hipLaunchKernelGGL((wbc_tick_sim3p_kernel<false, false>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   return check_launch("tick_sim3p");
 }
-int launch_tick_orthp(const KernelArgs& a, void* stream) {
-  hipLaunchKernelGGL(wbc_tick_orthp_kernel, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+int launch_tick_orthp(const KernelArgs& a, void* stream, int ineq) {
+  if (ineq) hipLaunchKernelGGL(wbc_tick_orthp_kernel<true>, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  else hipLaunchKernelGGL(wbc_tick_orthp_kernel<false>, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   return check_launch("tick_orthp");
 }
 int orthp_lds_bytes() { return (int)(4 * sizeof(QInst)); }
