@@ -955,6 +955,59 @@ def test_packed_orth_kernel_variants_and_non_finite_inputs(wx200, px100, posture
     bt.close()
 
 
+@pytest.mark.parametrize("variant", ["everything", "no_com_box", "no_trunk"])
+def test_packed_orth_kernel_with_inequality_rows(wx200, px100, variant):
+    """wbc_tick_orthp_kernel<INEQ>: the task problems whose tasks touch the stance legs AND that keep inequality rows — trunk box, CoM
+    box, the velocity box of every DoF (in the reduced coordinates: rows of Z, two per lane), with the trunk task — four instances per wavefront:
+    tests/common.py "everything" and relatives (no CoM box; no trunk task / trunk box; with three stance feet the reduced problem has 14 unknowns, more than
+    the variant's 12: general kernel) on a mixed wx200 / px100 batch at a size the default policy sends to it, ragged tail, q_next, the oracle's working-set changes, infeasible
+    instances (a trunk outside its box) reported as the oracle reports them, and non-finite inputs contained to their own instance."""
+    B = 4610
+    models = [wx200, px100]
+    kw = dict(everything=dict(Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint="PREV", task_com=True, cCoM=True, cTrunk=True,
+                              cFR=True, cFL=True, cRR=True, cRL=True, mode="static_reach"),
+              no_com_box=dict(Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint="PREV", task_com=True, cTrunk=True,
+                              cFR=True, cFL=True, cRR=True, cRL=True, mode="static_reach"),
+              no_trunk=dict(FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=True, task_com=True, cCoM=True,
+                            cFR=True, cFL=True, cRR=True, cRL=True, mode="static_reach"))[variant]
+    cfgs = [wbc_model.make_config(m, **kw) for m in models]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=61 + i, with_rot=True) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    d["q"] = d["q"].copy()
+    d["q"][6, 2] = np.nan                       # the base height
+    d["q"][1001, 4] = np.inf                    # a quaternion component
+    d["ee_target"] = d["ee_target"].copy()
+    d["ee_target"][2007, 4, 1] = np.nan         # the gripper target
+    ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
+    bad = np.zeros(B, bool)
+    bad[[6, 1001, 2007]] = True
+    assert (ref["status"][bad] != 0).all() and (ref["status"][~bad] == 0).mean() > 0.97
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    got = bt.tick(d, DT, want_q_next=True)
+    assert bt.stat("last_path") == 3 and bt.stat("last_orth") == 1     # the default policy: packed from 4608 instances on
+    ok = ref["status"] == 0
+    mism = np.nonzero((got["status"] != ref["status"]) & ~bad)[0]
+    assert mism.size == 0, (mism[:10], got["status"][mism[:10]], ref["status"][mism[:10]])     # infeasible trunk boxes included
+    assert (got["status"][bad] != 0).all()                             # (which code a NaN ends in is the path's own business)
+    assert (got["qdot"][~ok] == 0).all() and np.isfinite(got["qdot"]).all()
+    err = np.abs(got["qdot"] - ref["qdot"])[ok].max()
+    nd = bt.stat("deferred_last")
+    print("packed orth kernel with inequality rows, %s, mixed batch: qdot max-abs err %.3e, working-set changes %.2f (oracle %.2f), %d instances redone in the tail, infeasible %d" % (
+        variant, err, got["iters"][ok].mean(), ref["iters"][ok].mean(), nd, int((ref["status"] == 2).sum())))
+    assert err < QDOT_TOL and np.abs(got["q_next"] - ref["q_next"])[ok].max() < 1e-7
+    assert nd <= 0.02 * B
+    assert (got["iters"] == ref["iters"])[ok & (mid == 0)].mean() > 0.98
+    assert (got["iters"] + 1 == ref["iters"])[ok & (mid == 1)].mean() > 0.98   # (the oracle also counts px100's padded 26th DoF, a locked bound)
+    bt.set_option("packed_orth", 0)
+    one = bt.tick(d, DT)
+    assert bt.stat("last_path") == 0 and np.abs(one["qdot"] - got["qdot"])[ok].max() < 1e-6 and (one["status"] == got["status"])[~bad].all()
+    bt.close()
+
+
 @pytest.mark.parametrize("variant", ["warm_up", "prev_no_trunk", "three_tasks"])
 def test_packed_box_kernel_variants_and_non_finite_inputs(wx200, px100, variant):
     """wbc_tick_boxp_kernel (task problems without constraint rows, four per wavefront, base + one thigh eliminated by a Schur complement):
@@ -1116,8 +1169,8 @@ def test_gpu_solution_against_the_exact_optimum(wx200, px100, cfg_name, with_rot
         assert {(2, 0), (1, 0), (0, 0)} <= paths          # packed, one-instance compact, general
     if cfg_name in ("c2", "everything"):
         assert {(0, 1), (0, 0)} <= paths                  # orthonormal presolve, full size
-    if cfg_name == "c2":
-        assert (3, 1) in paths                            # the packed orth kernel
+    if cfg_name in ("c2", "everything"):
+        assert (3, 1) in paths                            # the packed orth kernel (configs[1]) / its INEQ variant ("everything")
     if cfg_name == "full":
         assert {(4, 0), (0, 0)} <= paths                  # the packed box kernel, full size
         assert worst[((1, 1, 1, 1), (4, 0))] < 1e-9      # the Schur complement conditions the problem: the packed path is the MOST accurate one
