@@ -1002,6 +1002,21 @@ def test_packed_orth_kernel_with_inequality_rows(wx200, px100, variant):
     assert nd <= 0.02 * B
     assert (got["iters"] == ref["iters"])[ok & (mid == 0)].mean() > 0.98
     assert (got["iters"] + 1 == ref["iters"])[ok & (mid == 1)].mean() > 0.98   # (the oracle also counts px100's padded 26th DoF, a locked bound)
+    if variant == "everything":   # a short closed-loop roll-out stays on the packed kernels too (cold ticks: the INEQ variant carries no working sets)
+        K = 3
+        clean = {k: (v[~bad] if isinstance(v, np.ndarray) and v.shape[0] == B else v) for k, v in d.items()}
+        Bc = int((~bad).sum())
+        rro = oracle.rollout(models, cfgs, clean, DT, Bc, K, nthreads=8)
+        bt2 = WbcBatch(models, Bc)
+        for i, c in enumerate(cfgs):
+            bt2.configure(c, i)
+        bt2.set_option("warm_start", 0)
+        bt2.set_option("packed_orth", 2)
+        gro = bt2.rollout(clean, DT, K)
+        assert bt2.stat("last_path") == 3 and bt2.stat("last_update_packed") == 1
+        okr = rro["status"] == 0
+        assert (gro["status"] == rro["status"]).all() and np.abs(gro["q"] - rro["q"])[okr].max() < 1e-6
+        bt2.close()
     bt.set_option("packed_orth", 0)
     one = bt.tick(d, DT)
     assert bt.stat("last_path") == 0 and np.abs(one["qdot"] - got["qdot"])[ok].max() < 1e-6 and (one["status"] == got["status"])[~bad].all()
