@@ -5597,9 +5597,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
         a0[0] = lin0[2] + wxp[2]; a0[1] = ang0[0]; a0[2] = ang0[1]; a0[3] = ang0[2];
       }
       if (c_con_com) { a0[4] = jc0[0]; a0[5] = jc0[1]; a1[4] = has1 ? jc1[0] : 0.0; a1[5] = has1 ? jc1[1] : 0.0; }
-      block(a0, a1, zr, -1, true, true, false);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) rowreg[i] = AZ[s + 16 * i];           // (kept in registers: X is the sweep's and then J's)
+      block(a0, a1, zr, -1, true, true, false);          // (the images stay in AZ through the sweep, which leaves X alone)
     }
     // bounds: the velocity damper of this lane's two DoF (:572-637) goes to its row of Z (base / stance leg) or to its reduced variable (arm); the
     // trunk box's and the CoM box's sides to rows 0..5
@@ -5646,8 +5644,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     WSYNC();
     if (D0.bl >= 0) { rbl[6 + D0.bl] = l0; rbu[6 + D0.bl] = u0; } else if (D0.red >= 6) { vbl[D0.red & 15] = l0; vbu[D0.red & 15] = u0; }
     if (has1) { if (D1.bl >= 0) { rbl[6 + D1.bl] = l1; rbu[6 + D1.bl] = u1; } else if (D1.red >= 6) { vbl[D1.red & 15] = l1; vbu[D1.red & 15] = u1; } }
-    WSYNC();
-    lb = vbl[s]; ub = vbu[s]; clb0 = rbl[s]; cub0 = rbu[s]; clb1 = rbl[16 + s]; cub1 = rbu[16 + s];
+    // (rows and bounds wait in LDS — X beyond AZ, pf | ow — until the QP: read into registers before the sweep they were spilled across it,
+    //  ~1.3 KB of scratch traffic per tick)
   }
   QSTOP(5, h[0] + h[5] + h[13] + gacc);
   // posture rows (qpJointA / qpJointb, :1199-1268): Z'(d^2 I)Z = d^2 I; the target's part of g through Z
@@ -5739,6 +5737,13 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     double* const qyv = I.gp;
     double* const qtv = I.gp + 16;
     WSYNC();
+    {
+      const double* rbl = I.X + 204; const double* rbu = I.X + 236;
+      lb = I.pf[s]; ub = I.ow[s]; clb0 = rbl[s]; cub0 = rbu[s]; clb1 = rbl[16 + s]; cub1 = rbu[16 + s];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) rowreg[i] = I.X[108 + s + 16 * i];
+    }
+    WSYNC();                                 // (everything the QP's matrices overwrite has been read)
     if (s < QPV) {
 #pragma unroll
       for (int k = 0; k < QPV; k += 2) sts2(J + s * QLD + k, y[k], y[k + 1]);
