@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Where the packed orth kernel's time goes (BASELINE configs[1] at B = 65536), by ablation: option "dbg_stop" = 200 + k of the -DWBC_ABLATE
+"""Where the packed orth kernel's time goes (BASELINE configs[1] at B = 65536; or, second argument, tests/common.py "everything": its INEQ variant), by ablation: option "dbg_stop" = 200 + k of the -DWBC_ABLATE
 build cuts wbc_tick_orthp_kernel after stage k; stage k costs T(k) - T(k - 1). Same occupancy as the product; read shares.
-    python3 tools/ablate_orthp.py [B]"""
+    python3 tools/ablate_orthp.py [B] [c2 | everything]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "mech5845m-wbc-for-legged-manipulator_amd")
@@ -13,8 +13,14 @@ import wbc_model, wbc_workload
 from wbc_batch import WbcBatch
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+name = sys.argv[2] if len(sys.argv) > 2 else "c2"          # "everything": the kernel's INEQ variant (the cuts are the same stages)
 model = wbc_model.load_model("a1_wx200")
-cfg = wbc_model.equality_only_config(model)
+if name == "c2":
+    cfg = wbc_model.equality_only_config(model)
+else:
+    sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+    import common
+    cfg = common.config(name, model)
 bt = WbcBatch(model, B)
 bt.configure(cfg)
 bt.set_option("packed_orth", 2)      # (also below the batch-size policy's threshold: B = 1024 shows one wave's latency, stage by stage)
@@ -24,7 +30,7 @@ class FK:
         return bt.fk(q, want=("oMf",))["oMf"]
     def com(_, q):
         return bt.fk(q, want=("com",))["com"]
-d = wbc_workload.make_tick_inputs(model, cfg, B, 5, FK())
+d = wbc_workload.make_tick_inputs(model, cfg, B, 5, FK()) if name == "c2" else common.tick_inputs(model, cfg, B, 5, with_rot=True)
 dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d.items()}
 out = dict(qdot=torch.zeros((B, 26), dtype=torch.float64, device="cuda"), status=torch.zeros(B, dtype=torch.int32, device="cuda"),
            iters=torch.zeros(B, dtype=torch.int32, device="cuda"))
