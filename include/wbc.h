@@ -327,7 +327,7 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          of waves covers the batch and the one-instance kernel's shorter dependent chain wins (25 vs 55 us at
  *                          B = 1024, equal at 4096, 0.29 vs 0.78 ms at 65536); 2: at every batch size; 0: never. Its INEQ variant covers
  *                          the same task problems WITH inequality rows (trunk box, CoM box, the velocity box — rows of Z in the reduced
- *                          coordinates, two per lane — and the trunk task: tests' "everything", 0.58 vs 1.24 ms at 65536), cold starts only.
+ *                          coordinates, two per lane — and the trunk task: tests' "everything", 0.58 vs 1.24 ms at 65536), cold or hot-started.
  *   "packed_box"       [1] the task problems WITHOUT constraint rows (the warm-up problem of setInitialState, Robot_Wrapper4.py:196-351:
  *                          trunk / EE tasks + posture Tikhonov / PREV, velocity box only) run FOUR instances per wavefront on
  *                          wbc_tick_boxp_kernel: the base and, where 16 lanes do not hold the rest, the limb DoF with the widest box are

@@ -865,7 +865,6 @@ static bool orthp_eligible(const WbcBatch* b, const KernelArgs& a) {
   if (!b->packed_orth || !b->packed_kernel || !b->presolve || !b->presolve_orth || b->n_models < 1 || b->jtj_mfma > 0) return false;
   if (a.in.q_con || a.in.posture_u || b->dbg_alias || (b->dbg_stop > 0 && b->dbg_stop < 200)) return false;   // (dbg_stop 201.. cuts this kernel; working sets: nothing to seed, an empty set out)
   for (int i = 0; i < b->n_models; ++i) if (!b->plan_host[i].q_ok || b->plan_host[i].q_ok != b->plan_host[0].q_ok) return false;
-  if (b->plan_host[0].q_ok == 2 && (a.ws_in || a.ws_out)) return false;      // (the INEQ variant carries no working sets)
   return true;
 }
 // the packed box kernel: every plan x_ok, nothing passed that it does not read; packed_box: 1 (default) from WBC_BOXP_MIN_BATCH instances on, 2: always.

@@ -5124,9 +5124,11 @@ constexpr int WT_W = 0, WT_w = 30, WT_G = 35, WT_CW = 78, WT_CG = 81;   // offse
 // Robot_Wrapper4.py:707-754), CoM box (CoMConstraint, :669-694), the velocity box of every DoF (:572-637) — and the trunk task (tests/common.py
 // "everything"). In the reduced coordinates y (qd = Z y) the velocity bounds of the base and the stance legs are the ROWS of Z (six columns each),
 // the trunk and CoM boxes six dense rows (formed with the task blocks' own A Z machinery), the arm's bounds stay simple bounds: <= 24 rows, two per
-// lane, and the packed sim3 kernel's dual active-set method on n' <= 12 unknowns. Cold starts only; an instance that needs more than 11 active
-// constraints goes to the tail with the flagged ones.
-template <bool INEQ>
+// lane, and the packed sim3 kernel's dual active-set method on n' <= 12 unknowns. An instance that needs more than 11 active constraints goes to
+// the tail with the flagged ones.
+// WARM (INEQ only): working sets in and out — the packed sim3 kernel's scheme (seeds through the add step, x / u rebuilt from the factors, restoration).
+// In FULL-problem indexing a row of Z is the velocity bound of its DoF (word 0), the trunk / CoM box rows are findConstraints' rows (word 1).
+template <bool INEQ, bool WARM = false>
 __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                                const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   __shared__ union { QInst Q[4]; Smem G; } SU;
@@ -5141,6 +5143,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
   const WbcConfig& cfg = cfgs[mid];
   const DevPlan& P = plans[mid];
   const double dt = A.dt, inv_dt = 1.0 / A.dt;
+  const unsigned long long ws_mine = (INEQ && WARM && s < 2 && A.ws_in && valid) ? A.ws_in[2 * (size_t)b + s] : 0ull;   // (lane 0: bounds, lane 1: rows)
+  unsigned long long ws_o0 = 0ull, ws_o1 = 0ull;
   // ---- loads: inputs (coalesced per instance), then the per-lane records
   {
     const double* qg = A.in.q + (size_t)b * NQ;
@@ -5906,6 +5910,117 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
         ++q;
       }
     };
+    if (WARM) {
+      // ================================ warm start (the packed sim3 kernel's scheme) ====================================================
+      const unsigned long long ws0 = ((unsigned long long)(unsigned)bpermi((int)(ws_mine >> 32), rbase) << 32) | (unsigned)bpermi((int)(unsigned)ws_mine, rbase);
+      const unsigned long long ws1 = ((unsigned long long)(unsigned)bpermi((int)(ws_mine >> 32), rbase + 1) << 32) | (unsigned)bpermi((int)(unsigned)ws_mine, rbase + 1);
+      auto bits = [](const unsigned long long w, const int i) -> int { return (int)(((w >> (i & 31)) & 1ull) | (((w >> (32 + (i & 31))) & 1ull) << 1)); };
+      const int tbase = c_con_com ? 2 : 0;   // findConstraints' order: CoM rows, then the trunk box
+      const int dofv = P.q_red2dof[s & 15], dofr0 = P.q_bl2dof[(s >= 6 ? s - 6 : 0) % 18], dofr1 = P.q_bl2dof[(10 + s) % 18];
+      int sb = (has_b && s >= 6) ? bits(ws0, dofv) : 0;
+      int sr0 = (s < 4) ? (c_con_trunk ? bits(ws1, tbase + s) : 0) : ((s < 6) ? (c_con_com ? bits(ws1, s - 4) : 0) : bits(ws0, dofr0));
+      int sr1 = has_r1 ? bits(ws0, dofr1) : 0;
+      if (sb == 3) sb = 0;
+      if (sr0 == 3) sr0 = 0;
+      if (sr1 == 3) sr1 = 0;
+      const double x0r = x;
+      WSYNC();
+      qxv[s] = has_b ? x : 0.0;
+      WSYNC();
+      const double near = 0.25 * fmax(1.0, -rmin16(has_b ? -fabs(x) : 0.0));
+      const double v0 = row_dot(s, qxv), v1 = has_r1 ? row_dot(16 + s, qxv) : 0.0;
+      const double slb = (sb == 2) ? ub - x : x - lb;
+      const double sl0 = (sr0 == 2) ? cub0 - v0 : v0 - clb0;
+      const double sl1 = (sr1 == 2) ? cub1 - v1 : v1 - clb1;
+      bool pend_b = searching && has_b && ((sb == 1 && lb > -QP_INF) || (sb == 2 && ub < QP_INF)) && (slb <= near);
+      bool pend_0 = searching && ((sr0 == 1 && clb0 > -QP_INF) || (sr0 == 2 && cub0 < QP_INF)) && (sl0 <= near);
+      bool pend_1 = searching && has_r1 && ((sr1 == 1 && clb1 > -QP_INF) || (sr1 == 2 && cub1 < QP_INF)) && (sl1 <= near);
+      bool seeded = false;
+#pragma unroll 1
+      for (;;) {                            // one seed per row and pass: bounds first, then rows 0..15, then rows 16..23; lowest index first
+        const unsigned mb = (unsigned)((__ballot(pend_b) >> rbase) & 0xFFFFull), m0 = (unsigned)((__ballot(pend_0) >> rbase) & 0xFFFFull),
+                       m1 = (unsigned)((__ballot(pend_1) >> rbase) & 0xFFFFull);
+        const bool seeding = (mb | m0 | m1) != 0u;
+        if (!__ballot(seeding)) break;
+        const int kind = mb ? 0 : (m0 ? 1 : 2);
+        const int idx = seeding ? __ffs((int)(kind == 0 ? mb : (kind == 1 ? m0 : m1))) - 1 : 0;
+        if (seeding && s == idx) { if (kind == 0) pend_b = false; else if (kind == 1) pend_0 = false; else pend_1 = false; }
+        const int my_side = ((kind == 0 ? sb : (kind == 1 ? sr0 : sr1)) == 2) ? 256 : 0;
+        const double my_n2 = (kind == 0) ? 1.0 : ((kind == 1) ? cn0 : cn1);
+        const int wsrc = rbase + idx;
+        const int wc = ((kind == 0 ? idx : 32 + 16 * (kind - 1) + idx) & 255) | bpermi(my_side, wsrc);
+        const double np2 = bperm(my_n2, wsrc);
+        const int ip = wc & 255;
+        const bool is_row = ip >= 32;
+        const int rr_ = is_row ? ip - 32 : 0;
+        const double sgn = (wc >> 8) ? -1.0 : 1.0;
+        double d = normal_d(is_row, rr_, ip, sgn);
+        if (!has_b || !seeding) d = 0.0;
+        WSYNC();
+        qdv[s] = d; qyv[s] = (s >= q) ? d : 0.0;
+        WSYNC();
+        const double zn = rsum16(s >= q ? d * d : 0.0);
+        const Zr zr = products(__ballot(seeding && q > 0) != 0);
+        const bool add = seeding && (zn > 100.0 * n * EPS2 * jf2 * np2) && q < QTC;      // (a dependent seed, or one more than T holds, is simply not taken)
+        if (__ballot(add)) {
+          add_step(add, zn, zr, wc, 0.0);
+          if (add) { seeded = true; ++iters; }
+        }
+      }
+      // x, u from the factors: with s_j = b_j - n_j'x0 the slacks of the slots at x0:  w = T's,  x = x0 + J1 w,  u = T w
+      auto refresh = [&](const bool on) {
+        const int cc = a_code & 255;
+        const int rr = cc >= 32 ? cc - 32 : 0;
+        const double f_b = bperm(-slb, rbase + (cc & 15)), f_0 = bperm(-sl0, rbase + (rr & 15)), f_1 = bperm(-sl1, rbase + (rr & 15));   // (every lane takes part)
+        const double sj = (s < q) ? ((cc < 32) ? f_b : ((rr < 16) ? f_0 : f_1)) : 0.0;
+        WSYNC();
+        qdv[s] = sj;
+        WSYNC();
+        double w = 0.0;
+#pragma unroll
+        for (int j = 0; j < QTC; ++j) w = fma(T[j * QLD + sT], qdv[j], w);
+        WSYNC();
+        qyv[s] = (s < q && s < QTC) ? w : 0.0;
+        WSYNC();
+        double xa = 0.0, ua = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < QPV; kk += 2) {
+          const double2a j2 = lds2(J + sJ * QLD + kk), t2 = lds2(T + sT * QLD + kk), w2 = lds2(qyv + kk);
+          xa = fma(j2.x, w2.x, fma(j2.y, w2.y, xa)); ua = fma(t2.x, w2.x, fma(t2.y, w2.y, ua));
+        }
+        if (on) { x = has_b ? x0r + xa : 0.0; u = (s < q) ? ua : 0.0; }
+      };
+      if (__ballot(seeded)) {
+        refresh(seeded);
+        bool restoring = seeded, did = false, again = false;
+#pragma unroll 1
+        for (;;) {                          // RESTORATION: while a seeded multiplier is negative the most negative slot is dropped
+          const double um = rmin16((s < q) ? u : 0.0);
+          bool rest = restoring && (um < 0.0);
+          if (rest && ++iters > max_iter) { status = WBC_QP_MAX_ITER; rest = false; restoring = false; searching = false; }
+          if (!__ballot(rest)) {
+            if (!__ballot(restoring && did && !again)) break;
+            const bool on = restoring && did && !again;
+            refresh(on);
+            if (on) again = true;
+            continue;
+          }
+          const int l = rest ? __ffs((int)((__ballot(rest && s < q && u == um) >> rbase) & 0xFFFFull)) - 1 : 0;
+          const int lcode = bpermi(a_code, rbase + (l < 0 ? 0 : l));
+          drop_slot(rest, l < 0 ? 0 : l);
+          const int ip = lcode & 255;
+          const bool is_row = ip >= 32;
+          const int rr_ = is_row ? ip - 32 : 0;
+          double d = normal_d(is_row, rr_, ip, (lcode >> 8) ? -1.0 : 1.0);
+          if (!has_b || !rest) d = 0.0;
+          WSYNC();
+          qdv[s] = d; qyv[s] = (s >= q) ? d : 0.0;
+          WSYNC();
+          const Zr zr = products(__ballot(rest && q > 0) != 0);
+          if (rest) { x = fma(-um, zr.z, x); u = fma(um, zr.rv, u); did = true; }
+        }
+      }
+    }
 #pragma unroll 1
     for (;;) {
       WSYNC();
@@ -5990,6 +6105,19 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
       const unsigned long long om = __ballot(valid && overflow);
       if ((om >> rbase) & 0xFFFFull) { defer = true; live = false; }
     }
+    if (WARM && A.ws_out) {   // the final working set in FULL-problem indexing; an unsolved QP carries nothing
+      const int cc = a_code & 255, sd = (a_code >> 8) & 1;
+      const int rr = cc >= 32 ? cc - 32 : 0;
+      const int tbase = c_con_com ? 2 : 0;
+      const int dv_ = P.q_red2dof[cc & 15], dr_ = P.q_bl2dof[(rr >= 6 ? rr - 6 : 0) % 18];
+      if (status == WBC_QP_OPTIMAL && s < q) {
+        if (cc < 32) ws_o0 = 1ull << (32 * sd + (dv_ & 31));
+        else if (rr < 4) ws_o1 = 1ull << (32 * sd + tbase + rr);
+        else if (rr < 6) ws_o1 = 1ull << (32 * sd + (rr - 4));
+        else ws_o0 = 1ull << (32 * sd + (dr_ & 31));
+      }
+      ws_o0 = ror16(ws_o0); ws_o1 = ror16(ws_o1);
+    }
   }
   if (status == WBC_QP_OPTIMAL) {
     const unsigned long long bad = __ballot(s < n && !(fabs(x) <= 1.7976931348623157e308));
@@ -6025,7 +6153,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
   }
   // working sets (a hot-started tick / roll-out of these configurations stays on this kernel): the problem has no inequality, so a carried set
   // seeds nothing and the set handed on is empty — as the general kernel reports it, tail instances included
-  if (A.ws_out && valid && s < 2) A.ws_out[2 * (size_t)b + s] = 0ull;
+  if (A.ws_out && valid && s < 2 && !(INEQ && WARM && defer)) A.ws_out[2 * (size_t)b + s] = (INEQ && WARM) ? (s == 0 ? ws_o0 : ws_o1) : 0ull;   // (a deferred instance's set is the tail's)
   if (A.out.q_next) {   // jointVelocitiestoConfig (Robot_Wrapper4.py:440-441)
     WSYNC();
     if (INEQ) {                              // (the QP's T took the staged configuration's place)
@@ -6060,12 +6188,14 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
 #pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
       if (!((tailm >> (16 * rr)) & 1ull)) continue;
-      tail_instance<false, true>(&SU.G, 4 * (int)blockIdx.x + rr, models, cfgs, plans);
+      if (INEQ && WARM) tail_instance<true, false>(&SU.G, 4 * (int)blockIdx.x + rr, models, cfgs, plans);     // (the general kernel's warm path: full-size solve)
+      else tail_instance<false, true>(&SU.G, 4 * (int)blockIdx.x + rr, models, cfgs, plans);
     }
   }
 }
 template __global__ void wbc_tick_orthp_kernel<false>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
 template __global__ void wbc_tick_orthp_kernel<true>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
+template __global__ void wbc_tick_orthp_kernel<true, true>(const KernelArgs, const DevModel* __restrict__, const WbcConfig* __restrict__, const DevPlan* __restrict__);
 
 // ================================================================================================
 // The PACKED BOX kernel (round 3): FOUR instances per wavefront for the task problems WITHOUT constraint rows — the warm-up problem of
@@ -6974,7 +7104,8 @@ int launch_tick_sim3p(const KernelArgs& a, void* stream) {
   return check_launch("tick_sim3p");
 }
 int launch_tick_orthp(const KernelArgs& a, void* stream, int ineq) {
-  if (ineq) hipLaunchKernelGGL(wbc_tick_orthp_kernel<true>, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  if (ineq && (a.ws_in || a.ws_out)) hipLaunchKernelGGL((wbc_tick_orthp_kernel<true, true>), dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
+  else if (ineq) hipLaunchKernelGGL(wbc_tick_orthp_kernel<true>, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   else hipLaunchKernelGGL(wbc_tick_orthp_kernel<false>, dim3((a.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   return check_launch("tick_orthp");
 }

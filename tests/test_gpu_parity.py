@@ -1500,6 +1500,8 @@ def test_warm_started_tick_reaches_the_cold_optimum(wx200, px100, cfg_name):
     bt = WbcBatch(models, B)
     for i, c in enumerate(cfgs):
         bt.configure(c, i)
+    if cfg_name == "everything":
+        bt.set_option("packed_orth", 2)                                # (B = 2048: the default policy would keep it on the one-instance kernel) -> the INEQ variant, WARM
     # "previous tick": the same robots a moment earlier (targets 0.3 mm back)
     prev = dict(d)
     prev["ee_target"] = d["ee_target"] - 3e-4
@@ -1544,6 +1546,28 @@ def test_warm_started_tick_reaches_the_cold_optimum(wx200, px100, cfg_name):
         its["general-path set into the compact kernel"] = back["iters"][ok].mean()
         same = (gen_cold["working_set"][ok] == cold["working_set"][ok]).all(axis=1).mean()
         assert same > 0.95, same                                           # both paths name the active constraints alike
+    if cfg_name == "everything":
+        assert bt.stat("last_path") == 3                               # working sets in and out on the packed orth kernel's INEQ variant
+        bt.set_option("packed_orth", 0)                                # ... and the general kernel names the same constraints
+        gen_cold = bt.tick(d, DT, want_working_set=True)
+        assert bt.stat("last_path") == 0
+        gen = bt.tick(dict(d, working_set=cold["working_set"]), DT, want_working_set=True)
+        assert np.abs(gen["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL and (gen["status"] == ref["status"]).all()
+        bt.set_option("packed_orth", 2)
+        back = bt.tick(dict(d, working_set=gen_cold["working_set"]), DT, want_working_set=True)
+        assert bt.stat("last_path") == 3 and np.abs(back["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
+        its["general-path set into the packed kernel"] = back["iters"][ok].mean()
+        lock = np.where(mid == 0, (7 << 23) | (7 << (32 + 23)), (7 << 22) | (7 << (32 + 22)))     # (the general path also names the DoF the box locks at 0)
+        same = (((gen_cold["working_set"][ok][:, 0] & ~lock[ok]) == (cold["working_set"][ok][:, 0] & ~lock[ok])) &
+                ((gen_cold["working_set"][ok][:, 1] & 0x3F0000003F) == (cold["working_set"][ok][:, 1] & 0x3F0000003F))).mean()
+        print("   packed and general kernel name the same active set on %.4f of the instances" % same)
+        assert same > 0.95, same
+    if cfg_name == "c2":
+        bt.set_option("packed_orth", 2)                                # (B = 2048: the default policy keeps small batches on the one-instance kernel)
+        got = bt.tick(dict(d, working_set=junk), DT, want_working_set=True)
+        assert bt.stat("last_path") == 3                               # working sets do not send configs[1] off the packed orth kernel:
+        assert (got["working_set"] == 0).all()                         # no inequality to seed, an empty set out
+        assert (got["status"] == ref["status"]).all() and np.abs(got["qdot"] - ref["qdot"])[ok].max() < QDOT_TOL
     if cfg_name == "full":
         assert bt.stat("last_path") == 4                               # a working set was passed: the packed box kernel's WARM variant
         bt.set_option("packed_box", 0)                                 # ... and the general kernel names the same bounds
