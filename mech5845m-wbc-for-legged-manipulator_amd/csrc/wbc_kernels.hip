@@ -5793,7 +5793,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
       const unsigned long long nb = __ballot(status != WBC_QP_OPTIMAL);
       if ((nb >> rbase) & 0xFFFFull) status = WBC_QP_NUMERICAL;
     }
-    bool act_b = false, act0 = false, act1 = false, overflow = false;
+    int actm = 0;                             // bit 0: this lane's bound is active, bit 1: its row s, bit 2: its row 16 + s (ONE register: three bools
+                                              // set through a selected reference lived in scratch, a flat store per working-set change)
+    bool overflow = false;
     double u = 0.0;
     int a_code = 0, q = 0;
     const int max_iter = 10 * (n + 24) + 20;
@@ -5815,8 +5817,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
       return d;
     };
     auto set_act = [&](const int code, const bool val) {
-      if (code >= 32) { const int rr = code - 32; if (s == (rr & 15)) { if (rr < 16) act0 = val; else act1 = val; } }
-      else if (s == code) act_b = val;
+      const int rr = code - 32;
+      const int bit = (code >= 32) ? ((rr < 16) ? 2 : 4) : 1;
+      const bool mine = (code >= 32) ? (s == (rr & 15)) : (s == code);
+      if (mine) actm = val ? (actm | bit) : (actm & ~bit);
     };
     auto drop_slot = [&](const bool dr, const int l_) {
       const int l = dr ? l_ : 0;
@@ -6028,16 +6032,16 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
       WSYNC();
       double best = 0.0; int code = -1;
       double cand_b = 0.0, cand_n2 = 1.0;
-      if (has_b && !act_b) {
+      if (has_b && !(actm & 1)) {
         if (lb > -QP_INF) { const double sl = x - lb; if (sl < -1e-9 * fmax(1.0, fabs(lb)) && sl < best) { best = sl; code = s; cand_b = lb; } }
         if (ub < QP_INF) { const double sl = ub - x; if (sl < -1e-9 * fmax(1.0, fabs(ub)) && sl < best) { best = sl; code = s | 256; cand_b = -ub; } }
       }
-      if (!act0) {
+      if (!(actm & 2)) {
         const double v = row_dot(s, qxv);
         if (clb0 > -QP_INF) { const double sl = v - clb0; if (sl < -1e-9 * fmax(1.0, fabs(clb0)) && sl < best) { best = sl; code = 32 + s; cand_b = clb0; cand_n2 = cn0; } }
         if (cub0 < QP_INF) { const double sl = cub0 - v; if (sl < -1e-9 * fmax(1.0, fabs(cub0)) && sl < best) { best = sl; code = (32 + s) | 256; cand_b = -cub0; cand_n2 = cn0; } }
       }
-      if (has_r1 && !act1) {
+      if (has_r1 && !(actm & 4)) {
         const double v = row_dot(16 + s, qxv);
         if (clb1 > -QP_INF) { const double sl = v - clb1; if (sl < -1e-9 * fmax(1.0, fabs(clb1)) && sl < best) { best = sl; code = 48 + s; cand_b = clb1; cand_n2 = cn1; } }
         if (cub1 < QP_INF) { const double sl = cub1 - v; if (sl < -1e-9 * fmax(1.0, fabs(cub1)) && sl < best) { best = sl; code = (48 + s) | 256; cand_b = -cub1; cand_n2 = cn1; } }
