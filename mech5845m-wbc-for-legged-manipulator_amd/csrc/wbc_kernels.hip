@@ -4510,7 +4510,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   }
   PSTOP(5, x + cn2 + jf2);
   // ---- dual active-set iterations (per-row state; loops run until every row of the wave is done)
-  bool act_b = false, act_r = false;
+  int actm = 0;                             // bit 0: this lane's bound is in the working set, bit 1: its row (ONE register: as two bools assigned under
+                                            // selected conditions they lived in scratch — two byte loads in every violation scan, a store per change)
   double u = 0.0;
   int a_code = 0, q = 0, iters = 0;
   const int max_iter = 10 * (n + p) + 20;
@@ -4529,7 +4530,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   auto drop_slot = [&](const bool dr, const int l_) {
     const int l = dr ? l_ : 0;
     const int lc = bpermi(a_code, rbase + l) & 255;
-    if (dr) { if (lc >= n) { if (s == lc - n) act_r = false; } else { if (s == lc) act_b = false; } }
+    if (dr && s == ((lc >= n) ? lc - n : lc)) actm &= (lc >= n) ? ~2 : ~1;
     WSYNC();
     V.yv[s] = u; V.tv[s] = (double)a_code;
     WSYNC();
@@ -4622,7 +4623,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       const double idel = (zr.dq >= 0.0) ? -rsz : rsz;
       if (s < q) T[s * PLD + q] = -zr.rv * idel;
       if (s == q) { T[s * PLD + q] = idel; u = u_new; a_code = wc; }
-      if (is_row) { if (s == rr_) act_r = true; } else { if (s == (ip & 15)) act_b = true; }
+      if (s == (is_row ? rr_ : (ip & 15))) actm |= is_row ? 2 : 1;
       ++q;
     }
   };
@@ -4752,11 +4753,11 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     WSYNC();
     double best = 0.0; int code = -1;
     double cand_b = 0.0, cand_n2 = 1.0;    // bound value (signed by side) and |normal|^2 of this lane's candidate: fetched with its code in ONE round
-    if (has_b && !act_b) {
+    if (has_b && !(actm & 1)) {
       if (lb > -QP_INF) { const double sl = x - lb; if (sl < -1e-9 * fmax(1.0, fabs(lb)) && sl < best) { best = sl; code = s; cand_b = lb; } }
       if (ub < QP_INF) { const double sl = ub - x; if (sl < -1e-9 * fmax(1.0, fabs(ub)) && sl < best) { best = sl; code = s | 256; cand_b = -ub; } }
     }
-    if (has_r && !act_r) {
+    if (has_r && !(actm & 2)) {
       const double2a c0 = lds2(I.Cq + s * 6), c1 = lds2(I.Cq + s * 6 + 2), c2 = lds2(I.Cq + s * 6 + 4);
       const double2a x0 = lds2(V.xv), x1 = lds2(V.xv + 2), x2 = lds2(V.xv + 4);
       const double v = fma(c0.x, x0.x, fma(c0.y, x0.y, fma(c1.x, x1.x, fma(c1.y, x1.y, fma(c2.x, x2.x, c2.y * x2.y)))));
