@@ -200,7 +200,8 @@ class GpuEngine:
 
     def other_configs(self):
         """Context for the headline (not bench lines): BASELINE configs[1] (five EE tasks + CoM task, contact equalities, no
-        velocity box) at its own batch 1024 and at 65536, and the warm-up problem at 65536 — each on the kernel the library picks."""
+        velocity box) at its own batch 1024 and at 65536, the warm-up problem and the tests' all-tasks / all-constraints stack at 65536 —
+        each on the kernel the library picks."""
         import wbc_model
         import wbc_workload
         from wbc_batch import WbcBatch
@@ -209,7 +210,10 @@ class GpuEngine:
         # (name, configuration, batch sizes): BASELINE configs[1], and the warm-up problem of setInitialState (Robot_Wrapper4.py:196-351, SURVEY §8 f4:
         #  six Cartesian tasks + Tikhonov, velocity box only — 2000 of these per robot)
         cases = (("c2", wbc_model.equality_only_config(self.model), (1024, 65536)),
-                 ("warmup", wbc_model.make_config(self.model, Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=True), (65536,)))
+                 ("warmup", wbc_model.make_config(self.model, Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint=True), (65536,)),
+                 # every task and every constraint type at once (tests/common.py "everything": coverage, not a reference preset)
+                 ("everything", wbc_model.make_config(self.model, Trunk=True, FR=True, FL=True, RR=True, RL=True, Grip=True, Joint="PREV", task_com=True, cCoM=True,
+                                                      cTrunk=True, cFR=True, cFL=True, cRR=True, cRL=True, mode="static_reach"), (65536,)))
         for name, cfg, B in ((n_, c_, b_) for n_, c_, bs in cases for b_ in bs):
             bt = WbcBatch(self.model, B, device_id=self.dev.index)
             bt.configure(cfg)
@@ -238,7 +242,8 @@ class GpuEngine:
             path = bt.stat("last_path")
             out["%s_B%d" % (name, B)] = {"ticks_per_s": B / ms * 1e3, "ms_per_step": ms, "task_rows": bt.task_rows, "constraint_rows": bt.constraint_rows,
                                          "optimal_frac": float((dev_out["status"] == 0).double().mean().item()),
-                                         "kernel_path": "wbc_tick_orthp_kernel (packed: four instances per wavefront)" if path == 3 else
+                                         "kernel_path": ("wbc_tick_orthp_kernel<INEQ> (packed: four instances per wavefront)" if bt.constraint_rows > 12 else
+                                                         "wbc_tick_orthp_kernel (packed: four instances per wavefront)") if path == 3 else
                                                         "wbc_tick_boxp_kernel (packed: four instances per wavefront)" if path == 4 else
                                                         ("wbc_tick_kernel<MODE_TICK, ORTH>" if bt.stat("last_orth") else "wbc_tick_kernel<MODE_TICK>")}
             bt.close()
