@@ -5,8 +5,11 @@ A "step" is ONE pass of the fused hot path (wbc_tick: FK -> Jacobians -> task st
 over one batch of synthetic robot states already resident in HBM. Workload (config.workload): BASELINE configs[2],
 "Batch=65536 A1+wx200 with 4-foot contact + ... inequalities, 1 MI355X" = SURVEY.md §8(d) C3: the reference's sim3
 switch set (Grip task + posture; 12 contact equalities, 4 trunk-box rows, 26 velocity-damper bounds, 3 locked DoF).
-With --gpus N (launched under torch.distributed.run) every rank runs its own 65536-instance shard on its own GPU —
-no data-path collective — and the job value is the sum: scaling "weak".
+With --gpus N every rank runs its own 65536-instance shard on its own GPU — no data-path collective —
+and the job value is the sum: scaling "weak". Ranks: either torch.distributed.run starts them (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment), or — a plain `python bench.py --gpus N` — this process starts N fresh child
+interpreters itself (`launch_ranks`: the parent never imports torch or touches a GPU, no exec), forwards rank 0's JSON
+line and returns the worst child's exit code.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R] [--batch B] [--no-cpu-baseline]
 
@@ -178,7 +181,7 @@ class GpuEngine:
         return {k: v.cpu().numpy() for k, v in self.dev_out.items()}
 
     def path(self):
-        return {2: "wbc_tick_sim3p_kernel (packed: four instances per wavefront; + wbc_tick_deferred_kernel)",
+        return {2: "wbc_tick_sim3p_kernel (packed: four instances per wavefront; one kernel per tick, what it cannot reduce is redone in its own tail)",
                 1: "wbc_tick_sim3_kernel (+ wbc_tick_deferred_kernel)"}.get(self.bt.stat("last_path"), "wbc_tick_kernel<MODE_TICK>")
 
     def closed_loop(self, host_in, ticks):
@@ -393,13 +396,25 @@ def main(argv=None):
                     help="posture mode of the tick (default PREV = the BASELINE workload; HYBRID is what sim3.py:145 sets)")
     args = ap.parse_args(argv)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:     # plain `python bench.py --gpus N`: be the launcher
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-    engine = GpuEngine(args, local)
-    comm = Comm("nccl", rank, world, engine.dev)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's world size and --gpus must agree" % (args.gpus, world))
+    stub = os.environ.get("WBC_BENCH_ENGINE_STUB")           # tests only ("file.py:Class"): CPU ranks over gloo, the line says so in config.engine
+    if stub:
+        import importlib.util
+        path, cls = stub.rsplit(":", 1)
+        spec = importlib.util.spec_from_file_location("bench_engine_stub", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        engine = getattr(mod, cls)(args, local)
+        comm = Comm("gloo", rank, world, None)
+    else:
+        engine = GpuEngine(args, local)
+        comm = Comm("nccl", rank, world, engine.dev)
     line, res = run_rank(args, comm, engine, make_inputs)
     ok = True
     if rank == 0:
@@ -421,6 +436,53 @@ def main(argv=None):
     engine.close()
     if not ok:
         raise SystemExit("bench.py: accuracy gate failed (see \"accuracy\" in the line above)")
+
+
+def launch_ranks(n, argv, timeout_s=None):
+    """`python bench.py --gpus N` without a launcher: start N fresh interpreters of this file, one per GPU, with the
+    environment torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free
+    MASTER_PORT), wait for all of them, and return the worst exit code. Rank 0 inherits stdout (its JSON line is the job's
+    line); the other ranks' stdout goes to stderr. This process never imports torch nor touches a GPU and never execs: the
+    children are ordinary child processes. If one rank dies the others (who would wait at the next barrier for ever) are
+    terminated by their exact PIDs."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    t0, worst = time.time(), 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0:
+                worst = worst or (rc if rc > 0 else 1)
+        failed = worst != 0 or (timeout_s is not None and time.time() - t0 > timeout_s)
+        if failed and alive:
+            time.sleep(5.0)                                  # let the others fail by themselves first (their own message is better)
+            for p in alive:
+                if p.poll() is None:
+                    p.terminate()
+            for p in alive:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            worst = worst or 1
+            alive = []
+    return worst
 
 
 if __name__ == "__main__":

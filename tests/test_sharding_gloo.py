@@ -51,46 +51,7 @@ def test_two_rank_shards_reproduce_the_single_process_batch(tmp_path):
     assert np.array_equal(got, ref)                                   # shards are independent: bit-identical
 
 
-class _OracleEngine:
-    """Stands in for bench.GpuEngine on a CPU rank: same interface, the tick is the oracle's."""
-    name = "oracle-cpu"
-
-    def __init__(self):
-        import common
-        self.model = common.models()[0]
-        self.cfg = common.config("c3", self.model)
-        self.options = {}
-        self.steps_run = 0
-
-    def fk(self, q):
-        import oracle
-        return oracle.fk([self.model], q, want_com=False)["oMf"]
-
-    def load(self, host_in):
-        self.inp = host_in
-
-    def step(self):
-        import oracle
-        B = self.inp["q"].shape[0]
-        self.out = oracle.tick([self.model], [self.cfg], self.inp, 0.002, B, want_q_next=False)
-        self.steps_run += 1
-
-    def sync(self):
-        pass
-
-    def timed_block(self, steps):
-        import time
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step()
-        ms = 1e3 * (time.perf_counter() - t0)
-        return lambda: ms
-
-    def results(self):
-        return self.out
-
-    def path(self):
-        return "oracle"
+from bench_engine_stub import OracleEngine as _OracleEngine  # noqa: E402  (the same stub `bench.py --gpus 2` is run with below)
 
 
 def _bench_worker(rank, world, port, out_dir):
@@ -146,3 +107,49 @@ def test_bench_rank_body_over_gloo(tmp_path):
         d = wbc_workload.make_tick_inputs(wx, cfg, 40, seed=r, fk=common.OracleFK([wx]), stress=True)
         assert np.array_equal(d["q"], z[r]["q"])
         assert np.array_equal(oracle.tick([wx], [cfg], d, 0.002, 40, want_q_next=False)["qdot"], z[r]["qdot"])
+
+
+def test_bench_command_line_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it (what the driver's scaling run types): the parent starts two fresh
+    child ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, no exec, no torch or GPU in the parent), forwards rank 0's
+    JSON line and exits with the worst child's code. CPU ranks: gloo + the oracle engine stub."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["WBC_BENCH_ENGINE_STUB"] = os.path.join(HERE, "bench_engine_stub.py") + ":OracleEngine"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "3",
+                        "--batch", "40"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                  # ONE line, rank 0's
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 80 and line["config"]["engine"] == "oracle-cpu"
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 80.0) < 1e-6
+    assert "cpu_baseline" not in line                                 # rank 0 at N = 1 only
+
+
+def test_bench_launcher_returns_the_worst_rank_exit_code(tmp_path):
+    """a rank that fails (here: an engine stub that does not exist) makes the launcher return non-zero instead of hanging"""
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["WBC_BENCH_ENGINE_STUB"] = os.path.join(str(tmp_path), "missing.py") + ":Nope"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_under_an_external_launcher_still_works(tmp_path):
+    """the torch.distributed.run path: WORLD_SIZE already set -> no children, this process IS a rank (world 1 here)"""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29563",
+               WBC_BENCH_ENGINE_STUB=os.path.join(HERE, "bench_engine_stub.py") + ":OracleEngine")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--repeats", "1",
+                        "--batch", "16", "--no-cpu-baseline", "--rollout-ticks", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["config"]["global_batch"] == 16
