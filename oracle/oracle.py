@@ -155,6 +155,36 @@ def qp_solve(H, g, C_=None, lb=None, ub=None, Clb=None, Cub=None, nthreads=1):
     return x, st, it
 
 
+def qp_solve_ls(A, b, C_=None, lb=None, ub=None, Clb=None, Cub=None, nthreads=1):
+    """QP(A, b, ...) as QP_Wrapper.py:10-53 takes it (H = A'A, g = -A'b formed inside, the refinement's residual from A and b);
+    A is [B][m][n] or [m][n]."""
+    A = _f64(A)
+    single = A.ndim == 2
+    m, n = A.shape[-2:]
+    A = A.reshape(-1, m, n)
+    B = A.shape[0]
+    b = _f64(b).reshape(B, m)
+    p = 0 if C_ is None else np.asarray(C_).shape[-2]
+    Cc = None if C_ is None else _f64(C_).reshape(B, p, n)
+    lb_, ub_ = (None if lb is None else _f64(lb).reshape(B, n)), (None if ub is None else _f64(ub).reshape(B, n))
+    cl, cu = (None if Clb is None else _f64(Clb).reshape(B, p)), (None if Cub is None else _f64(Cub).reshape(B, p))
+    x = np.zeros((B, n))
+    st = np.zeros(B, dtype=np.int32)
+    it = np.zeros(B, dtype=np.int32)
+    lib().orc_qp_ls_batch(C.c_int(B), C.c_int(n), C.c_int(p), C.c_int(m), _p(A), _p(b), _p(Cc), _p(lb_), _p(ub_), _p(cl), _p(cu),
+                          _p(x), _p(st), _p(it), C.c_int(nthreads))
+    if single:
+        return x[0], int(st[0]), int(it[0])
+    return x, st, it
+
+
+def set_refine_steps(k):
+    """iterative-refinement steps at the final working set (default 1; 0 = the plain dual method); returns the previous setting"""
+    old = lib().orc_get_refine_steps()
+    lib().orc_set_refine_steps(C.c_int(k))
+    return old
+
+
 def posture_target(models, cfgs, q, model_id=None, nthreads=1):
     """qpJointb MANI / HYBRID (Robot_Wrapper4.py:1220-1260) under cfgs[model].task_joint / posture_literal:
     returns (u [B,26], q_after [B,27])."""

@@ -573,27 +573,81 @@ static double con_value(const QpCons* Q, int c, const double* x) { /* a'x */
 
 #define QN 32 /* max n handled by the oracle QP */
 
-static int qp_solve_body(int n, int p, const double* H, const double* g, const double* C, const double* lb,
-                         const double* ub, const double* Clb, const double* Cub, double* x, int* iters_out);
+static int qp_solve_body(int n, int p, int m, const double* A, const double* bv, const double* H, const double* g, const double* C,
+                         const double* lb, const double* ub, const double* Clb, const double* Cub, double* x, int* iters_out);
+/* Iterative refinement at the final working set (QP_Wrapper.py:37 asks qpOASES for numRefinementSteps = 100; one step is what converges
+ * here). 0 switches it off (tests measure what it buys). */
+static int g_refine_steps = 1;
+void orc_set_refine_steps(int k) { g_refine_steps = k < 0 ? 0 : k; }
+int orc_get_refine_steps(void) { return g_refine_steps; }
 /* Contract for a QP that was not solved (iteration cap, infeasible, numerical): x = 0. The reference ignores qpOASES'
  * return value; qpOASES' getPrimalSolution() does not write its argument unless the QP is solved, so xOpt keeps what it
  * held — zeros on the first QP (QP_Wrapper.py:50), the previous tick's answer afterwards (QP_Wrapper.py:71-73). The batched
  * path has no "previous answer" per call: it returns the first-call value, 0 (hold still), and the mirrors keep the stale
  * vector like the reference. */
+int orc_qp_solve_ls(int n, int p, int m, const double* A, const double* bv, const double* H, const double* g, const double* C,
+                    const double* lb, const double* ub, const double* Clb, const double* Cub, double* x, int* iters_out);
 int orc_qp_solve(int n, int p, const double* H, const double* g, const double* C, const double* lb,
                  const double* ub, const double* Clb, const double* Cub, double* x, int* iters_out) {
+  return orc_qp_solve_ls(n, p, 0, 0, 0, H, g, C, lb, ub, Clb, Cub, x, iters_out);
+}
+/* The same QP with its least-squares data: H = A'A, g = -A'b as QP_Wrapper.py:17-18 forms them, A (m x n) and b kept for the
+ * refinement's residual (see qp_refine). */
+int orc_qp_solve_ls(int n, int p, int m, const double* A, const double* bv, const double* H, const double* g, const double* C,
+                    const double* lb, const double* ub, const double* Clb, const double* Cub, double* x, int* iters_out) {
   int st = -1;
   for (int i = 0; i < n; ++i) if ((lb && lb[i] != lb[i]) || (ub && ub[i] != ub[i])) st = WBC_QP_NUMERICAL;   /* NaN bound: refuse */
   for (int i = 0; i < p; ++i) if (Clb[i] != Clb[i] || Cub[i] != Cub[i]) st = WBC_QP_NUMERICAL;
-  if (st < 0) st = qp_solve_body(n, p, H, g, C, lb, ub, Clb, Cub, x, iters_out);
+  if (st < 0) st = qp_solve_body(n, p, m, A, bv, H, g, C, lb, ub, Clb, Cub, x, iters_out);
   else if (iters_out) *iters_out = 0;
   if (st == WBC_QP_OPTIMAL)
     for (int i = 0; i < n; ++i) if (!(fabs(x[i]) <= 1.7976931348623157e308)) st = WBC_QP_NUMERICAL;   /* NaN / Inf: never "optimal" */
   if (st != WBC_QP_OPTIMAL) for (int i = 0; i < n; ++i) x[i] = 0.0;
   return st;
 }
-static int qp_solve_body(int n, int p, const double* H, const double* g, const double* C, const double* lb,
-                         const double* ub, const double* Clb, const double* Cub, double* x, int* iters_out) {
+/* One step of iterative refinement at the final working set W (normals n_k, right-hand sides b_k, multipliers u_k >= 0 with
+ * grad f(x) = sum u_k n_k at the optimum). QP_Wrapper.py:37 sets qpOASES' numRefinementSteps = 100; this is its analogue for the
+ * dual method's factors J = L^-T Q (J J' = H^-1; J' n_k = column k of [R; 0]):
+ *     r1 = -(grad f(x) - sum u_k n_k),   r2_k = b_k - n_k'x,
+ *     dx = J1 R^-T r2 + J2 J2' r1        (the KKT correction H dx - N'du = r1, N dx = r2 solved through the factors).
+ * The residual comes from the UNFACTORED data. With the least-squares data at hand (the tick: H = A'A, g = -A'b, QP_Wrapper.py:17-18)
+ * grad f = A'(A x - b) is formed as two products — it never sees the rounding of H. That is the point: on the benchmark tick the
+ * posture rows weigh (0.001/26)^2 = 1.5e-9 against O(1) task rows (Robot_Wrapper4.py:1202-1204, 1437), so fl(A'A) carries that
+ * block with 1e-5 relative error and the EXACT optimum of the rounded (H, g) already sits 1e-7 .. 1e-6 away from the exact optimum
+ * of the least-squares problem (and from the exact optimum of any other rounding of H: numpy's, the device's). A residual from H
+ * (the only choice for QP(H, g): orc_qp_solve) converges to the former and gains little; the least-squares residual converges to
+ * the latter, which every implementation shares to ~cond(A) eps = 1e-11 (tests/test_oracle_qp.py measures both). */
+static void qp_refine(int n, int q, int m, const double* A, const double* bv, const double* H, const double* g, const QpCons* Q,
+                      double J[QN][QN], double R[QN][QN], const int* act, const int* act_side, const double* u, double* x) {
+  double r1[QN], r2[QN], dy[QN], np[QN];
+  if (A && m > 0) {                                   /* r1 = A'(b - A x) */
+    for (int i = 0; i < n; ++i) r1[i] = 0;
+    for (int r = 0; r < m; ++r) {
+      double e = bv[r];
+      for (int k = 0; k < n; ++k) e -= A[(size_t)r * n + k] * x[k];
+      for (int k = 0; k < n; ++k) r1[k] += A[(size_t)r * n + k] * e;
+    }
+  } else {                                            /* r1 = -(H x + g) */
+    for (int i = 0; i < n; ++i) { double s = g[i]; for (int k = 0; k < n; ++k) s += H[i * n + k] * x[k]; r1[i] = -s; }
+  }
+  for (int k = 0; k < q; ++k) {
+    con_normal(Q, act[k], act_side[k], np);
+    const double bk = act_side[k] ? -con_hi(Q, act[k]) : con_lo(Q, act[k]);
+    double s = bk;
+    for (int i = 0; i < n; ++i) { s -= np[i] * x[i]; r1[i] += u[k] * np[i]; }
+    r2[k] = s;
+  }
+  for (int k = 0; k < q; ++k) {                       /* dy1 = R^-T r2 (R upper triangular: forward substitution on R') */
+    double s = r2[k];
+    for (int i = 0; i < k; ++i) s -= R[i][k] * dy[i];
+    dy[k] = s / R[k][k];
+  }
+  for (int k = q; k < n; ++k) { double s = 0; for (int i = 0; i < n; ++i) s += J[i][k] * r1[i]; dy[k] = s; }   /* dy2 = J2' r1 */
+  for (int i = 0; i < n; ++i) { double s = 0; for (int k = 0; k < n; ++k) s += J[i][k] * dy[k]; x[i] += s; }
+}
+
+static int qp_solve_body(int n, int p, int m, const double* A, const double* bv, const double* H, const double* g, const double* C,
+                         const double* lb, const double* ub, const double* Clb, const double* Cub, double* x, int* iters_out) {
   if (n > QN || p > 64) return WBC_QP_NUMERICAL;
   QpCons Q = {n, p, C, lb, ub, Clb, Cub};
   double L[QN][QN], J[QN][QN], R[QN][QN], d[QN], z[QN], r[QN], u[QN + 1], np[QN];
@@ -747,6 +801,8 @@ static int qp_solve_body(int n, int p, const double* H, const double* g, const d
     }
   }
 done:
+  if (status == WBC_QP_OPTIMAL)
+    for (int k = 0; k < g_refine_steps; ++k) qp_refine(n, q, m, A, bv, H, g, &Q, J, R, act, act_side, u, x);
   if (iters_out) *iters_out = iters;
   return status;
 }
@@ -886,10 +942,11 @@ void orc_tick_batch(const WbcModelBlob* const* models, const WbcConfig* cfgs, in
     const WbcConfig* c = cfgs + mi;
     const int p = orc_constraint_rows(c);
     double C[WBC_MAX_P * NV], Clb[WBC_MAX_P], Cub[WBC_MAX_P], lb[NV], ub[NV], H[NV * NV], g[NV], x[NV];
+    double At[WBC_MAX_M * NV], bt[WBC_MAX_M];          /* the task stack itself: the refinement's residual (qp_refine) */
     int it = 0;
     double qcon[NQS];
-    orc_assemble_one(m, c, in, b, dt, 0, 0, C, Clb, Cub, lb, ub, H, g, qcon);
-    const int st = orc_qp_solve(NV, p, H, g, C, lb, ub, Clb, Cub, x, &it);
+    orc_assemble_one(m, c, in, b, dt, At, bt, C, Clb, Cub, lb, ub, H, g, qcon);
+    const int st = orc_qp_solve_ls(NV, p, orc_task_rows(c), At, bt, H, g, C, lb, ub, Clb, Cub, x, &it);
     if (out->qdot) memcpy(out->qdot + (size_t)b * NV, x, sizeof x);
     if (out->status) out->status[b] = st;
     if (out->iters) out->iters[b] = it;
@@ -915,6 +972,30 @@ void orc_assemble_batch(const WbcModelBlob* const* models, const WbcConfig* cfgs
                      o->Cub ? o->Cub + (size_t)b * p : 0, o->lb ? o->lb + (size_t)b * NV : 0,
                      o->ub ? o->ub + (size_t)b * NV : 0, o->H ? o->H + (size_t)b * NV * NV : 0,
                      o->g ? o->g + (size_t)b * NV : 0, 0);
+  }
+}
+
+/* QP(A, b, ...) as QP_Wrapper.py:10-53 takes it: H = A'A and g = -A'b formed here as numpy forms them (:17-18) */
+void orc_qp_ls_batch(int B, int n, int p, int m, const double* A, const double* bv, const double* C, const double* lb,
+                     const double* ub, const double* Clb, const double* Cub, double* x, int32_t* status, int32_t* iters,
+                     int nthreads) {
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 16)
+  for (int b = 0; b < B; ++b) {
+    double H[QN * QN], g[QN];
+    const double* Ab = A + (size_t)b * m * n;
+    const double* bb = bv + (size_t)b * m;
+    int it = 0, st = WBC_QP_NUMERICAL;
+    if (n <= QN) {
+      for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) { double s = 0; for (int r = 0; r < m; ++r) s += Ab[(size_t)r * n + i] * Ab[(size_t)r * n + j]; H[i * n + j] = s; }
+        double s = 0; for (int r = 0; r < m; ++r) s += Ab[(size_t)r * n + i] * bb[r];
+        g[i] = -s;
+      }
+      st = orc_qp_solve_ls(n, p, m, Ab, bb, H, g, C ? C + (size_t)b * p * n : 0, lb ? lb + (size_t)b * n : 0, ub ? ub + (size_t)b * n : 0,
+                           Clb ? Clb + (size_t)b * p : 0, Cub ? Cub + (size_t)b * p : 0, x + (size_t)b * n, &it);
+    }
+    if (status) status[b] = st;
+    if (iters) iters[b] = it;
   }
 }
 

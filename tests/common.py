@@ -112,18 +112,32 @@ def kkt_residuals(H, g, C, lb, ub, cl, cu, x, act_tol=1e-7):
     return viol, stat
 
 
+def exact_normal_equations(A, b):
+    """H = A'A and g = -A'b of double-precision A, b in EXACT rational arithmetic (lists of Fractions): the least-squares problem itself,
+    free of the rounding that forming H in doubles adds (1e-5 relative on the posture block of the benchmark tick)."""
+    from fractions import Fraction
+    m, n = A.shape
+    Af = [[Fraction(float(A[i, j])) for j in range(n)] for i in range(m)]
+    bf = [Fraction(float(v)) for v in b]
+    nz = [[k for k in range(m) if Af[k][i] != 0] for i in range(n)]
+    H = [[sum(Af[k][i] * Af[k][j] for k in nz[i]) for j in range(n)] for i in range(n)]
+    g = [-sum(Af[k][i] * bf[k] for k in nz[i]) for i in range(n)]
+    return H, g
+
+
 def exact_kkt(H, g, rows, rhs):
-    """Exact (rational) solution of  H x + N'lam = -g,  N x = rhs  for double-precision data; returns (x, lam) as floats."""
+    """Exact (rational) solution of  H x + N'lam = -g,  N x = rhs  for double-precision data (or H, g already given as Fractions:
+    exact_normal_equations); returns (x, lam) as floats."""
     from fractions import Fraction
     n, p = len(g), len(rhs)
     N = n + p
     M = [[Fraction(0)] * (N + 1) for _ in range(N)]
     for i in range(n):
         for j in range(n):
-            M[i][j] = Fraction(float(H[i, j]))
+            M[i][j] = Fraction(H[i][j])
         for j in range(p):
             M[i][n + j] = M[n + j][i] = Fraction(float(rows[j][i]))
-        M[i][N] = Fraction(float(-g[i]))
+        M[i][N] = -Fraction(g[i])
     for j in range(p):
         M[n + j][N] = Fraction(float(rhs[j]))
     for c in range(N):
@@ -138,6 +152,13 @@ def exact_kkt(H, g, rows, rhs):
     sol = [float(M[i][N] / M[i][i]) for i in range(N)]
     return np.array(sol[:n]), np.array(sol[n:])
 
+
+
+def exact_ls_optimum(A, b, C, lb, ub, Clb, Cub, x_float):
+    """exact_optimum for the least-squares form  min 1/2 |A x - b|^2  (QP_Wrapper.py:17-18: H = A'A, g = -A'b) with H and g formed in
+    rational arithmetic from the double-precision A, b — the optimum every correct rounding of H approximates."""
+    H, g = exact_normal_equations(np.asarray(A), np.asarray(b))
+    return exact_optimum(H, g, C, lb, ub, Clb, Cub, x_float)
 
 
 def exact_optimum(H, g, C, lb, ub, Clb, Cub, x_float):
