@@ -51,6 +51,7 @@ struct WbcBatch {
   int posture_par, last_posture_par;   // option [1]: MANI / HYBRID posture targets on wbc_posture_par_kernel (every finite-difference point on its own lane); what the last one ran on
   int packed_box;        // 1 (default): task problems without constraint rows (the warm-up problem) run four instances per wavefront (wbc_tick_boxp_kernel)
   int packed_orth;       // 1 (default): equality-only task problems run four instances per wavefront (wbc_tick_orthp_kernel)
+  int refine;            // iterative-refinement steps at the final working set (default 1; 0 = the plain dual method: tests / A-B timing)
   int warm_start;        // 1: wbc_rollout carries each instance's working set from tick to tick (default 0: measured slower)
   int32_t* d_defer;      // [1 + max_batch]: count + compact list of the instances the sim3 kernel deferred (lazy)
   unsigned long long* d_dstat;   // packed kernel: (launch sequence, instances its tail redid on the general path) (lazy)
@@ -153,7 +154,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
   b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->presolve_orth = 1; b->packed_update = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
-  b->jtj_mfma = -1; b->warm_start = 0; b->packed_kernel = 1; b->packed_orth = 1; b->packed_box = 1; b->posture_par = 1;
+  b->jtj_mfma = -1; b->refine = 1; b->warm_start = 0; b->packed_kernel = 1; b->packed_orth = 1; b->packed_box = 1; b->posture_par = 1;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
@@ -619,6 +620,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!strcmp(name, "posture_par")) { b->posture_par = value; return WBC_OK; }
   if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
   if (!strcmp(name, "warm_start")) { b->warm_start = value != 0; return WBC_OK; }
+  if (!strcmp(name, "refine")) { b->refine = value < 0 ? 0 : (value > 2 ? 2 : value); return WBC_OK; }
   if (!strcmp(name, "count_pivoted")) { b->count_pivoted = value != 0; return WBC_OK; }
   if (!strcmp(name, "dbg_force_defer")) { b->force_defer = value != 0; return WBC_OK; }
   if (!strcmp(name, "dbg_stop")) {
@@ -820,7 +822,7 @@ static void fill_args(KernelArgs& a, const WbcBatch* b, int B, double dt) {
   a.models = b->d_models; a.cfgs = b->d_cfgs; a.plans = b->d_plans; a.n_models = b->n_models;
   // J'J on the matrix cores: forced (1), off (0) or, by default (-1), for wide Cartesian stacks only — measured on MI355X
   // (profiles/r02_mfma_evidence.txt): +9 % ticks/s at 33 and 45 Cartesian rows (config 2, "everything"), a wash at 6 (config 3)
-  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma < 0 ? (b->mcart >= WBC_MFMA_AUTO_ROWS) : b->jtj_mfma; a.presolve = b->presolve; a.presolve_orth = b->presolve_orth ? 1 + any_orth_plan(b) : 0; a.orth_qr = b->orth_qr; a.sing_tol = b->sing_tol; a.dbg_alias = b->dbg_alias; a.dt = dt;
+  a.B = B; a.mrows = b->mrows; a.prows = b->prows; a.mcart = b->mcart; a.jtj_mfma = b->jtj_mfma < 0 ? (b->mcart >= WBC_MFMA_AUTO_ROWS) : b->jtj_mfma; a.presolve = b->presolve; a.presolve_orth = b->presolve_orth ? 1 + any_orth_plan(b) : 0; a.orth_qr = b->orth_qr; a.refine = b->refine; a.sing_tol = b->sing_tol; a.dbg_alias = b->dbg_alias; a.dt = dt;
   a.prof = b->d_prof; a.dbg_stop = b->dbg_stop;
   a.fk_nj = b->max_nj; a.fk_nf = b->max_nf;
 }
@@ -1159,6 +1161,7 @@ static int qp_common(WbcBatch* b, int B, QpArgs& a, int mem, void* stream, const
   st.out(&a.x, N * n); st.out(&a.status, N); st.out(&a.iters, N); st.out(&a.H_out, N * n * n); st.out(&a.g_out, N * n);
   st.in(&a.ws_in, N * 2); st.out(&a.ws_out, N * 2);   // (host buffers are staged separately, so in and out may be the same host array)
   if ((rc = st.stage())) return rc;
+  a.refine = b->refine;
   if (int e = launch_qp(a, grid_for(b, B), stream)) return fail(WBC_E_HIP, "qp kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return st.finish();
 }

@@ -118,7 +118,8 @@ struct KernelArgs {
   uint32_t tick_seq;                // packed kernel: this launch's sequence number (the "deferred_last" statistic is (seq, count) in one word)
   unsigned long long* defer_stat;   // packed kernel: that word (instances its tail redid on the general path), or null
   int32_t presolve_orth;            // the orthonormal contact presolve where DevPlan.orth: 0 off, 1 on, 2 on and a plan of this batch has DevPlan.orth (host)
-  int32_t orth_qr, pad3_;           // diagnostic: the null-space basis always through the Householder QR (else only for flagged leg blocks)
+  int32_t orth_qr;                  // diagnostic: the null-space basis always through the Householder QR (else only for flagged leg blocks)
+  int32_t refine;                   // iterative-refinement steps at the final working set (QP_Wrapper.py:37 numRefinementSteps; option "refine", default 1)
   // warm start: the final working set of the previous tick, [B][2] words in FULL-problem indexing whatever
   // kernel wrote them: word 0 = velocity bounds (bit d: DoF d at its lower bound, bit 32 + d: at its upper bound), word 1 =
   // constraint rows of findConstraints' order (bit i / 32 + i). Either may be null (cold start / nothing carried); they may alias.
@@ -135,7 +136,7 @@ struct KernelArgs {
 
 struct QpArgs {
   int32_t B, n, p, m;               // m > 0: least-squares form (A, b given)
-  int32_t use_mfma, pad0;
+  int32_t use_mfma, refine;         // refine: iterative-refinement steps at the final working set (option "refine", default 1)
   const double *H, *g, *A, *bvec, *C, *lb, *ub, *Clb, *Cub;
   double *x, *H_out, *g_out;
   int32_t *status, *iters;

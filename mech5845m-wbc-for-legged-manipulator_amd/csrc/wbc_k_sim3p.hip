@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       if (s < 9) { V.dv[s] = A.in.ee_ref_rot[(size_t)b * 45 + 36 + s]; V.yv[s] = A.in.ee_prev_rot[(size_t)b * 45 + 36 + s]; }
     }
   }
+  double at6[6] = {0, 0, 0, 0, 0, 0};      // TRUNK: the trunk task's image of base variable s (kept for the refinement's residual; its targets in V.pad_)
   if (TRUNK) {
     WSYNC();                               // (the staged inputs are visible)
     const double* const qv = V.in;
@@ -137,6 +138,14 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       for (int rr = 0; rr < 6; rr += 2) sts2(At2 + s * 6 + rr, at[rr], at[rr + 1]);
     }
     WSYNC();
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) at6[rr] = at[rr];
+    if (s < 6) {
+      double vs = vel[0];
+#pragma unroll
+      for (int i = 1; i < 6; ++i) vs = (s == i) ? vel[i] : vs;
+      V.pad_[s] = vs * trunk_w;              // b of the trunk rows (TrunkB, :914-920)
+    }
     if (s < 6) {
       double gs = 0.0;
 #pragma unroll
@@ -260,6 +269,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   double* const Bb = I.M2 + 16 * 6 + 48;   // [6][4]:  linear WORLD column of base DoF c
   double g = 0.0;
   double a[6] = {0, 0, 0, 0, 0, 0};
+  double bt[6] = {0, 0, 0, 0, 0, 0};        // the Grip rows' targets (b of qpb): kept for the refinement's residual, parked in V.in[28..33] below
   if (has_grip) {
     const bool sup = (s < n) && ((gsup >> s) & 1u);
     double wxp[3];
@@ -275,6 +285,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     for (int i = 0; i < 3; ++i) {          // calcTargetVelEE3 (:1052-1157); EndEffectorB2 (:907-910)
       const double br = ((xt[i] - xp[i]) * inv_dt + eG[i] * ((xt[i] - pfe[i]) * inv_dt)) * ee_w;
       g = fma(-a[i], br, g);
+      bt[i] = br;
     }
     if (A.in.ee_ref_rot) {                 // omega = vee(((R* - R*_prev)/dt) R*^T)  (:1125-1128, 1133); zero when the reference rests
       const double* Rs = V.dv;
@@ -286,6 +297,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       const double w4 = D[0] * Rs[6] + D[1] * Rs[7] + D[2] * Rs[8];   // S[0][2]
       const double w5 = D[3] * Rs[0] + D[4] * Rs[1] + D[5] * Rs[2];   // S[1][0]
       g = fma(-a[3], w3 * ee_w, g); g = fma(-a[4], w4 * ee_w, g); g = fma(-a[5], w5 * ee_w, g);
+      bt[3] = w3 * ee_w; bt[4] = w4 * ee_w; bt[5] = w5 * ee_w;
     }
   }
   if (TRUNK && s < 6) g += I.Cq[36 + s];    // the trunk task's part (formed at the top)
@@ -298,6 +310,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // posture rows (qpJointA / qpJointb, :1199-1268) of reduced variable s and of leg DoF s
   const double dpost = (1.0 / nv) * joint_w;
   double g1 = 0.0;                          // posture term of leg DoF s in g
+  double bp0 = 0.0, bp1 = 0.0;              // posture rows' targets (b of qpJointb) of reduced variable s / of leg DoF s: the refinement's residual
   {
     const bool prev0 = (c_task_joint == WBC_JOINT_PREV) || (c_task_joint >= WBC_JOINT_MANI && !((P.post_zero >> dof0) & 1u));
     const bool prev1 = (c_task_joint == WBC_JOINT_PREV) || (c_task_joint >= WBC_JOINT_MANI && !((P.post_zero >> dof1) & 1u));
@@ -309,6 +322,8 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     }
     if (s < n) g = fma(-dpost, (1.0 / nv) * u0 * joint_w, g);
     if (s < nl) g1 = -dpost * ((1.0 / nv) * u1 * joint_w);
+    bp0 = (s < n) ? (1.0 / nv) * u0 * joint_w : 0.0;
+    bp1 = (s < nl) ? (1.0 / nv) * u1 * joint_w : 0.0;
   }
   if (s >= n) g = 0.0;
   if (A.post_static && P.post_pert) {     // the state qpJointb leaves behind: bounds and integrate see it
@@ -317,6 +332,12 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     if (16 + s < NQ && ((P.post_pert >> (16 + s)) & 1u)) V.in[16 + s] = (qv[16 + s] + 0.0002) - (0.0002 * 2);
   }
   WSYNC();
+  if (s < 6) {                              // (every lane has read the Grip targets: their slots take the rows' b)
+    double v = bt[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) v = (s == i) ? bt[i] : v;
+    V.in[28 + s] = v;
+  }
   // row s of H' = sum_r At[s][r] At[k][r] (+ posture): straight into the registers the Cholesky sweep works on
   double h[PV];
   {
@@ -627,6 +648,32 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
           row[c] = (s == p_keep + l2) ? uc : ((c == cstar) ? crc * wz + crz : row[c] + crc * uc);
         }
       }
+      // the Grip task's image in the new unknowns, A'' = A M (column j: a_j + u_j a_c*, column c*: wz a_c*; z2 moves no task frame): what the
+      // refinement's residual is formed from at the end
+      if (TRUNK) {                          // (the trunk task's image lives in registers: lanes s < 6)
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) {
+          const double ac = bperm(at6[rr], rbase + cstar);
+          if (on && s < n) at6[rr] = (s == cstar) ? wz * ac : fma(us, ac, at6[rr]);
+        }
+      }
+      if (QCON) {                           // (the second kinematics pass took the image's place in M2: this variant keeps it in registers)
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) {
+          const double ac = bperm(a[rr], rbase + cstar);
+          if (on && s < n) a[rr] = (s == cstar) ? wz * ac : fma(us, ac, a[rr]);
+        }
+      } else {
+        const double2a c0 = lds2(At + cstar * 6), c1 = lds2(At + cstar * 6 + 2), c2 = lds2(At + cstar * 6 + 4);
+        WSYNC();
+        if (on && s < n) {
+          const double2a m0 = lds2(At + s * 6), m1 = lds2(At + s * 6 + 2), m2 = lds2(At + s * 6 + 4);
+          const bool pv = s == cstar;
+          sts2(At + s * 6, pv ? wz * c0.x : fma(us, c0.x, m0.x), pv ? wz * c0.y : fma(us, c0.y, m0.y));
+          sts2(At + s * 6 + 2, pv ? wz * c1.x : fma(us, c1.x, m1.x), pv ? wz * c1.y : fma(us, c1.y, m1.y));
+          sts2(At + s * 6 + 4, pv ? wz * c2.x : fma(us, c2.x, m2.x), pv ? wz * c2.y : fma(us, c2.y, m2.y));
+        }
+      }
       // the kept rows of the feet still to come, in the new unknowns
 #pragma unroll 1
       for (int f2 = f + 1; f2 < 4; ++f2) {
@@ -639,9 +686,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
         const int rl2 = rbase + ((p_keep + l2) & 15);
         const double nl_ = bperm(clb, rl2), nu_ = bperm(cub, rl2), ol_ = bperm(lb, rbase + cstar), ou_ = bperm(ub, rbase + cstar);
         const int dB = bpermi(dofB, rbase + (l2 & 15)), dA = bpermi(dofA, rbase + cstar);
-        if (on && s == cstar) { lb = nl_; ub = nu_; dofA = dB; }
+        const double pB = bperm(bp1, rbase + (l2 & 15)), pA = bperm(bp0, rbase + cstar);   // the posture rows' targets follow their DoF
+        if (on && s == cstar) { lb = nl_; ub = nu_; dofA = dB; bp0 = pB; }
         if (on && s == p_keep + l2) { clb = ol_; cub = ou_; }
-        if (on && s == l2) dofB = dA;
+        if (on && s == l2) { dofB = dA; bp1 = pA; }
       }
       WSYNC();
     }
@@ -723,6 +771,10 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   const double jf2 = rsum16(s < PV ? sq : 0.0);
   double* const J = I.M2;
   double* const T = I.M1;
+  if (!QCON) {                              // the Grip image of reduced variable s comes back from LDS before J takes its place (free registers across the sweep)
+    const double2a t0 = lds2(At + s * 6), t1 = lds2(At + s * 6 + 2), t2 = lds2(At + s * 6 + 4);
+    a[0] = t0.x; a[1] = t0.y; a[2] = t1.x; a[3] = t1.y; a[4] = t2.x; a[5] = t2.y;
+  }
   WSYNC();
   if (s < PV) {
 #pragma unroll
@@ -1076,6 +1128,81 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       }
       if (stepping) drop_l = l;             // blocking slot: dropped at the top of the next pass, then the step is retried
     }
+  }
+  // ================================ iterative refinement ==========================================
+  // One step at the final working set (QP_Wrapper.py:37 asks qpOASES for numRefinementSteps = 100; oracle: qp_refine). With the slots' normals
+  // n_k, right-hand sides b_k and multipliers u_k:   r1 = -(grad f(y) - sum u_k n_k),  r2_k = b_k - n_k'y,   dy = J1 T' r2 + J2 J2' r1.
+  // grad f comes from the UNFACTORED least-squares data — the Grip image A Z (a[] of every lane), the posture rows d (y_s - u_s) of the reduced
+  // variables and of the eliminated leg DoF (x_l = G_l y: rows p_keep + l of Cq) — never from H': fl(H') carries the 1.5e-9 posture block
+  // with 1e-5 relative error, which IS the 1e-6 the plain method is off by (cond(H) ~ 3e9); the least-squares residual's own rounding lies in
+  // the range of (A Z)', where H' is well conditioned.
+  if (A.refine > 0) {
+    WSYNC();
+    V.xv[s] = has_b ? x : 0.0;
+    V.cl[s] = lb; V.cl[16 + s] = ub; V.tv[s] = clb; V.dv[s] = cub;
+    V.yv[s] = 0.0;
+    WSYNC();
+    const double2a x0 = lds2(V.xv), x1_ = lds2(V.xv + 2), x2 = lds2(V.xv + 4);
+    auto rowval = [&](const int rr_) -> double {     // C'_rr y (every reduced row has base support only)
+      const double2a c0 = lds2(I.Cq + rr_ * 6), c1 = lds2(I.Cq + rr_ * 6 + 2), c2 = lds2(I.Cq + rr_ * 6 + 4);
+      return fma(c0.x, x0.x, fma(c0.y, x0.y, fma(c1.x, x1_.x, fma(c1.y, x1_.y, fma(c2.x, x2.x, c2.y * x2.y)))));
+    };
+    const double vrow = has_r ? rowval(s) : 0.0;     // row s at y; rows p_keep + l: the velocity of leg DoF l
+    // slot s: residual and signed multiplier of its constraint
+    const int cc = a_code & 255, sd = (a_code >> 8) & 1;
+    const bool slot = s < q, srow = cc >= n;
+    const int rr_ = srow ? ((cc - n) & 15) : 0, iv = cc & 15;
+    const double sgn = sd ? -1.0 : 1.0;
+    const double val = srow ? rowval(rr_) : V.xv[iv];
+    const double bnd = srow ? (sd ? V.dv[rr_] : V.tv[rr_]) : (sd ? V.cl[16 + iv] : V.cl[iv]);
+    const double r2 = slot ? sgn * (bnd - val) : 0.0;
+    const double us = slot ? sgn * u : 0.0;
+    const double bpl = bperm(bp1, rbase + ((s - p_keep) & 15));     // posture target of the leg DoF whose velocity row s carries
+    WSYNC();
+    V.dv[s] = 0.0;
+    if (s >= p_keep && s < p) V.yv[s] = dpost * (bpl - dpost * vrow);   // weights of the rows in r1: the leg DoF's posture residual ...
+    WSYNC();
+    if (slot && srow) V.yv[rr_] += us;                                  // ... and the active rows' multipliers on top
+    if (slot && !srow) V.dv[iv] = us;                                   // active bounds' multipliers by variable
+    // Grip rows: e = b - (A Z) y, then (A Z)'e
+    double r1 = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+      const double e = V.in[28 + rr] - rsum16(has_b ? a[rr] * x : 0.0);
+      r1 = fma(a[rr], e, r1);
+    }
+    if (TRUNK) {                            // trunk rows (base columns): the same with their image and targets
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) {
+        const double e = V.pad_[rr] - rsum16(has_b ? at6[rr] * x : 0.0);
+        r1 = fma(at6[rr], e, r1);
+      }
+    }
+    r1 = fma(dpost, bp0 - dpost * x, r1);
+    WSYNC();
+    r1 += V.dv[s];
+    if (s < 6) {
+#pragma unroll
+      for (int rr = 0; rr < PN; ++rr) r1 = fma((rr < p) ? I.Cq[rr * 6 + s] : 0.0, V.yv[rr], r1);
+    }
+    if (!has_b) r1 = 0.0;
+    WSYNC();
+    V.tv[s] = r1; V.dv[s] = r2;
+    WSYNC();
+    const int sv = s < PV ? s : PV - 1;
+    double dy1 = 0.0, dy2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < PV; ++j) {
+      dy1 = fma(T[j * PLD + sv], V.dv[j], dy1);       // T'r2 (T is zero outside the slots)
+      dy2 = fma(J[j * PLD + sv], V.tv[j], dy2);       // J'r1
+    }
+    WSYNC();
+    V.yv[s] = (s < PV) ? ((s < q) ? dy1 : dy2) : 0.0;
+    WSYNC();
+    double da = 0.0, db = 0.0;
+#pragma unroll
+    for (int k = 0; k < PV; k += 2) { const double2a j2 = lds2(J + sv * PLD + k), w2 = lds2(V.yv + k); da = fma(j2.x, w2.x, da); db = fma(j2.y, w2.y, db); }
+    if (has_b && status == WBC_QP_OPTIMAL) x += da + db;
   }
   if (status == WBC_QP_OPTIMAL) {
     const unsigned long long bad = __ballot(has_b && !(fabs(x) <= 1.7976931348623157e308));
