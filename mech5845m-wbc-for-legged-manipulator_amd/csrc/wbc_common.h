@@ -251,10 +251,117 @@ __device__ __forceinline__ unsigned long long low_bits(unsigned long long m, int
 // solve_v3). The seeds go through the register-resident Householder QR of the equality block — an order of magnitude cheaper
 // per constraint than a dual iteration — but stay droppable (their columns of T = R22^-1 are built along the way); seeds whose
 // multiplier comes out negative are removed by the restoration steps in front of the dual iterations.
-template <int NM, class SM = Smem, int CS = LDJ, bool WARM = false>
+// RF: the caller's residual functor for the iterative refinement at the final working set (qp_refine below): rf(x) returns, on lane k < n,
+// entry k of -grad f(x) formed from the caller's UNFACTORED data (least-squares data where it has them); every lane calls it (it may reduce
+// over the wave) and it may use S.xv / S.yv / S.dv / S.npv. NoRefine: nothing is compiled in.
+struct NoRefine { static constexpr bool enabled = false; __device__ double operator()(double) const { return 0.0; } };
+template <class F> struct Refine { static constexpr bool enabled = true; const F& f; __device__ __forceinline__ double operator()(double v) const { return f(v); } };
+
+// One step of iterative refinement at the final working set (QP_Wrapper.py:37 asks qpOASES for numRefinementSteps = 100; oracle: qp_refine).
+// Needs nothing of the dual method but its final J (J J' = H^-1, the first q columns spanning the active normals) and the list of
+// active constraints: R = J1'N is REBUILT from them (one product per slot), so equality slots — whose part of R the register-resident QR
+// never stores — are corrected like the others, and T = R^-1 (inequality slots only) is not used; R takes T's place in RA.
+//     gneg = -grad f(x) (rf),  u = -R^-1 J1'gneg,  r1 = gneg + N'u,  r2_k = b_k - n_k'x,   x += J1 R^-T r2 + J2 J2' r1.
+// Forming N'u before the product with J2 matters: J2'gneg alone is a sum of O(|J| |grad f|) terms that cancel to ~0 (|J| ~ 1/d = 2.6e4 on the
+// benchmark tick) and its rounding would come back through J2 as 1e-7 on x; r1 is small, so its products are clean.
+template <int NM, class SM, int CS, class RF>
+__device__ __forceinline__ double qp_refine(SM& S, const RF& rf, const double x_in, const int n, const int p, const int lane, const int q,
+                                            const int a_code, const bool fixb, const double lb, const double ub, const double clb, const double cub) {
+  const int li = lane < NM ? lane : NM - 1;
+  double* const R = S.RA;
+  const double* const J = S.RB;
+  const double* const Cm = S.RC;
+  const double gneg_ = rf(x_in);
+  const double gneg = (lane < n && !fixb) ? gneg_ : 0.0;
+  WSYNC();
+  if (lane < 32) { S.xv[lane] = (lane < n) ? x_in : 0.0; S.dv[lane] = lb; S.yv[lane] = ub; S.npv[lane] = clb; S.lv[lane] = cub; S.dinv[lane] = gneg; }
+  WSYNC();
+  // slot `lane`: its constraint's residual b - n'x
+  const int cc = a_code & 255, sd = (a_code >> 8) & 1;
+  const bool slot = lane < q, srow = cc >= n;
+  const int rr = (srow && slot) ? cc - n : 0, iv = (slot && !srow) ? cc : 0;
+  double val = S.xv[iv & 31];
+  if (__ballot(slot && srow)) {
+    double v = 0.0, vb = 0.0;
+#pragma unroll
+    for (int k = 0; k < NM; k += 2) { const double2a c2 = lds2(Cm + rr * CS + k); const double2a x2 = lds2(S.xv + k); v = fma(c2.x, x2.x, v); vb = fma(c2.y, x2.y, vb); }
+    if (srow) val = v + vb;
+  }
+  const double bnd = srow ? (sd ? S.lv[rr & 31] : S.npv[rr & 31]) : (sd ? S.yv[iv & 31] : S.dv[iv & 31]);
+  const double sgn_s = sd ? -1.0 : 1.0;
+  double t = slot ? sgn_s * (bnd - val) : 0.0;          // r2 of slot `lane`
+  // w = J'gneg (lane k: column k of J)
+  double w = 0.0;
+#pragma unroll
+  for (int i = 0; i < NM; ++i) w = fma(J[i * LDJ + li], S.dinv[i], w);
+  WSYNC();
+  // R = J1'N, column by column (slot k uniform): lane i <= k keeps R[i][k]; what rounding leaves below the diagonal is dropped
+#pragma unroll 1
+  for (int k = 0; k < q; ++k) {
+    const int ck = rdli(a_code, k);
+    const int ip = ck & 255;
+    const double sg = (ck >> 8) ? -1.0 : 1.0;
+    double d;
+    if (ip >= n) {
+      const int r_ = ip - n;
+      double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NM; i += 2) {
+        const double2a c2 = lds2(Cm + r_ * CS + i);
+        d0 = fma(J[i * LDJ + li], c2.x, d0); d1 = fma(J[(i + 1) * LDJ + li], c2.y, d1);
+      }
+      d = (d0 + d1) * sg;
+    } else d = sg * J[ip * LDJ + li];
+    if (lane < q) R[lane * LDJ + k] = (lane <= k) ? d : 0.0;
+  }
+  WSYNC();
+  // multipliers: R u = -w1 (back substitution; lane k ends up with u_k)
+  double c = slot ? -w : 0.0, um = 0.0;
+#pragma unroll 1
+  for (int k = q - 1; k >= 0; --k) {
+    const double uk = rdl(c, k) / R[k * LDJ + k];
+    if (lane == k) um = uk;
+    if (lane < k) c = fma(-R[lane * LDJ + k], uk, c);
+  }
+  // r1 = gneg + N'u
+  double r1 = gneg;
+#pragma unroll 1
+  for (int k = 0; k < q; ++k) {
+    const int ck = rdli(a_code, k);
+    const int ip = ck & 255;
+    const double uk = rdl(um, k) * ((ck >> 8) ? -1.0 : 1.0);
+    if (ip >= n) r1 = fma(uk, Cm[(ip - n) * CS + li], r1);
+    else if (lane == ip) r1 += uk;
+  }
+  if (!(lane < n) || fixb) r1 = 0.0;
+  if (lane < 32) S.dinv[lane] = r1;
+  WSYNC();
+  double dy = 0.0;
+#pragma unroll
+  for (int i = 0; i < NM; ++i) dy = fma(J[i * LDJ + li], S.dinv[i], dy);     // J'r1: lanes >= q keep it (J2'r1)
+  // R'dy1 = r2 (forward substitution; lane k ends up with dy1_k)
+  double dy1 = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < q; ++k) {
+    const double dk = rdl(t, k) / R[k * LDJ + k];
+    if (lane == k) dy1 = dk;
+    if (lane > k && lane < q) t = fma(-R[k * LDJ + lane], dk, t);
+  }
+  WSYNC();
+  if (lane < 32) S.dinv[lane] = (lane < q) ? dy1 : ((lane < NM) ? dy : 0.0);
+  WSYNC();
+  double da = 0.0, db = 0.0;
+#pragma unroll
+  for (int k = 0; k < NM; k += 2) { const double2a j2 = lds2(J + li * LDJ + k); const double2a w2 = lds2(S.dinv + k); da = fma(j2.x, w2.x, da); db = fma(j2.y, w2.y, db); }
+  WSYNC();
+  return (lane < n && !fixb) ? x_in + (da + db) : x_in;
+}
+
+template <int NM, class SM = Smem, int CS = LDJ, bool WARM = false, class RF = NoRefine>
 __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const double lb_in, const double ub_in,
                                             const double clb_in, const double cub_in, const int n, const int p, const int lane,
-                                            unsigned long long* ts, const int dbg_stop = 0, const int ws_b_in = 0, const int ws_r_in = 0) {
+                                            unsigned long long* ts, const int dbg_stop = 0, const int ws_b_in = 0, const int ws_r_in = 0,
+                                            const RF& rf = RF(), const int refine = 0) {
   const int li = lane < NM ? lane : NM - 1;
   QpResult res;
   res.status = WBC_QP_OPTIMAL;
@@ -420,8 +527,9 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
       if (e < ntot) {                                    // uniform
         const double* col;
         double be, n2, sg = 1.0;
-        if (mb) { const int c = ctz64(mb); mb &= mb - 1; col = S.RB + c * LDJ; be = rdl(lb, c); n2 = 1.0; }
-        else if (mr) { const int c = ctz64(mr); mr &= mr - 1; col = S.RA + c * LDJ; be = rdl(clb, c); n2 = rdl(cn2, c); }
+        int ecode = 0;                                   // (equality slots: kept for the refinement, which rebuilds R from the active constraints)
+        if (mb) { const int c = ctz64(mb); mb &= mb - 1; col = S.RB + c * LDJ; be = rdl(lb, c); n2 = 1.0; ecode = c; }
+        else if (mr) { const int c = ctz64(mr); mr &= mr - 1; col = S.RA + c * LDJ; be = rdl(clb, c); n2 = rdl(cn2, c); ecode = n + c; }
         else if (WARM && sb) {
           const int c = ctz64(sb); sb &= sb - 1; col = S.RB + c * LDJ; n2 = 1.0;
           const bool up = rdli(ws_b_in, c) == 2;
@@ -432,7 +540,7 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
           sg = up ? -1.0 : 1.0; be = up ? -rdl(cub, c) : rdl(clb, c);
         }
         v = sg * col[li];
-        if (lane == 0) { S.dinv[e] = be; S.lv[e] = n2; }   // (dinv / lv are free after the substitution)
+        if (lane == 0) { S.dinv[e] = be; S.lv[e] = n2; if (RF::enabled) S.xv[e] = (double)ecode; }   // (dinv / lv / xv are free after the substitution)
       }
       bq[e] = (lane < n) ? v : 0.0;
     }
@@ -513,6 +621,7 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
       beta = (vv > 0.0) ? 2.0 / vv : 0.0;
       const double yq = (b_e - dy) / delta;
       if (lane == q) y1 = yq;
+      if (RF::enabled && !seed && lane == q) a_code = (int)S.xv[e];
       if (seed) {
         // the seed stays droppable: column q of T = R22^-1 is (-T r / delta, 1 / delta) with r = the column's entries on the
         // inequality slots [qe, q) — the same append the dual method's add step makes
@@ -823,6 +932,9 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
     }
   }
 done:
+  if (RF::enabled) {
+    if (refine > 0 && res.status == WBC_QP_OPTIMAL) x = qp_refine<NM, SM, CS, RF>(S, rf, x, n, p, lane, q, a_code, fixb, lb, ub, clb, cub);
+  }
   STAMP(ts, T_INEQ);
   // a QP that was not solved returns x = 0 (the reference's xOpt on its first QP: qpOASES does not write the primal vector
   // of an unsolved problem, QP_Wrapper.py:50, 71-73) — and a roll-out holds still instead of integrating a partial iterate

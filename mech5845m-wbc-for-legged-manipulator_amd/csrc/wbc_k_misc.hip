@@ -89,7 +89,39 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
       sb = (lane < 32) ? (int)(((w0 >> lane) & 1ull) | (((w0 >> (32 + lane)) & 1ull) << 1)) : 0;
       sr = (lane < 32) ? (int)(((w1 >> lane) & 1ull) | (((w1 >> (32 + lane)) & 1ull) << 1)) : 0;
     }
-    const QpResult res = qp_core<NM, Smem, LDJ, WARM>(S, g, lb, ub, clb, cub, n, p, lane, ts, 0, sb == 3 ? 0 : sb, sr == 3 ? 0 : sr);
+    // the refinement's residual from the caller's own data in HBM (L2-resident: just read): QP(A, b, ...) -> A'(b - A x), rows on lanes
+    // (lane r: rows r and r + 64), e through S.in (unused here), then column k on lane k; QP(H, g) -> -(H x + g), the only residual it has
+    auto resid = [&](const double xk) -> double {
+      WSYNC();
+      if (lane < 32) S.xv[lane] = (lane < n) ? xk : 0.0;
+      WSYNC();
+      double r = 0.0;
+      if (m > 0) {
+        const double* Ab = A.A + (size_t)b * m * n;
+        const double* bb = A.bvec + (size_t)b * m;
+#pragma unroll 1
+        for (int r0 = 0; r0 < m; r0 += 64) {
+          const int row = r0 + lane;
+          if (row < m) {
+            double e = bb[row];
+            for (int k = 0; k < n; ++k) e = fma(-Ab[(size_t)row * n + k], S.xv[k], e);
+            S.in[row] = e;
+          }
+        }
+        WSYNC();
+        if (lane < n) for (int row = 0; row < m; ++row) r = fma(Ab[(size_t)row * n + lane], S.in[row], r);
+      } else if (lane < n) {
+        const double* Hb = A.H + (size_t)b * n * n + (size_t)lane * n;
+        double t_ = A.g[(size_t)b * n + lane];
+        for (int k = 0; k < n; ++k) t_ = fma(Hb[k], S.xv[k], t_);
+        r = -t_;
+      }
+      WSYNC();
+      return r;
+    };
+    typedef Refine<decltype(resid)> RF_;
+    const RF_ rf{resid};
+    const QpResult res = qp_core<NM, Smem, LDJ, WARM, RF_>(S, g, lb, ub, clb, cub, n, p, lane, ts, 0, sb == 3 ? 0 : sb, sr == 3 ? 0 : sr, rf, A.refine);
     if (WARM && A.ws_out) {
       const unsigned long long o0 = (__ballot(res.ws_b == 1) & 0xFFFFFFFFull) | (__ballot(res.ws_b == 2) << 32);
       const unsigned long long o1 = (__ballot(res.ws_r == 1) & 0xFFFFFFFFull) | (__ballot(res.ws_r == 2) << 32);
