@@ -915,7 +915,10 @@ static int launch_tick_auto(WbcBatch* b, KernelArgs& a, int B, void* stream) {
     if (int e = launch_tick_orthp(a, stream, b->plan_host[0].q_ok == 2)) return fail(WBC_E_HIP, "packed orth tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));
     return WBC_OK;
   }
-  if (!sim3_eligible(b, a)) {
+  // The one-instance compact kernel (path 1) does not refine: it lives on 168 VGPRs / 13.2 KB LDS (3 waves per SIMD) and has room neither for the
+  // task image nor for the Jacobian columns the residual is formed from. With the refinement on (default) what the packed kernel does not take
+  // runs on the general kernel, whose structural presolve solves the same reduced problem and refines it (option refine = 0 brings path 1 back).
+  if (!sim3_eligible(b, a) || (b->refine > 0 && !packed_eligible(b, a))) {
     b->last_path = 0;
     b->last_orth = a.presolve && a.presolve_orth == 2 && !(a.ws_in || a.ws_out);
     if (int e = launch_tick(a, MODE_TICK, grid_tick(b, B), stream)) return fail(WBC_E_HIP, "tick kernel launch failed: %s", hipGetErrorString((hipError_t)e));

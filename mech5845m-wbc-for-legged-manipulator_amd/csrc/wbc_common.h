@@ -22,6 +22,7 @@
 // plain numpy in tests/gi_variant.py (solve_v2).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 #include "wbc_device.h"
 
 namespace wbc {
@@ -46,6 +47,7 @@ struct __attribute__((aligned(16))) Smem {
   double dv[32], xv[32], npv[32], lv[32], dinv[32], yv[32];
   double cl[64];                        // Cholesky column broadcast; entries 26..63 stay zero
   double bt[48];                        // Cartesian task targets (b of qpb), uniform values
+  double pft[16];                       // the five EE frame origins at the TASK state (pf follows a second kinematics pass): the refinement's residual
 };
 constexpr int OFF_OMI = 0;              // RA: oMi[24][12] (dead before H is accumulated)
 constexpr int OFF_MC = 24 * 12;         // RA: m*c per joint [32][4]
@@ -254,7 +256,12 @@ __device__ __forceinline__ unsigned long long low_bits(unsigned long long m, int
 // RF: the caller's residual functor for the iterative refinement at the final working set (qp_refine below): rf(x) returns, on lane k < n,
 // entry k of -grad f(x) formed from the caller's UNFACTORED data (least-squares data where it has them); every lane calls it (it may reduce
 // over the wave) and it may use S.xv / S.yv / S.dv / S.npv. NoRefine: nothing is compiled in.
-struct NoRefine { static constexpr bool enabled = false; __device__ double operator()(double) const { return 0.0; } };
+struct NoRefine {
+  static constexpr bool enabled = false;
+  __device__ NoRefine() {}
+  template <class F> __device__ NoRefine(const F&) {}
+  __device__ double operator()(double) const { return 0.0; }
+};
 template <class F> struct Refine { static constexpr bool enabled = true; const F& f; __device__ __forceinline__ double operator()(double v) const { return f(v); } };
 
 // One step of iterative refinement at the final working set (QP_Wrapper.py:37 asks qpOASES for numRefinementSteps = 100; oracle: qp_refine).
@@ -1261,12 +1268,14 @@ constexpr int GS = 10;                 // row stride of G: 6 base columns + up t
 // variable k is DoF Fd[k], reduced row r is the r-th kept row or, from p_keep on, the velocity bound of eliminated leg DoF legd[r - p_keep]
 // — and the final one mapped back, so that res.ws_b / res.ws_r come out in the caller's indexing (lane = DoF / original constraint row),
 // like process_sim3's.
-template <bool WARM = false, class KA = KernelArgs>
+// RFULL: the caller's full-space residual functor (lane d: entry d of -grad f at the velocity it is handed on lane d) for the refinement; here it is
+// wrapped into the reduced coordinates: x = Z y, r' = Z'r.
+template <bool WARM = false, class KA = KernelArgs, class RFULL = NoRefine>
 __device__ __forceinline__ bool contact_presolve(Smem& S, const KA& A, const DevModel& M, const WbcConfig& cfg,
                                                  const DevPlan& P, const double dpost, const double g, const double lb,
                                                  const double ub, const double clb, const double cub, const int lane,
                                                  unsigned long long* ts, QpResult& res, const unsigned long long ws0 = 0ull,
-                                                 const unsigned long long ws1 = 0ull) {
+                                                 const unsigned long long ws1 = 0ull, const RFULL& rfull = RFULL(), const int refine = 0) {
   if (!A.presolve || !P.enabled) return false;
   const int nv = M.nv, p = A.prows;
   const int nelim = P.nelim, n_red = P.n_red, nl = 3 * nelim;
@@ -1408,8 +1417,33 @@ __device__ __forceinline__ bool contact_presolve(Smem& S, const KA& A, const Dev
     if (sd_b == 3) sd_b = 0;
     if (sd_r == 3) sd_r = 0;
   }
-  if (n_red <= 12) res = qp_core<12, Smem, LDJ, WARM>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, 0, sd_b, sd_r);   // (qp_core's sweeps cost ~NM^2)
-  else res = qp_core<NR, Smem, LDJ, WARM>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, 0, sd_b, sd_r);
+  // the refinement's residual in the reduced coordinates: y -> x = Z y by DoF -> the caller's full-space residual -> Z'r
+  auto resid_red = [&](const double yk) -> double {
+    WSYNC();
+    if (lane < 32) S.xv[lane] = (lane < n_red) ? yk : 0.0;
+    WSYNC();
+    double xd = 0.0;
+    if (my_pos >= 0) xd = S.xv[my_pos];
+    else if (my_l >= 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) xd = fma(Gm[my_l * GS + c], S.xv[c], xd);
+    }
+    const double rd = rfull((lane < nv) ? xd : 0.0);
+    WSYNC();
+    if (lane < 32) S.yv[lane] = (lane < nv) ? rd : 0.0;
+    WSYNC();
+    double rk = (lane < n_red) ? S.yv[fj] : 0.0;
+    if (lane < 6) {
+#pragma unroll
+      for (int l = 0; l < 12; ++l) rk = fma((l < nl) ? Gm[l * GS + lane] : 0.0, S.yv[legd[l]], rk);
+    }
+    WSYNC();
+    return rk;
+  };
+  typedef typename std::conditional<RFULL::enabled, Refine<decltype(resid_red)>, NoRefine>::type RRED;
+  const RRED rred{resid_red};
+  if (n_red <= 12) res = qp_core<12, Smem, LDJ, WARM, RRED>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, 0, sd_b, sd_r, rred, refine);   // (qp_core's sweeps cost ~NM^2)
+  else res = qp_core<NR, Smem, LDJ, WARM, RRED>(S, g_red, lb_red, ub_red, nclb, ncub, n_red, i2, lane, ts, 0, sd_b, sd_r, rred, refine);
   res.iters += nl + P.nlock;                         // the eliminated equalities and the locked DoF, so that `iters` keeps its meaning
   // ---- x = Z y
   WSYNC();
@@ -2122,6 +2156,11 @@ __device__ __forceinline__ void process_instance(Smem& S, const KA& A, const Dev
     }
     row += 3;
   }
+  // the lane's WORLD Jacobian column at the TASK state, parked for the refinement's residual (a second kinematics pass below replaces lin / ang):
+  // the Cartesian targets [28..57] and the input groups 2 and 3 [64..191] of the staging image are dead from here on
+  double* const colst = S.in + ((lane < 21) ? 64 + 6 * lane : 28 + 6 * ((lane < NV ? lane : NV - 1) - 21));
+  if (MODE == MODE_TICK && lane < NV) { sts2(colst, lin[0], lin[1]); sts2(colst + 2, lin[2], ang[0]); sts2(colst + 4, ang[1], ang[2]); }
+  if (MODE == MODE_TICK && lane < 15) S.pft[lane] = S.pf[lane];
   WSYNC();
   STAMP(ts, T_A1);
   // pass 2: H[lane][i] = sum_r At[i][r] At[lane][r] — or, where the orthonormal contact presolve applies and the constraints are
@@ -2290,7 +2329,48 @@ __device__ __forceinline__ void process_instance(Smem& S, const KA& A, const Dev
 #endif
   // warm start in the problem's own indexing: lane d <-> bound of DoF d, lane i <-> constraint row i
   const unsigned long long w0 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b] : 0ull, w1 = (WARM && A.ws_in) ? A.ws_in[2 * (size_t)b + 1] : 0ull;
-  if (!contact_presolve<WARM>(S, A, M, cfg, P, dpost, g, lb, ub, clb, cub, lane, ts, res, w0, w1) &&
+  // The refinement's residual in full space (lane d = DoF d): -grad f(x) = A'(b - A x) from the UNFACTORED task stack, block by block as pass 1
+  // formed it — the lane's column of every Cartesian block from its parked Jacobian column, the frame origins S.pf and the configuration's weights,
+  // e = b - A x by wave reductions against the targets S.bt, then the posture rows. Nothing of H enters (qp_refine says why). The CoM task's
+  // rows need the CoM Jacobian column too, which is not kept: those configurations (cond(H) ~ 1e6: 3e-8 without) are not refined here.
+  auto resid_full = [&](const double xd) -> double {
+    const double2a s0 = lds2(colst), s1 = lds2(colst + 2), s2 = lds2(colst + 4);
+    const double lt[3] = {s0.x, s0.y, s1.x}, at[3] = {s1.y, s2.x, s2.y};
+    double rr_ = 0.0;
+    int row_ = 0;
+#pragma unroll 1
+    for (unsigned tm = P.task_ee_mask; tm; tm &= tm - 1) {
+      const int e = __ffs((int)tm) - 1;
+      const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_EE0 + e] >> lane) & 1u);
+      const double w = cfg.ee_w[e];
+      const double pfe[3] = {S.pft[3 * e], S.pft[3 * e + 1], S.pft[3 * e + 2]};
+      double wxp[3];
+      cross3(at, pfe, wxp);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double a = sup ? cfg.ee_W[e][r] * ((r < 3 ? lt[r < 3 ? r : 0] + wxp[r < 3 ? r : 0] : at[r < 3 ? 0 : r - 3]) * w) : 0.0;
+        const double er = S.bt[row_ + r] - wsum(a * xd);
+        rr_ = fma(a, er, rr_);
+      }
+      row_ += 6;
+    }
+    if (cfg.task_trunk) {
+      const bool sup = (lane < nv) && ((M.frame_support[WBC_FR_TRUNK] >> lane) & 1u);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double a = sup ? (cfg.trunk_W[r] * (r < 3 ? lt[r < 3 ? r : 0] : at[r < 3 ? 0 : r - 3])) * cfg.trunk_w : 0.0;
+        const double er = S.bt[row_ + r] - wsum(a * xd);
+        rr_ = fma(a, er, rr_);
+      }
+      row_ += 6;
+    }
+    if (lane < nv) rr_ = fma(dpost, upost - dpost * xd, rr_);
+    return (lane < nv) ? rr_ : 0.0;
+  };
+  typedef Refine<decltype(resid_full)> RFULL;
+  const RFULL rfull{resid_full};
+  const int n_refine = cfg.task_com ? 0 : A.refine;
+  if (!contact_presolve<WARM, KA, RFULL>(S, A, M, cfg, P, dpost, g, lb, ub, clb, cub, lane, ts, res, w0, w1, rfull, n_refine) &&
       !(ORTH && contact_presolve_orth(S, A, M, cfg, P, g, lb, ub, clb, cub, lane, ts, res, direct))) {
     const int sb = (lane < 32) ? (int)(((w0 >> lane) & 1ull) | (((w0 >> (32 + lane)) & 1ull) << 1)) : 0;
     const int sr = (lane < 32) ? (int)(((w1 >> lane) & 1ull) | (((w1 >> (32 + lane)) & 1ull) << 1)) : 0;
@@ -2307,11 +2387,11 @@ __device__ __forceinline__ void process_instance(Smem& S, const KA& A, const Dev
         if (lane < A.prows) S.RC[lane * LDJ + k] = 0.0;
       }
       WSYNC();
-      res = qp_core<24>(S, (lane < n_eff) ? g : 0.0, lb, ub, clb, cub, n_eff, A.prows, lane, ts);
+      res = qp_core<24, Smem, LDJ, false, RFULL>(S, (lane < n_eff) ? g : 0.0, lb, ub, clb, cub, n_eff, A.prows, lane, ts, 0, 0, 0, rfull, n_refine);
       res.iters += ntail;
       if (lane >= n_eff) res.x = 0.0;
     } else
-    res = qp_core<NV, Smem, LDJ, WARM>(S, g, lb, ub, clb, cub, nv, A.prows, lane, ts, 0, sb == 3 ? 0 : sb, sr == 3 ? 0 : sr);
+    res = qp_core<NV, Smem, LDJ, WARM, RFULL>(S, g, lb, ub, clb, cub, nv, A.prows, lane, ts, 0, sb == 3 ? 0 : sb, sr == 3 ? 0 : sr, rfull, n_refine);
   }
   if (WARM && A.ws_out) {   // (res.ws_* are in full-problem indexing on every path; an unsolved QP carries nothing)
     const unsigned long long o0 = (__ballot(res.ws_b == 1) & 0xFFFFFFFFull) | (__ballot(res.ws_b == 2) << 32);
