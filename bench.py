@@ -146,9 +146,10 @@ class GpuEngine:
         self.bt = WbcBatch(self.model, args.batch, device_id=local)
         self.bt.configure(self.cfg)
         self.options = {"jtj_mfma": int(args.jtj_mfma), "presolve": 1, "presolve_orth": 1, "sim3_kernel": 1, "packed_kernel": 1, "packed_update": 1,
-                        "dbg_alias_inputs": 0}
+                        "dbg_alias_inputs": 0, "refine": 1}
         for env, opt in (("WBC_PRESOLVE", "presolve"), ("WBC_PRESOLVE_ORTH", "presolve_orth"), ("WBC_SIM3_KERNEL", "sim3_kernel"),
-                         ("WBC_PACKED_KERNEL", "packed_kernel"), ("WBC_PACKED_UPDATE", "packed_update"), ("WBC_DBG_ALIAS", "dbg_alias_inputs")):
+                         ("WBC_PACKED_KERNEL", "packed_kernel"), ("WBC_PACKED_UPDATE", "packed_update"), ("WBC_DBG_ALIAS", "dbg_alias_inputs"),
+                         ("WBC_REFINE", "refine")):
             if os.environ.get(env) not in (None, ""):       # diagnostic A/B switches: they change WHAT is measured, so they are reported
                 self.options[opt] = int(os.environ[env])
         for k, v in self.options.items():

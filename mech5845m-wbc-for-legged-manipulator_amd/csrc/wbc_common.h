@@ -2446,6 +2446,7 @@ template <bool WARM, bool ORTH>
 __device__ __forceinline__ void tail_instance(Smem* Sp, const int bt_v, const DevModel* __restrict__ models, const WbcConfig* __restrict__ cfgs,
                                               const DevPlan* __restrict__ plans) {   // (the kernel's own noalias table pointers: scalar loads)
   Smem& S = *Sp;
+  asm volatile("; WBC_TAIL_BEGIN" ::: "memory");                 // (a comment in the assembly listing: tools/hot_path_spills.py splits the ISA here)
   __attribute__((address_space(4))) const KernelArgs* Ap =
       (const __attribute__((address_space(4))) KernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(Ap));                                   // (opaque: these loads are not merged with, nor hoisted to, the kernel's entry loads)
@@ -2465,6 +2466,7 @@ __device__ __forceinline__ void tail_instance(Smem* Sp, const int bt_v, const De
   WSYNC();
   process_instance<MODE_TICK, WARM, ORTH>(S, A, models[mi], cfgs[mi], plans[mi], lc, cur, bt_, ln, 0ull);
   WSYNC();
+  asm volatile("; WBC_TAIL_END" ::: "memory");
 }
 
 static int check_launch(const char* what) {

@@ -851,6 +851,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_boxp_kernel(const KernelArgs A
   // ---- the tail: instances whose reduction did not hold are redone by this wave on the general path
   const unsigned long long tailm = __ballot(valid && flagged && s == 0);
   if (tailm) {
+    asm volatile("; WBC_TAIL_BEGIN" ::: "memory");   // (a comment in the assembly listing: tools/hot_path_spills.py cuts the control-flow graph here)
     if (valid && flagged && s == 0 && A.defer_stat) {
       unsigned long long old = *(volatile unsigned long long*)A.defer_stat, assumed;
       do {

@@ -461,6 +461,15 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
     }
     block(a0, a1, br, -1, true, true);
   }
+  // INEQ: the CoM box's rows and bounds (formed after the EE loop: their images must stay in AZ through the sweep) need the x / y rows of the CoM
+  // Jacobian columns and the CoM again. Live across the EE loop those nine doubles were spilled around it — 76 B per lane out and back, 1.2 KB of
+  // scratch traffic per tick each way (profiles/r03_pmc_summary_everything.txt: WRITE_SIZE 5x the outputs). They wait in LDS instead: the row
+  // bounds' slots X[204..] are written only after the loop.
+  double* const jst = I.X + 204;             // [16][4] jc0.x, jc0.y, jc1.x, jc1.y of lane s; then com.x, com.y
+  if (INEQ) {
+    sts2(jst + 4 * s, jc0[0], jc0[1]); sts2(jst + 4 * s + 2, jc1[0], jc1[1]);
+    if (s == 0) sts2(jst + 64, com[0], com[1]);
+  }
   const unsigned tmask = (unsigned)__builtin_amdgcn_readfirstlane((int)P.task_ee_mask);
   const unsigned armsup = (unsigned)__builtin_amdgcn_readfirstlane((int)P.q_armsup);
 #pragma unroll 1
@@ -518,9 +527,13 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
         cross3(ang0, ptr, wxp);
         a0[0] = lin0[2] + wxp[2]; a0[1] = ang0[0]; a0[2] = ang0[1]; a0[3] = ang0[2];
       }
-      if (c_con_com) { a0[4] = jc0[0]; a0[5] = jc0[1]; a1[4] = has1 ? jc1[0] : 0.0; a1[5] = has1 ? jc1[1] : 0.0; }
+      if (c_con_com) {
+        const double2a j0 = lds2(jst + 4 * s), j1 = lds2(jst + 4 * s + 2);
+        a0[4] = j0.x; a0[5] = j0.y; a1[4] = has1 ? j1.x : 0.0; a1[5] = has1 ? j1.y : 0.0;
+      }
       block(a0, a1, zr, -1, true, true, false);          // (the images stay in AZ through the sweep, which leaves X alone)
     }
+    const double2a comxy = lds2(jst + 64);                // (read before the row bounds take these slots)
     // bounds: the velocity damper of this lane's two DoF (:572-637) goes to its row of Z (base / stance leg) or to its reduced variable (arm); the
     // trunk box's and the CoM box's sides to rows 0..5
     double* const rbl = I.X + 204;            // row bounds [32] lower, [32] upper
@@ -556,8 +569,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
       }
       if (c_con_com && (s == 4 || s == 5)) {  // EE_frame_pos[1] = FL, [2] = RR (:675-677)
         const int r_ = s - 4;
-        tl = ((I.pf[3 * 2 + r_] - com[r_]) * inv_dt) * cb_s;
-        tu = ((I.pf[3 * 1 + r_] - com[r_]) * inv_dt) * cb_s;
+        const double cr_ = r_ ? comxy.y : comxy.x;
+        tl = ((I.pf[3 * 2 + r_] - cr_) * inv_dt) * cb_s;
+        tu = ((I.pf[3 * 1 + r_] - cr_) * inv_dt) * cb_s;
       }
     }
     WSYNC();                                 // (pf has been read)
@@ -1099,6 +1113,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
   // ---- the tail: instances left out above (a flagged leg block; diagnostic orth_qr) are redone by this wave on the general path
   const unsigned long long tailm = __ballot(valid && defer && s == 0);
   if (tailm) {
+    asm volatile("; WBC_TAIL_BEGIN" ::: "memory");   // (a comment in the assembly listing: tools/hot_path_spills.py cuts the control-flow graph here)
     if (valid && defer && s == 0 && A.defer_stat) {
       unsigned long long old = *(volatile unsigned long long*)A.defer_stat, assumed;
       do {

@@ -1270,6 +1270,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
 #ifndef WBC_NO_TAIL   // (A/B variant builds only: make variant VFLAGS=-DWBC_NO_TAIL measures what carrying the tail costs the common path)
   const unsigned long long tailm = __ballot(valid && flagged && s == 0);
   if (tailm) {
+    asm volatile("; WBC_TAIL_BEGIN" ::: "memory");   // (a comment in the assembly listing: tools/hot_path_spills.py cuts the control-flow graph here)
 #pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
       if (!((tailm >> (16 * rr)) & 1ull)) continue;
