@@ -28,6 +28,10 @@ struct WbcModel {
   DevModel dev;
 };
 
+// The packed sim3 kernel's batch-size policy (tools/small_batch.py, profiles/r04_small_batch_c3.txt): below this many instances a launch is a
+// single partial round of waves and one tick's latency is what counts.
+constexpr int WBC_SIM3P_MIN_BATCH = 1;
+
 struct WbcBatch {
   int device_id, n_models, max_batch, grid;
   const WbcModel* models[WBC_MAX_MODELS];
@@ -47,6 +51,7 @@ struct WbcBatch {
   int32_t* d_status;     // status buffer of our own when the caller passes none (the deferred pass needs one)
   int dbg_alias, dbg_stop;
   int count_pivoted, force_defer;   // diagnostics of the sim3 kernel's pivoted elimination / second pass
+  int packed_min_batch;  // the packed sim3 kernel takes batches from this many instances on (default WBC_SIM3P_MIN_BATCH; option "packed_min_batch")
   int packed_kernel;     // 1 (default): eligible batches run four instances per wavefront (wbc_tick_sim3p_kernel)
   int posture_par, last_posture_par;   // option [1]: MANI / HYBRID posture targets on wbc_posture_par_kernel (every finite-difference point on its own lane); what the last one ran on
   int packed_box;        // 1 (default): task problems without constraint rows (the warm-up problem) run four instances per wavefront (wbc_tick_boxp_kernel)
@@ -154,7 +159,7 @@ extern "C" int wbc_batch_create(const WbcModel* const* models, int n_models, int
   if (!b) return fail(WBC_E_ARG, "out of memory");
   memset(b, 0, sizeof *b);
   b->device_id = device_id; b->n_models = n_models; b->max_batch = max_batch; b->presolve = 1; b->presolve_orth = 1; b->packed_update = 1; b->sim3_kernel = 1; b->sing_tol = 1e-7;
-  b->jtj_mfma = -1; b->refine = 1; b->warm_start = 0; b->packed_kernel = 1; b->packed_orth = 1; b->packed_box = 1; b->posture_par = 1;
+  b->jtj_mfma = -1; b->refine = 1; b->packed_min_batch = WBC_SIM3P_MIN_BATCH; b->warm_start = 0; b->packed_kernel = 1; b->packed_orth = 1; b->packed_box = 1; b->posture_par = 1;
   std::vector<DevModel> dm(n_models);
   for (int i = 0; i < n_models; ++i) {
     if (!models[i]) { delete b; return fail(WBC_E_ARG, "wbc_batch_create: model %d is null", i); }
@@ -615,6 +620,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!strcmp(name, "presolve_tol_exp")) { double t = 1.0; for (int i = 0; i < value; ++i) t *= 0.1; b->sing_tol = t; return WBC_OK; }
   if (!strcmp(name, "sim3_kernel")) { b->sim3_kernel = value; return WBC_OK; }
   if (!strcmp(name, "packed_kernel")) { b->packed_kernel = value; return WBC_OK; }
+  if (!strcmp(name, "packed_min_batch")) { b->packed_min_batch = value < 1 ? 1 : value; return WBC_OK; }
   if (!strcmp(name, "packed_orth")) { b->packed_orth = value; return WBC_OK; }
   if (!strcmp(name, "packed_box")) { b->packed_box = value; return WBC_OK; }
   if (!strcmp(name, "posture_par")) { b->posture_par = value; return WBC_OK; }
@@ -839,7 +845,7 @@ static int launch_update_auto(WbcBatch* b, UpdateArgs& u, int B, void* stream) {
 }
 static bool packed_eligible(const WbcBatch* b, const KernelArgs& a) {
   const bool qcon = a.in.q_con || a.in.posture_u;     // the QCON variant (second kinematics pass at q_con, posture target from posture_u)
-  bool packed = b->packed_kernel &&
+  bool packed = b->packed_kernel && a.B >= b->packed_min_batch &&
                 !b->count_pivoted && !(b->dbg_stop > 0 && b->dbg_stop < 100) && !b->dbg_alias;   // (dbg_stop 101.. cuts the packed kernel)
   for (int i = 0; i < b->n_models && packed; ++i) packed = qcon ? (b->plan_host[i].packed_ok_pu != 0) : (b->plan_host[i].packed_ok != 0);
   return packed;

@@ -28,10 +28,19 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   __shared__ union { SmemP P; Smem G; } SU;
   static_assert(sizeof(Smem) <= 20480 && sizeof(SmemP) <= 20480, "8 waves per CU");
   SmemP& SP = SU.P;
-  const int lane = threadIdx.x, r = lane >> 4, s = lane & 15, rbase = lane & 48;
+#ifndef SIM3P_ITERS
+#define SIM3P_ITERS 1      // experiment (variant builds): groups of four instances a wave processes one after the other (grid = groups / SIM3P_ITERS)
+#endif
+  unsigned long long tail_all = 0ull;      // (SIM3P_ITERS > 1: bit 4 it + row = an instance left to the tail, which runs after the loop)
+#pragma unroll 1
+  for (int it_ = 0; it_ < SIM3P_ITERS; ++it_) {
+  const int grp = (SIM3P_ITERS > 1) ? (int)(blockIdx.x + it_ * gridDim.x) : (int)blockIdx.x;
+  int lane = threadIdx.x;
+  if (SIM3P_ITERS > 1) { WSYNC(); asm volatile("" : "+v"(lane) :: "memory"); }   // (opaque per trip: nothing derived from the lane index is loop invariant)
+  const int r = lane >> 4, s = lane & 15, rbase = lane & 48;
   PInst& I = SP.I[r];
   PVec& V = SP.V[r];
-  const int b_raw = 4 * blockIdx.x + r;
+  const int b_raw = 4 * grp + r;
   const bool valid = b_raw < A.B;
   const int b = valid ? b_raw : A.B - 1;
   int mid = 0;
@@ -1137,10 +1146,13 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // with 1e-5 relative error, which IS the 1e-6 the plain method is off by (cond(H) ~ 3e9); the least-squares residual's own rounding lies in
   // the range of (A Z)', where H' is well conditioned.
   if (A.refine > 0) {
+    // r2 — the active constraints' own residual b_k - n_k'y — is formed on the WARM variant only (its iterate is rebuilt from the factors after the
+    // seeds: refresh). On the cold path the dual method's steps keep the working set satisfied to rounding and the term changes nothing (same-box
+    // check: 6.68e-9 worst with and without it).
     WSYNC();
     V.xv[s] = has_b ? x : 0.0;
-    V.cl[s] = lb; V.cl[16 + s] = ub; V.tv[s] = clb; V.dv[s] = cub;
     V.yv[s] = 0.0;
+    if (WARM) { V.cl[s] = lb; V.cl[16 + s] = ub; V.tv[s] = clb; V.dv[s] = cub; }
     WSYNC();
     const double2a x0 = lds2(V.xv), x1_ = lds2(V.xv + 2), x2 = lds2(V.xv + 4);
     auto rowval = [&](const int rr_) -> double {     // C'_rr y (every reduced row has base support only)
@@ -1148,56 +1160,77 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
       return fma(c0.x, x0.x, fma(c0.y, x0.y, fma(c1.x, x1_.x, fma(c1.y, x1_.y, fma(c2.x, x2.x, c2.y * x2.y)))));
     };
     const double vrow = has_r ? rowval(s) : 0.0;     // row s at y; rows p_keep + l: the velocity of leg DoF l
-    // slot s: residual and signed multiplier of its constraint
+    // slot s: the signed multiplier of its constraint
     const int cc = a_code & 255, sd = (a_code >> 8) & 1;
-    const bool slot = s < q, srow = cc >= n;
+    const bool slot = s < q, srow = slot && cc >= n;
     const int rr_ = srow ? ((cc - n) & 15) : 0, iv = cc & 15;
     const double sgn = sd ? -1.0 : 1.0;
-    const double val = srow ? rowval(rr_) : V.xv[iv];
-    const double bnd = srow ? (sd ? V.dv[rr_] : V.tv[rr_]) : (sd ? V.cl[16 + iv] : V.cl[iv]);
-    const double r2 = slot ? sgn * (bnd - val) : 0.0;
     const double us = slot ? sgn * u : 0.0;
+    double r2 = 0.0;
+    if (WARM) {
+      const double vbd = V.xv[iv];
+      const double val = srow ? rowval(rr_) : vbd;
+      const double* const bsrc = srow ? ((sd ? V.dv : V.tv) + rr_) : (V.cl + (sd ? 16 : 0) + iv);
+      r2 = slot ? sgn * (*bsrc - val) : 0.0;
+    }
     const double bpl = bperm(bp1, rbase + ((s - p_keep) & 15));     // posture target of the leg DoF whose velocity row s carries
+    const double wl = (s >= p_keep && s < p) ? dpost * (bpl - dpost * vrow) : 0.0;   // the leg DoF's posture residual: row s's weight in r1
     WSYNC();
-    V.dv[s] = 0.0;
-    if (s >= p_keep && s < p) V.yv[s] = dpost * (bpl - dpost * vrow);   // weights of the rows in r1: the leg DoF's posture residual ...
-    WSYNC();
-    if (slot && srow) V.yv[rr_] += us;                                  // ... and the active rows' multipliers on top
-    if (slot && !srow) V.dv[iv] = us;                                   // active bounds' multipliers by variable
+    V.xv[s] = wl;
+    if (srow) V.yv[rr_] = us;                                           // the active rows' multipliers (yv was cleared above)
+    if (slot && !srow) V.dv[iv] = us;                                   // active bounds' multipliers by variable (read where actm says so)
+    if (WARM) V.cl[s] = r2;
     // Grip rows: e = b - (A Z) y, then (A Z)'e
     double r1 = 0.0;
-#pragma unroll
-    for (int rr = 0; rr < 6; ++rr) {
-      const double e = V.in[28 + rr] - rsum16(has_b ? a[rr] * x : 0.0);
-      r1 = fma(a[rr], e, r1);
-    }
-    if (TRUNK) {                            // trunk rows (base columns): the same with their image and targets
+    {
+      const double2a b0 = lds2(V.in + 28), b1 = lds2(V.in + 30), b2 = lds2(V.in + 32);
+      const double btv[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+      const double xm = has_b ? x : 0.0;
+      // (the products are made opaque: fused into the butterfly's first add — a x + neighbour's rounded product — the two lanes of a pair end with
+      //  sums one rounding apart, e differs from lane to lane, and r1 = sum a e leaves the range of (A Z)': 5e-7 on q̇ instead of 7e-9, measured)
 #pragma unroll
       for (int rr = 0; rr < 6; ++rr) {
-        const double e = V.pad_[rr] - rsum16(has_b ? at6[rr] * x : 0.0);
-        r1 = fma(at6[rr], e, r1);
+        double pr = a[rr] * xm;
+        asm volatile("" : "+v"(pr));
+        r1 = fma(a[rr], btv[rr] - rsum16(pr), r1);
+      }
+      if (TRUNK) {                            // trunk rows (base columns): the same with their image and targets
+        const double2a t0 = lds2(V.pad_), t1 = lds2(V.pad_ + 2), t2 = lds2(V.pad_ + 4);
+        const double ttv[6] = {t0.x, t0.y, t1.x, t1.y, t2.x, t2.y};
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) {
+          double pr = at6[rr] * xm;
+          asm volatile("" : "+v"(pr));
+          r1 = fma(at6[rr], ttv[rr] - rsum16(pr), r1);
+        }
       }
     }
     r1 = fma(dpost, bp0 - dpost * x, r1);
     WSYNC();
-    r1 += V.dv[s];
+    if (actm & 1) r1 += V.dv[s];
     if (s < 6) {
 #pragma unroll
-      for (int rr = 0; rr < PN; ++rr) r1 = fma((rr < p) ? I.Cq[rr * 6 + s] : 0.0, V.yv[rr], r1);
+      for (int rr = 0; rr < PN; rr += 2) {
+        const double2a m2 = lds2(V.yv + rr), l2 = lds2(V.xv + rr);
+        r1 = fma((rr < p) ? I.Cq[rr * 6 + s] : 0.0, m2.x + l2.x, r1);
+        r1 = fma((rr + 1 < p) ? I.Cq[(rr + 1) * 6 + s] : 0.0, m2.y + l2.y, r1);
+      }
     }
     if (!has_b) r1 = 0.0;
-    WSYNC();
-    V.tv[s] = r1; V.dv[s] = r2;
+    V.tv[s] = r1;
     WSYNC();
     const int sv = s < PV ? s : PV - 1;
     double dy1 = 0.0, dy2 = 0.0;
 #pragma unroll
-    for (int j = 0; j < PV; ++j) {
-      dy1 = fma(T[j * PLD + sv], V.dv[j], dy1);       // T'r2 (T is zero outside the slots)
-      dy2 = fma(J[j * PLD + sv], V.tv[j], dy2);       // J'r1
+    for (int j = 0; j < PV; j += 2) {
+      const double2a r1v = lds2(V.tv + j);
+      dy2 = fma(J[j * PLD + sv], r1v.x, fma(J[(j + 1) * PLD + sv], r1v.y, dy2));       // J'r1
+      if (WARM) {
+        const double2a r2v = lds2(V.cl + j);
+        dy1 = fma(T[j * PLD + sv], r2v.x, fma(T[(j + 1) * PLD + sv], r2v.y, dy1));     // T'r2 (T is zero outside the slots)
+      }
     }
-    WSYNC();
-    V.yv[s] = (s < PV) ? ((s < q) ? dy1 : dy2) : 0.0;
+    V.yv[s] = (s < PV) ? ((s < q) ? dy1 : dy2) : 0.0;                                  // (every lane read yv before the last fence)
     WSYNC();
     double da = 0.0, db = 0.0;
 #pragma unroll
@@ -1269,12 +1302,26 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // shared with the packed layout). No list, no second launch, and a batch that defers everything runs at the general kernel's occupancy.
 #ifndef WBC_NO_TAIL   // (A/B variant builds only: make variant VFLAGS=-DWBC_NO_TAIL measures what carrying the tail costs the common path)
   const unsigned long long tailm = __ballot(valid && flagged && s == 0);
-  if (tailm) {
+  if (SIM3P_ITERS > 1) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) if ((tailm >> (16 * rr)) & 1ull) tail_all |= 1ull << (4 * it_ + rr);
+  } else if (tailm) {
     asm volatile("; WBC_TAIL_BEGIN" ::: "memory");   // (a comment in the assembly listing: tools/hot_path_spills.py cuts the control-flow graph here)
 #pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
       if (!((tailm >> (16 * rr)) & 1ull)) continue;
-      tail_instance<WARM, false>(&SU.G, 4 * (int)blockIdx.x + rr, models, cfgs, plans);
+      tail_instance<WARM, false>(&SU.G, 4 * grp + rr, models, cfgs, plans);
+    }
+  }
+#endif
+  }   // (SIM3P_ITERS)
+#ifndef WBC_NO_TAIL
+  if (SIM3P_ITERS > 1 && tail_all) {
+    asm volatile("; WBC_TAIL_BEGIN" ::: "memory");
+#pragma unroll 1
+    for (int k = 0; k < 4 * SIM3P_ITERS; ++k) {
+      if (!((tail_all >> k) & 1ull)) continue;
+      tail_instance<WARM, false>(&SU.G, 4 * (int)(blockIdx.x + (k >> 2) * gridDim.x) + (k & 3), models, cfgs, plans);
     }
   }
 #endif
@@ -1311,7 +1358,7 @@ KDECL(true, false, true)
 #if SIM3P_PART <= 0
 int launch_tick_sim3p(const KernelArgs& a, void* stream) {
   const bool warm = a.ws_in || a.ws_out, trunk = a.in.trunk_target && a.packed_trunk, qcon = a.in.q_con || a.in.posture_u;
-  const dim3 grid((a.B + 3) / 4);
+  const dim3 grid(((a.B + 3) / 4 + SIM3P_ITERS - 1) / SIM3P_ITERS);
   if (qcon && warm) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<true, false, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   else if (qcon) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<false, false, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   else if (warm && trunk) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<true, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);

@@ -3,7 +3,7 @@
 is told apart from the packed path by the line tables of the device-only listing (hipcc -S -g1): see analyse(). Prints, per kernel variant,
 the scratch_load / scratch_store instructions on the packed path and in the tail and, with -v, the source lines the packed path's belong to.
 CPU only (cross-compiles):
-    python tools/hot_path_spills.py [family.part ...]      default: sim3p.0 orthp.0 orthp.1 boxp.0"""
+    python tools/hot_path_spills.py [-v] [family.part ...]      default: sim3p.0 orthp.0 orthp.1 boxp.0   (WBC_XFLAGS="-D..." adds compiler flags)"""
 import os
 import re
 import subprocess
@@ -19,7 +19,7 @@ def listing(part):
     fam, k = part.split(".")
     out = os.path.join(tempfile.gettempdir(), "wbc_%s_%s.s" % (fam, k))
     subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "--cuda-device-only", "-S", "-g1",
-                           "-D%s_PART=%s" % (fam.upper(), k), os.path.join(CSRC, "wbc_k_%s.hip" % fam), "-o", out])
+                           "-D%s_PART=%s" % (fam.upper(), k)] + os.environ.get("WBC_XFLAGS", "").split() + [os.path.join(CSRC, "wbc_k_%s.hip" % fam), "-o", out])
     return open(out).read()
 
 
