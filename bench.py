@@ -300,7 +300,7 @@ def run_rank(args, comm, engine, make_inputs):
         "config": {"workload": "BASELINE configs[2] / SURVEY C3: A1+wx200 (nq 27, nv 26), sim3 switch set: Grip task + " + args.posture + " posture, "
                                "12 contact equalities + 4 trunk-box rows + 26 damper bounds (3 locked), m=32 p=16 n=26",
                    "batch_per_gpu": B, "global_batch": B * world, "dt": DT, "parallelism": "shard%d (no collective)" % world,
-                   "engine": engine.name, "kernel_path": engine.path(), "options": getattr(engine, "options", {}),
+                   "engine": engine.name, "backend": getattr(engine, "backend", None), "kernel_path": engine.path(), "options": getattr(engine, "options", {}),
                    "jtj": "mfma_f64" if getattr(engine, "options", {}).get("jtj_mfma", -1) > 0 else "valu_f64"},
         "repeats": {"n": R, "ms_per_step": [1e3 * e / K for e in elapsed], "kernel_ms_per_step": kernel_ms,
                     "spread": (max(elapsed) - min(elapsed)) / t_med, "reported": "median block"},
@@ -414,8 +414,15 @@ def main(argv=None):
         engine = getattr(mod, cls)(args, local)
         comm = Comm("gloo", rank, world, None)
     else:
+        # one rank per GPU. WBC_BENCH_SHARE_GPU=1 (rehearsals on a box with fewer GPUs than ranks): rank r uses device r mod the device count and
+        # the collectives run over gloo — RCCL refuses two ranks on one device; the line then says "backend": "gloo"
+        share = os.environ.get("WBC_BENCH_SHARE_GPU") == "1"
+        if share:
+            import torch
+            local = local % max(1, torch.cuda.device_count())
         engine = GpuEngine(args, local)
-        comm = Comm("nccl", rank, world, engine.dev)
+        comm = Comm("gloo" if share else "nccl", rank, world, None if share else engine.dev)
+        engine.backend = "gloo (ranks share GPUs: rehearsal)" if share else "nccl (RCCL)"
     line, res = run_rank(args, comm, engine, make_inputs)
     ok = True
     if rank == 0:
@@ -442,8 +449,8 @@ def main(argv=None):
 def launch_ranks(n, argv, timeout_s=None):
     """`python bench.py --gpus N` without a launcher: start N fresh interpreters of this file, one per GPU, with the
     environment torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free
-    MASTER_PORT), wait for all of them, and return the worst exit code. Rank 0 inherits stdout (its JSON line is the job's
-    line); the other ranks' stdout goes to stderr. This process never imports torch nor touches a GPU and never execs: the
+    MASTER_PORT), wait for all of them, and return the worst exit code. Rank 0's JSON line is forwarded to stdout (the job's
+    line); everything else the ranks print goes to stderr. This process never imports torch nor touches a GPU and never execs: the
     children are ordinary child processes. If one rank dies the others (who would wait at the next barrier for ever) are
     terminated by their exact PIDs."""
     import socket
@@ -457,7 +464,16 @@ def launch_ranks(n, argv, timeout_s=None):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=None if r == 0 else sys.stderr))
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    # rank 0's stdout is filtered: only its JSON line reaches ours (communication libraries print banners there), the rest goes to stderr
+    import threading
+
+    def pump(p):
+        for ln in p.stdout:
+            (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
+            sys.stdout.flush()
+    th = threading.Thread(target=pump, args=(procs[0],), daemon=True)
+    th.start()
     t0, worst = time.time(), 0
     alive = list(procs)
     while alive:
@@ -483,6 +499,7 @@ def launch_ranks(n, argv, timeout_s=None):
                     p.wait()
             worst = worst or 1
             alive = []
+    th.join(timeout=10)
     return worst
 
 
