@@ -202,7 +202,7 @@ class GpuEngine:
                 "worst_status_histogram": {name: int((st == code).sum()) for code, name in enumerate(("optimal", "max_iter", "infeasible", "numerical"))},
                 "optimal_frac": float((st == 0).mean()), "iters_per_tick": float(ro["iters"].double().mean().item()) / ticks}
 
-    def other_configs(self):
+    def other_configs(self, check=True):
         """Context for the headline (not bench lines): BASELINE configs[1] (five EE tasks + CoM task, contact equalities, no
         velocity box) at its own batch 1024 and at 65536, the warm-up problem and the tests' all-tasks / all-constraints stack at 65536 —
         each on the kernel the library picks."""
@@ -244,8 +244,18 @@ class GpuEngine:
             self.sync()
             ms = ev0.elapsed_time(ev1) / 10
             path = bt.stat("last_path")
+            acc = {"gated": False}
+            if check:       # the same run's answers against the oracle on a sub-sample (the checker, after the timed region): these numbers are quoted too
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle
+                nchk = min(B, 2048)
+                ref = oracle.tick([self.model], [cfg], {k: v[:nchk] for k, v in d.items()}, DT, nchk, nthreads=min(32, len(os.sched_getaffinity(0))), want_q_next=False)
+                gq, gs = dev_out["qdot"][:nchk].cpu().numpy(), dev_out["status"][:nchk].cpu().numpy()
+                okc = (ref["status"] == 0) & (gs == 0)
+                acc = {"gated": True, "instances_checked": int(nchk), "status_agree_frac": float((ref["status"] == gs).mean()),
+                       "qdot_max_abs_err_vs_cpu": float(np.abs(gq - ref["qdot"])[okc].max()) if okc.any() else None}
             out["%s_B%d" % (name, B)] = {"ticks_per_s": B / ms * 1e3, "ms_per_step": ms, "task_rows": bt.task_rows, "constraint_rows": bt.constraint_rows,
-                                         "optimal_frac": float((dev_out["status"] == 0).double().mean().item()),
+                                         "optimal_frac": float((dev_out["status"] == 0).double().mean().item()), "accuracy": acc,
                                          "kernel_path": ("wbc_tick_orthp_kernel<INEQ> (packed: four instances per wavefront)" if bt.constraint_rows > 12 else
                                                          "wbc_tick_orthp_kernel (packed: four instances per wavefront)") if path == 3 else
                                                         "wbc_tick_boxp_kernel (packed: four instances per wavefront)" if path == 4 else
@@ -378,6 +388,7 @@ def cpu_baseline_and_accuracy(line, engine, host_in, res, args):
     pct = {name: float(np.percentile(e_inst, q)) for name, q in (("p50", 50), ("p99", 99), ("p99_9", 99.9))}
     line["accuracy"] = {"qdot_max_abs_err_vs_cpu": err, "qdot_err_percentiles": dict(pct, max=err), "status_agree_frac": agree,
                         "tolerance": QDOT_TOL, "instances": int(n), "instances_compared": int(ok.sum()),
+                        "refine_steps": getattr(engine, "options", {}).get("refine"),
                         "pass": bool(err < QDOT_TOL and agree == 1.0)}
     return line["accuracy"]["pass"]
 
@@ -436,7 +447,7 @@ def main(argv=None):
                                                   unit="closed-loop ticks/s per GPU", ticks=args.rollout_ticks,
                                                   inputs="same distribution without the stress recipe")
         if args.rollout_ticks > 0 and world == 1:
-            line["configs"] = engine.other_configs()
+            line["configs"] = engine.other_configs(check=not args.no_cpu_baseline)
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             ok = cpu_baseline_and_accuracy(line, engine, engine.host_in, res, args)
         print(json.dumps(line), flush=True)
@@ -444,6 +455,11 @@ def main(argv=None):
     engine.close()
     if not ok:
         raise SystemExit("bench.py: accuracy gate failed (see \"accuracy\" in the line above)")
+    if rank == 0 and line is not None:
+        for name, c in (line.get("configs") or {}).items():      # the context configurations' own gate (their numbers are quoted too)
+            a = c.get("accuracy", {})
+            if a.get("gated") and (a["status_agree_frac"] != 1.0 or (a["qdot_max_abs_err_vs_cpu"] is not None and not a["qdot_max_abs_err_vs_cpu"] < QDOT_TOL)):
+                raise SystemExit("bench.py: context configuration %s fails its accuracy gate: %s" % (name, a))
 
 
 def launch_ranks(n, argv, timeout_s=None):

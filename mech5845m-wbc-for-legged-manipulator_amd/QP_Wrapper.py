@@ -93,6 +93,7 @@ class QP:
         return x[0]
 
     def solveQP(self):
+        self._ws = None                 # a cold solve builds a fresh QProblem (QP_Wrapper.py:26-29): no working set is carried into it or past a failed one
         x = self._solve()
         self.xOpt = np.zeros((self.no_solutions,))
         if self.status == 0:            # qpOASES' getPrimalSolution leaves its argument alone for an unsolved QP (:50-51)

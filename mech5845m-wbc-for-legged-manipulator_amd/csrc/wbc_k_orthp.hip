@@ -1105,7 +1105,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_orthp_kernel(const KernelArgs 
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
         const int d = 6 + s + 16 * h2;
-        if (d < nv) { const int qi = d + 1; qn[qi] = qv[qi] + I.gp[d] * dt; }   // (one free-flyer + 1-DoF joints: q index = DoF + 1)
+        if (d < nv) { const int qi = M.col_q[d]; qn[qi] = qv[qi] + I.gp[d] * dt; }   // (the model's own q index of DoF d, as the other packed kernels read it)
       }
       if (s < NQ - nq) qn[nq + s] = 0.0;
     }

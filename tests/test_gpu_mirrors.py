@@ -27,7 +27,7 @@ def test_qp_class_matches_reference_surface_and_oracle():
     qp = QP(A, b, a["lb"][0], a["ub"][0], Cview, a["Clb"][0], a["Cub"][0], n_of_velocity_dimensions=26)
     x = qp.solveQP()
     assert x is qp.xOpt and x.shape == (26,) and qp.status == 0
-    assert np.abs(x - ref["qdot"][0]).max() < 1e-5
+    assert np.abs(x - ref["qdot"][0]).max() < 1e-7      # (the refinement, QP_Wrapper.py:37 numRefinementSteps, reaches the mirror: the oracle refines too)
     assert np.abs(qp.H - A.T @ A).max() < 1e-12 and np.abs(qp.g + A.T @ b).max() < 1e-12      # QP_Wrapper.py:17-18
     for k in (1, 2):                                   # hotstart: new H, g, C each call; the same ndarray comes back
         y = qp.solveQPHotstart(a["A"][k], a["b"][k], a["lb"][k], a["ub"][k], a["C"][k].T, a["Clb"][k], a["Cub"][k])
@@ -49,6 +49,20 @@ def test_qp_class_matches_reference_surface_and_oracle():
     qm = QP(A, b, a["lb"][0], a["ub"][0], Cview, a["Clb"][0], a["Cub"][0], n_of_velocity_dimensions=26)
     qm.use_mfma = True                                  # J'J on the fp64 matrix cores: same answer
     assert np.abs(qm.solveQP() - ref["qdot"][0]).max() < 1e-5
+    # the refinement (QP_Wrapper.py:37 numRefinementSteps) reaches the mirror: QP(A, b, ...) is within 1e-7 of the oracle, which refines too
+    assert np.abs(qm.xOpt - ref["qdot"][0]).max() < 1e-7
+    # the reference's state machine: a cold solveQP carries no working set — neither into it nor past a FAILED one. An infeasible
+    # problem (contradictory trunk box) through solveQP, then a feasible hot start: solved from an empty set, like a fresh QProblem's first hotstart
+    bad_lo, bad_hi = a["Clb"][0].copy(), a["Cub"][0].copy()
+    bad_lo[0], bad_hi[0] = 50.0, 60.0                   # trunk z rate far beyond every velocity bound
+    qf = QP(A, b, a["lb"][0], a["ub"][0], Cview, a["Clb"][0], a["Cub"][0], n_of_velocity_dimensions=26)
+    qf.solveQP()
+    assert qf.status == 0 and qf._ws is not None
+    qf.Clb, qf.Cub = bad_lo, bad_hi
+    xf = qf.solveQP()
+    assert qf.status != 0 and qf._ws is None and (xf == 0).all()          # unsolved: zeros (the fresh xOpt of :50), nothing carried
+    yh = qf.solveQPHotstart(a["A"][1], a["b"][1], a["lb"][1], a["ub"][1], a["C"][1].T, a["Clb"][1], a["Cub"][1])
+    assert qf.status == 0 and np.abs(yh - ref["qdot"][1]).max() < 1e-5 and int(qf.nWSR[0]) == int(ref["iters"][1])   # a cold count: no seed
 
 
 def test_integration_md_ctypes_stub_runs_as_written():

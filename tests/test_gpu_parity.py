@@ -513,6 +513,37 @@ def test_pivoted_elimination_and_second_pass_match_the_oracle(wx200, px100, tol_
     bt.close()
 
 
+def test_packed_orth_ineq_tail_hot_started_matches_cold(wx200):
+    """an instance the packed orth kernel's INEQ variant leaves to its tail is redone on the general kernel's ORTH variant when the tick
+    is cold and on its warm full-size path when a working set is passed — two numerical routes to one QP. Option orth_qr sends EVERY instance to
+    the tail: status and q̇ must agree between the two and with the oracle, and the tail's working set must seed the packed kernel back."""
+    B = 300
+    cfg = common.config("everything", wx200)
+    d = common.tick_inputs(wx200, cfg, B, seed=67, with_rot=True)
+    ref = oracle.tick([wx200], [cfg], d, DT, B, nthreads=8)
+    ok = ref["status"] == 0
+    bt = WbcBatch(wx200, B)
+    bt.configure(cfg)
+    bt.set_option("packed_orth", 2)
+    packed = bt.tick(d, DT, want_working_set=True)                    # the packed path itself (its WARM variant: a set is asked for)
+    assert bt.stat("last_path") == 3 and bt.stat("deferred_last") < 0.05 * B
+    bt.set_option("orth_qr", 1)
+    cold = bt.tick(d, DT)
+    assert bt.stat("last_path") == 3 and bt.stat("deferred_last") == B
+    warm = bt.tick(dict(d, working_set=packed["working_set"]), DT, want_working_set=True)
+    assert bt.stat("last_path") == 3 and bt.stat("deferred_last") == B
+    for name, got in (("cold tail", cold), ("hot-started tail", warm), ("packed", packed)):
+        assert (got["status"] == ref["status"]).all(), name
+        assert np.abs(got["qdot"] - ref["qdot"])[ok].max() < 1e-6, (name, np.abs(got["qdot"] - ref["qdot"])[ok].max())
+    assert np.abs(warm["qdot"] - cold["qdot"])[ok].max() < 1e-6
+    assert warm["iters"][ok].mean() <= cold["iters"][ok].mean() + 1e-9          # seeded with the optimum's own set: never more working-set changes
+    assert (warm["working_set"][ok] == packed["working_set"][ok]).all(axis=1).mean() > 0.97
+    bt.set_option("orth_qr", 0)
+    back = bt.tick(dict(d, working_set=warm["working_set"]), DT)                # the tail's set seeds the packed kernel
+    assert bt.stat("deferred_last") < 0.05 * B and (back["status"] == ref["status"]).all() and np.abs(back["qdot"] - ref["qdot"])[ok].max() < 1e-6
+    bt.close()
+
+
 @pytest.mark.parametrize("tol_exp,warm", [(0, 0), (3, 0), (3, 1)])
 def test_packed_kernel_redoes_what_it_cannot_reduce_in_its_own_tail(wx200, px100, tol_exp, warm):
     """The packed kernel launches no second pass: an instance it leaves out (a stance-leg block of rank < 2; here every flagged block, through
@@ -1067,7 +1098,7 @@ def test_packed_box_kernel_variants_and_non_finite_inputs(wx200, px100, variant)
         bt.configure(c, i)
     assert bt.constraint_rows == 0
     got = bt.tick(d, DT, want_q_next=True)
-    assert bt.stat("last_path") == 4                                   # the default policy: packed from 4608 instances on
+    assert bt.stat("last_path") == 4                                   # the default policy: the packed box kernel at every batch size (WBC_BOXP_MIN_BATCH = 1)
     ok = ref["status"] == 0
     # the tail takes exactly the instances whose optimum holds an ELIMINATED DoF (base; wx200: + the first thigh) at its velocity bound: none in the
     # warm-up problem (the trunk task pins the base), a handful without the trunk task
@@ -1420,7 +1451,7 @@ def test_batched_warm_up_matches_the_oracle(wx200, px100):
     # working-set changes: equal for wx200; the oracle also counts px100's padded 26th DoF (a locked bound) once per tick
     assert np.abs(short["iters"] - ref["iters"])[mid == 0].max() <= 4
     assert np.abs(short["iters"] + 100 - ref["iters"])[mid == 1].max() <= 4
-    # the same warm-up with every tick on the packed box kernel (the default policy takes it from 4608 robots on) and the packed state update
+    # the same warm-up with every tick on the packed box kernel (the default policy: at every batch size) and the packed state update
     bt.set_option("packed_box", 2)
     packed = bt.warm_up(q0, mid, DT, 50, foot_radius=fr)
     assert bt.stat("last_path") == 4 and bt.stat("last_update_packed") == 1
