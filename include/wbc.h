@@ -152,7 +152,7 @@ typedef struct WbcTickIn {
                                                 constraint rows in findConstraints' order (bit i: row i at Clb, bit 32 + i: at Cub).
                                                 Any bit pattern is accepted: a seed is used only if the equalities-only minimiser
                                                 violates it or comes close to it, and wrong seeds are dropped again (restoration
-                                                + refresh, wbc_kernels.hip qp_core); NULL or zeros => cold start */
+                                                + refresh, csrc/wbc_common.h qp_core); NULL or zeros => cold start */
 } WbcTickIn;
 
 #define WBC_Q_STRIDE 27   /* doubles per instance in q / q_next (nq of the largest model)           */
@@ -359,9 +359,26 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          per active inequality (0.9-1.05 here), a seed replaces it by an add step + a share of the rebuild, and
  *                          both pay the final feasibility scan. Off by default; never the 2.2x of round 2's fallback kernel.
  *                          (wbc_tick is warm exactly when WbcTickIn.working_set is passed.)
+ *   "refine"           [1] steps of iterative refinement at the final working set (0, 1, 2) — the analogue of the reference's
+ *                          qpOASES option numRefinementSteps = 100 (QP_Wrapper.py:37). With the active normals N, their multipliers u
+ *                          and the dual method's factors (J J' = H^-1, J'N' = [R; 0]):  r1 = -(grad f - N'u),  x += J2 J2' r1 (+ the
+ *                          active rows' own residual through R). grad f is formed from the UNFACTORED least-squares data — A'(A x - b)
+ *                          as two products, task block by task block, never through H = A'A: fl(A'A) carries the benchmark tick's
+ *                          1.5e-9 posture block with 1e-5 relative error, which is the whole 1e-6 the plain method is off by at
+ *                          cond(H) ~ 3e9. One step lands within 1e-8 of the exact least-squares optimum (oracle: qp_refine; both sides
+ *                          refine, so the parity margin on BASELINE configs[2] went from 5.7e-6 to 6.6e-8 against the 1e-5 tolerance,
+ *                          profiles/r04_soak_long.txt). Cost on the benchmark: 5.5 % (profiles/r04_ab_refine.txt). Refined: the packed
+ *                          sim3 kernel and its variants, the general kernel (full size and structural presolve), wbc_qp_solve_ls
+ *                          (wbc_qp_solve can only use -(H x + g): no gain where H itself is the rounding). Not refined, because their
+ *                          stacks are well conditioned (1e-8 .. 1e-10 without): the packed orth / box kernels and the orthonormal
+ *                          presolve; and the one-instance compact kernel (path 1: no room at 168 VGPRs / 13 KB LDS) — with refine > 0
+ *                          what it would take runs on the general kernel instead (refine = 0 brings it back).
+ *   "packed_min_batch" [1] the packed sim3 kernel takes batches from this many instances on. 1: it is the fastest path of the sim3
+ *                          family at EVERY batch size (13.6 us at B = 1 against 19 us on either one-instance kernel, 41 vs 53-55 us at
+ *                          1024: profiles/r04_small_batch_c3.txt).
  *   "grid"                 workgroups of the grid-stride kernels (wbc_qp_solve*, wbc_integrate); default = what fills the chip.
  *   "dbg_alias_inputs" [0] diagnostic: every instance reads instance 0's inputs (isolates input latency in timings).
- *   "dbg_stop"         [0] diagnostic (ablation build of the library only): the sim3 kernel stops after stage k (1..7, see wbc_kernels.hip;
+ *   "dbg_stop"         [0] diagnostic (ablation build of the library only): the sim3 kernel stops after stage k (1..7, see csrc/wbc_k_sim3.hip;
  *                          101.. the packed sim3 kernel, 201.. the packed orth kernel, 301.. the packed box kernel) — outputs are garbage,
  *                          only the run time means something (tools/ablate_sim3.py, ablate_orthp.py, ablate_boxp.py). */
 int wbc_batch_set_option(WbcBatch* b, const char* name, int value);

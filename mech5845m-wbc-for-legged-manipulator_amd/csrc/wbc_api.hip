@@ -226,7 +226,7 @@ static int any_orth_plan(const WbcBatch* b) {
   return 0;
 }
 
-// Which stance feet's contact equalities the tick kernel eliminates structurally (contact_presolve in wbc_kernels.hip).
+// Which stance feet's contact equalities the tick kernel eliminates structurally (contact_presolve in wbc_common.h).
 // Enabled only when (1) every contact foot's rows are supported by the 6 base DoF + 3 own leg DoF, the leg sets disjoint,
 // (2) NO active task touches an eliminated leg DoF (then H_ll = d^2 I, H_lf = 0 and the reduction costs no accuracy),
 // (3) the reduced problem fits qp_core<16>.

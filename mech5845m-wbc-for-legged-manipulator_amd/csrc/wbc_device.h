@@ -181,7 +181,7 @@ struct UpdateArgs {
   int32_t *status_max, *iters_sum;
 };
 
-// launchers (wbc_kernels.hip): single-wave workgroups; tick kernels take grid = B, the QP / integrate kernels min(B, resident waves)
+// launchers (one per kernel family, wbc_k_*.hip): single-wave workgroups; tick kernels take grid = B, the QP / integrate kernels min(B, resident waves)
 int launch_tick(const KernelArgs& a, int mode, int grid, void* stream);
 int launch_tick_sim3(const KernelArgs& a, int grid, void* stream);
 int launch_tick_sim3p(const KernelArgs& a, void* stream);      // packed: four instances per wavefront, grid = ceil(B / 4)

@@ -28,18 +28,14 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   __shared__ union { SmemP P; Smem G; } SU;
   static_assert(sizeof(Smem) <= 20480 && sizeof(SmemP) <= 20480, "8 waves per CU");
   SmemP& SP = SU.P;
-#ifndef SIM3P_ITERS
-#define SIM3P_ITERS 1      // experiment (variant builds): groups of four instances a wave processes one after the other (grid = groups / SIM3P_ITERS)
-#endif
-  unsigned long long tail_all = 0ull;      // (SIM3P_ITERS > 1: bit 4 it + row = an instance left to the tail, which runs after the loop)
-#pragma unroll 1
-  for (int it_ = 0; it_ < SIM3P_ITERS; ++it_) {
-  const int grp = (SIM3P_ITERS > 1) ? (int)(blockIdx.x + it_ * gridDim.x) : (int)blockIdx.x;
-  int lane = threadIdx.x;
-  if (SIM3P_ITERS > 1) { WSYNC(); asm volatile("" : "+v"(lane) :: "memory"); }   // (opaque per trip: nothing derived from the lane index is loop invariant)
-  const int r = lane >> 4, s = lane & 15, rbase = lane & 48;
+  const int lane = threadIdx.x, r = lane >> 4, s = lane & 15, rbase = lane & 48;
   PInst& I = SP.I[r];
   PVec& V = SP.V[r];
+  // (no loop over groups: a wave that takes two groups of four one after the other — half the workgroups, twice as long each — measured 6 % SLOWER
+  //  even with a clean register allocation (opaque lane index + -mllvm -disable-machine-licm; without them the hoisted invariants spill 139 loads /
+  //  91 stores into the packed path): profiles/r04_ab_licm_iters.txt. The first round of a launch costs twice a steady-state round — all waves
+  //  stall on their inputs at once — and fewer, longer waves do not change that.)
+  const int grp = (int)blockIdx.x;
   const int b_raw = 4 * grp + r;
   const bool valid = b_raw < A.B;
   const int b = valid ? b_raw : A.B - 1;
@@ -1145,7 +1141,12 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // variables and of the eliminated leg DoF (x_l = G_l y: rows p_keep + l of Cq) — never from H': fl(H') carries the 1.5e-9 posture block
   // with 1e-5 relative error, which IS the 1e-6 the plain method is off by (cond(H) ~ 3e9); the least-squares residual's own rounding lies in
   // the range of (A Z)', where H' is well conditioned.
-  if (A.refine > 0) {
+#ifdef WBC_ABLATE
+  const bool skip_refine_ = A.dbg_stop == 109;                        // timing cut: the whole tick without the refinement step
+#else
+  const bool skip_refine_ = false;
+#endif
+  if (A.refine > 0 && !skip_refine_) {
     // r2 — the active constraints' own residual b_k - n_k'y — is formed on the WARM variant only (its iterate is rebuilt from the factors after the
     // seeds: refresh). On the cold path the dual method's steps keep the working set satisfied to rounding and the term changes nothing (same-box
     // check: 6.68e-9 worst with and without it).
@@ -1302,26 +1303,12 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
   // shared with the packed layout). No list, no second launch, and a batch that defers everything runs at the general kernel's occupancy.
 #ifndef WBC_NO_TAIL   // (A/B variant builds only: make variant VFLAGS=-DWBC_NO_TAIL measures what carrying the tail costs the common path)
   const unsigned long long tailm = __ballot(valid && flagged && s == 0);
-  if (SIM3P_ITERS > 1) {
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) if ((tailm >> (16 * rr)) & 1ull) tail_all |= 1ull << (4 * it_ + rr);
-  } else if (tailm) {
+  if (tailm) {
     asm volatile("; WBC_TAIL_BEGIN" ::: "memory");   // (a comment in the assembly listing: tools/hot_path_spills.py cuts the control-flow graph here)
 #pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
       if (!((tailm >> (16 * rr)) & 1ull)) continue;
       tail_instance<WARM, false>(&SU.G, 4 * grp + rr, models, cfgs, plans);
-    }
-  }
-#endif
-  }   // (SIM3P_ITERS)
-#ifndef WBC_NO_TAIL
-  if (SIM3P_ITERS > 1 && tail_all) {
-    asm volatile("; WBC_TAIL_BEGIN" ::: "memory");
-#pragma unroll 1
-    for (int k = 0; k < 4 * SIM3P_ITERS; ++k) {
-      if (!((tail_all >> k) & 1ull)) continue;
-      tail_instance<WARM, false>(&SU.G, 4 * (int)(blockIdx.x + (k >> 2) * gridDim.x) + (k & 3), models, cfgs, plans);
     }
   }
 #endif
@@ -1358,7 +1345,7 @@ KDECL(true, false, true)
 #if SIM3P_PART <= 0
 int launch_tick_sim3p(const KernelArgs& a, void* stream) {
   const bool warm = a.ws_in || a.ws_out, trunk = a.in.trunk_target && a.packed_trunk, qcon = a.in.q_con || a.in.posture_u;
-  const dim3 grid(((a.B + 3) / 4 + SIM3P_ITERS - 1) / SIM3P_ITERS);
+  const dim3 grid((a.B + 3) / 4);
   if (qcon && warm) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<true, false, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   else if (qcon) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<false, false, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);
   else if (warm && trunk) hipLaunchKernelGGL((wbc_tick_sim3p_kernel<true, true>), grid, dim3(64), 0, (hipStream_t)stream, a, a.models, a.cfgs, a.plans);

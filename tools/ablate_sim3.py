@@ -48,9 +48,9 @@ for k in (1, 2, 3, 4, 5, 6, 7, 0):
 # the packed kernel (four instances per wavefront): cuts 106, 107, 101..105
 bt.set_option("packed_kernel", 1)
 pnames = {106: "inputs + plan records staged", 107: "sin/cos + root placement", 101: "FK levels", 102: "columns + task rows + H' rows", 103: "constraint rows + bounds + G + g' + G'G",
-          104: "Cholesky + substitutions", 105: "J store + x0", 108: "first violation scan + x = Z y + output", 0: "working-set changes (~2.5 passes per wave)"}
+          104: "Cholesky + substitutions", 105: "J store + x0", 108: "first violation scan + refinement + x = Z y + output", 109: "working-set changes (~3 passes per wave), no refinement", 0: "(whole tick; this row minus 108's refinement share is negative: the cut 109 row above is the tick without the step)"}
 pres, prev = {}, 0.0
-for k in (106, 107, 101, 102, 103, 104, 105, 108, 0):
+for k in (106, 107, 101, 102, 103, 104, 105, 108, 109, 0):
     bt.set_option("dbg_stop", k)
     for _ in range(3):
         step()

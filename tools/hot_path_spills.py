@@ -31,12 +31,12 @@ def analyse(part, verbose):
     txt = listing(part)
     files = dict(re.findall(r'\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', txt))
     res = []
-    for m in re.finditer(r"^(_ZN3wbc\w+):[^\n]*\n(.*?)^\s*s_endpgm", txt, re.S | re.M):
+    for m in re.finditer(r"^(_ZN3wbc\w+):[^\n]*\n(.*?)^\.Lfunc_end", txt, re.S | re.M):
         name = subprocess.check_output(["c++filt", m.group(1)], text=True).strip()
         name = re.sub(r"\(.*", "", name.replace("void wbc::", ""))
         # blocks: list of dicts(label, insts [(text, loc)], succ labels, falls through, has_marker_at index)
         blocks, cur, loc = [], {"label": "entry", "ins": [], "succ": [], "fall": True, "cut": None}, None
-        for line in m.group(2).splitlines() + ["\ts_endpgm"]:
+        for line in m.group(2).splitlines():
             lm = re.match(r"\s*\.loc\s+(\d+)\s+(\d+)", line)
             if lm:
                 loc = (os.path.basename(files.get(lm.group(1), "?")), int(lm.group(2)))
