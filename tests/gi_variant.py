@@ -16,7 +16,28 @@ INF = 1e20
 EPS2 = 2.220446049250313e-16 ** 2
 
 
-def solve(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, max_iter=None):
+def refine_step(J, q, act, act_side, x, neg_grad, normal, rhs):
+    """The kernels' refinement step at the final working set (csrc/wbc_common.h qp_refine; oracle: qp_refine) in plain numpy. Needs nothing of
+    the dual method but its final J (J J' = H^-1, the first q columns spanning the active normals) and the list of active constraints:
+    R = J1'N' is REBUILT from them (so equality slots, whose part of R the register-resident QR never stores, are covered), then
+        u = R^-1 J1' grad f,   r1 = -(grad f - N'u),   r2_k = b_k - n_k'x,   x += J1 R^-T r2 + J2 J2' r1.
+    neg_grad(x) returns -grad f(x) from the caller's UNFACTORED data (A'(b - A x) for a least-squares problem)."""
+    n = len(x)
+    gneg = neg_grad(x)
+    N = np.array([normal(c, sd) for c, sd in zip(act, act_side)]).reshape(q, n)
+    R = np.triu((J.T @ N.T)[:q, :q])                       # what rounding leaves below the diagonal is dropped, as on the device
+    w = J.T @ gneg
+    u = np.linalg.solve(R, -w[:q]) if q else np.zeros(0)   # back substitution
+    r1 = gneg + N.T @ u
+    r2 = np.array([rhs(c, sd) for c, sd in zip(act, act_side)]) - N @ x if q else np.zeros(0)
+    dy = J.T @ r1
+    if q:
+        dy[:q] = np.linalg.solve(R.T, r2)                  # forward substitution
+    return x + J @ dy
+
+
+def solve(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, max_iter=None, neg_grad=None):
+    """neg_grad: x -> -grad f(x) from the unfactored data; given, one refinement step (refine_step) is applied at the final working set."""
     n = len(g)
     p = 0 if C is None else C.shape[0]
     ncon = n + p
@@ -47,7 +68,7 @@ def solve(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, max_iter=None):
     x = -J @ (J.T @ g)
     T = np.zeros((n, n))
     u = np.zeros(n + 1)
-    act, act_eq, active = [], [], np.zeros(ncon, bool)
+    act, act_eq, act_side, active = [], [], [], np.zeros(ncon, bool)
     q = 0
     iters = 0
     max_iter = max_iter or 10 * (n + p) + 20
@@ -76,6 +97,8 @@ def solve(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, max_iter=None):
                     if s < -1e-9 * max(1.0, abs(hi(c))) and s < worst:
                         worst, ip, side, b_ip = s, c, 1, -hi(c)
             if ip < 0:
+                if neg_grad is not None:
+                    x = refine_step(J, q, act, act_side, x, neg_grad, normal, lambda c, sd: -hi(c) if sd else lo(c))
                 return x, 0, iters
             s_ip = worst
         npv = normal(ip, side)
@@ -121,13 +144,14 @@ def solve(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, max_iter=None):
                 u[q] = u_ip
                 act.append(ip)
                 act_eq.append(is_eq)
+                act_side.append(side)
                 active[ip] = True
                 q += 1
                 break
             # --- drop blocking constraint l: rotations from the removed row of T
             trow = T[l, l:q].copy()
             active[act[l]] = False
-            del act[l], act_eq[l]
+            del act[l], act_eq[l], act_side[l]
             u[l:q - 1] = u[l + 1:q].copy()
             Tt = np.delete(T[:q, :q], l, axis=0)       # (q-1) x q
             h = trow[0]

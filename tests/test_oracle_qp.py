@@ -194,6 +194,36 @@ def test_oracle_solution_is_the_exact_optimum_on_benchmark_ticks():
     assert max(e_round) > 10 * max(e_ref)                           # and why its residual must not come from fl(A'A)
 
 
+def test_kernel_refinement_step_restated_in_numpy():
+    """The refinement the kernels run (csrc/wbc_common.h qp_refine: R rebuilt from the final J and the active constraints, multipliers by back
+    substitution, r1 = -(grad f - N'u) with grad f = A'(A x - b), correction through J) stated in plain numpy (gi_variant.refine_step) on top of
+    the numpy model of the kernels' dual method: on benchmark ticks — 12 contact equalities, 3 fixed variables, cond(H) ~ 3e9 — it lands
+    on the exact least-squares optimum and on the oracle's refined answer, from 1e-6 away; with the residual taken from H instead it does not."""
+    import wbc_model
+    wx = wbc_model.load_model("a1_wx200")
+    cfg = common.config("c3", wx)
+    B = 6
+    d = common.tick_inputs(wx, cfg, B, seed=72)
+    a = oracle.assemble([wx], [cfg], d, 0.002, B)
+    t = oracle.tick([wx], [cfg], d, 0.002, B)
+    worst_ref, worst_plain, worst_h = 0.0, 0.0, 0.0
+    for b in range(B):
+        if t["status"][b] != 0:
+            continue
+        A, bb, H, g = a["A"][b], a["b"][b], a["H"][b], a["g"][b]
+        args = (a["C"][b], a["lb"][b], a["ub"][b], a["Clb"][b], a["Cub"][b])
+        x0, s0, it0 = gi_variant.solve(H, g, *args)
+        x1, s1, it1 = gi_variant.solve(H, g, *args, neg_grad=lambda x: A.T @ (bb - A @ x))
+        xh, sh, ith = gi_variant.solve(H, g, *args, neg_grad=lambda x: -(H @ x + g))
+        assert s0 == s1 == sh == 0 and it0 == it1 == ith == t["iters"][b]
+        x_ls = common.exact_ls_optimum(A, bb, *args, x1)
+        worst_ref = max(worst_ref, np.abs(x1 - x_ls).max(), np.abs(x1 - t["qdot"][b]).max())
+        worst_plain = max(worst_plain, np.abs(x0 - x_ls).max())
+        worst_h = max(worst_h, np.abs(xh - x_ls).max())
+    print("numpy model: refined %.2e, plain %.2e, refined with the residual from H %.2e" % (worst_ref, worst_plain, worst_h))
+    assert worst_ref < 1e-8 and worst_plain > 20 * worst_ref and worst_h > 20 * worst_ref
+
+
 def test_refinement_on_the_qp_entry_points():
     """QP(A, b, ...) (QP_Wrapper.py:10-53 -> oracle.qp_solve_ls: least-squares residual) reaches the exact least-squares optimum on an
     ill-conditioned random problem with active bounds and rows; QP(H, g) (oracle.qp_solve: the residual can only come from H) reaches the
