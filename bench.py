@@ -43,8 +43,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak
 ALGO_FLOP_PER_TICK = 5.5e4     # dense count of the n = 26 problem (+ ~1e4 per working-set change)
 REDUCED_FLOP_PER_TICK = 1.1e4  # the problem the sim3 kernels actually solve (n' = 11, no equalities): DESIGN.md §4
-PMC_PROFILE = "r03_pmc_summary_packed.txt"   # committed rocprofv3 PMC passes the static roofline.issue fields come from (tools/gpu_profile.sh)
-TRAFFIC_PROFILE = "r03_traffic_calibration.txt"   # FETCH_SIZE / WRITE_SIZE of the tick kernel, calibrated against known-byte-count kernels in the
+PMC_PROFILE = "r04_pmc_summary_packed.txt"   # committed rocprofv3 PMC passes the static roofline.issue fields come from (tools/gpu_profile.sh)
+TRAFFIC_PROFILE = "r04_traffic_calibration.txt"   # FETCH_SIZE / WRITE_SIZE of the tick kernel, calibrated against known-byte-count kernels in the
                                                   # tick's own access pattern (tools/calib_traffic.sh): roofline.traffic
 DT = 0.002
 QDOT_TOL = 1e-5
