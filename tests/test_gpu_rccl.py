@@ -37,3 +37,27 @@ def test_bench_rank_body_over_rccl_at_world_size_one():
         comm.close()
         engine.close()
     assert not dist.is_initialized()
+
+
+def test_bench_command_line_starts_two_ranks_on_the_gpu_box():
+    """`python bench.py --gpus 2` with no launcher around it, on real hardware: the parent (which never touches the GPU) starts two child ranks with the
+    real GpuEngine; on a one-GPU box both share device 0 and meet over gloo (WBC_BENCH_SHARE_GPU: RCCL refuses two ranks on one device), on a box
+    with two or more GPUs each rank takes its own and they meet over RCCL. One JSON line, n_gpus 2, the aggregate of both shards, rc 0."""
+    import json
+    import subprocess
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    shared = torch.cuda.device_count() < 2
+    if shared:
+        env["WBC_BENCH_SHARE_GPU"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "3", "--batch", "8192"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]           # nothing but rank 0's line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16384 and line["config"]["engine"] == "hip"
+    assert line["config"]["backend"].startswith("gloo" if shared else "nccl") and "sim3p" in line["config"]["kernel_path"]
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 16384.0) < 1e-3 and line["value"] > 1e6
+    assert "cpu_baseline" not in line and line["scaling"] == "weak"
