@@ -359,7 +359,7 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          per active inequality (0.9-1.05 here), a seed replaces it by an add step + a share of the rebuild, and
  *                          both pay the final feasibility scan. Off by default; never the 2.2x of round 2's fallback kernel.
  *                          (wbc_tick is warm exactly when WbcTickIn.working_set is passed.)
- *   "refine"           [1] steps of iterative refinement at the final working set (0, 1, 2) — the analogue of the reference's
+ *   "refine"           [1] one step of iterative refinement at the final working set (0 = off) — the analogue of the reference's
  *                          qpOASES option numRefinementSteps = 100 (QP_Wrapper.py:37). With the active normals N, their multipliers u
  *                          and the dual method's factors (J J' = H^-1, J'N' = [R; 0]):  r1 = -(grad f - N'u),  x += J2 J2' r1 (+ the
  *                          active rows' own residual through R). grad f is formed from the UNFACTORED least-squares data — A'(A x - b)
@@ -367,7 +367,7 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          1.5e-9 posture block with 1e-5 relative error, which is the whole 1e-6 the plain method is off by at
  *                          cond(H) ~ 3e9. One step lands within 1e-8 of the exact least-squares optimum (oracle: qp_refine; both sides
  *                          refine, so the parity margin on BASELINE configs[2] went from 5.7e-6 to 6.6e-8 against the 1e-5 tolerance,
- *                          profiles/r04_soak_long.txt). Cost on the benchmark: 5.5 % (profiles/r04_ab_refine.txt). Refined: the packed
+ *                          profiles/r04_soak_long.txt). A correction larger than 1e-3 max(1, |x|) or non-finite is not applied. Cost on the benchmark: 5.5 % (profiles/r04_ab_refine.txt). Refined: the packed
  *                          sim3 kernel and its variants, the general kernel (full size and structural presolve), wbc_qp_solve_ls
  *                          (wbc_qp_solve can only use -(H x + g): no gain where H itself is the rounding). Not refined, because their
  *                          stacks are well conditioned (1e-8 .. 1e-10 without): the packed orth / box kernels and the orthonormal

@@ -626,7 +626,7 @@ extern "C" int wbc_batch_set_option(WbcBatch* b, const char* name, int value) {
   if (!strcmp(name, "posture_par")) { b->posture_par = value; return WBC_OK; }
   if (!strcmp(name, "dbg_alias_inputs")) { b->dbg_alias = value; return WBC_OK; }
   if (!strcmp(name, "warm_start")) { b->warm_start = value != 0; return WBC_OK; }
-  if (!strcmp(name, "refine")) { b->refine = value < 0 ? 0 : (value > 2 ? 2 : value); return WBC_OK; }
+  if (!strcmp(name, "refine")) { b->refine = value > 0; return WBC_OK; }
   if (!strcmp(name, "count_pivoted")) { b->count_pivoted = value != 0; return WBC_OK; }
   if (!strcmp(name, "dbg_force_defer")) { b->force_defer = value != 0; return WBC_OK; }
   if (!strcmp(name, "dbg_stop")) {

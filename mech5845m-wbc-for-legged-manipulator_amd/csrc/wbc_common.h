@@ -361,7 +361,11 @@ __device__ __forceinline__ double qp_refine(SM& S, const RF& rf, const double x_
 #pragma unroll
   for (int k = 0; k < NM; k += 2) { const double2a j2 = lds2(J + li * LDJ + k); const double2a w2 = lds2(S.dinv + k); da = fma(j2.x, w2.x, da); db = fma(j2.y, w2.y, db); }
   WSYNC();
-  return (lane < n && !fixb) ? x_in + (da + db) : x_in;
+  // the correction is a rounding-level quantity (1e-6 here); one that is not — a working set on the edge of dependence — is not applied (oracle: same rule)
+  const double dxl = (lane < n && !fixb) ? da + db : 0.0;
+  const double dmax = -wmin(lane < 32 ? -fabs(dxl) : 0.0), xmax = fmax(1.0, -wmin(lane < 32 ? -fabs(lane < n ? x_in : 0.0) : 0.0));
+  const bool sane = __ballot(dxl != dxl) == 0 && dmax <= 1e-3 * xmax;
+  return sane ? x_in + dxl : x_in;
 }
 
 template <int NM, class SM = Smem, int CS = LDJ, bool WARM = false, class RF = NoRefine>

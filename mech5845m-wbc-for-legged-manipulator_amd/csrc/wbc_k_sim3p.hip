@@ -1236,7 +1236,11 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs 
     double da = 0.0, db = 0.0;
 #pragma unroll
     for (int k = 0; k < PV; k += 2) { const double2a j2 = lds2(J + sv * PLD + k), w2 = lds2(V.yv + k); da = fma(j2.x, w2.x, da); db = fma(j2.y, w2.y, db); }
-    if (has_b && status == WBC_QP_OPTIMAL) x += da + db;
+    // the correction is a rounding-level quantity (1e-6 here); one that is not — a working set on the edge of dependence — is not applied (oracle: same rule)
+    const double dxl = has_b ? da + db : 0.0;
+    const double dmax = -rmin16(-fabs(dxl)), xmax = fmax(1.0, -rmin16(has_b ? -fabs(x) : 0.0));
+    const bool nanr = ((__ballot(dxl != dxl) >> rbase) & 0xFFFFull) != 0;
+    if (has_b && status == WBC_QP_OPTIMAL && !nanr && dmax <= 1e-3 * xmax) x += dxl;
   }
   if (status == WBC_QP_OPTIMAL) {
     const unsigned long long bad = __ballot(has_b && !(fabs(x) <= 1.7976931348623157e308));

@@ -643,7 +643,18 @@ static void qp_refine(int n, int q, int m, const double* A, const double* bv, co
     dy[k] = s / R[k][k];
   }
   for (int k = q; k < n; ++k) { double s = 0; for (int i = 0; i < n; ++i) s += J[i][k] * r1[i]; dy[k] = s; }   /* dy2 = J2' r1 */
-  for (int i = 0; i < n; ++i) { double s = 0; for (int k = 0; k < n; ++k) s += J[i][k] * dy[k]; x[i] += s; }
+  /* the correction is a rounding-level quantity (1e-6 here); one that is not — a working set on the edge of dependence, non-finite data —
+   * is not applied: x keeps the dual method's answer (same rule on the device) */
+  double dx[QN], xmax = 1.0, dmax = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double s = 0;
+    for (int k = 0; k < n; ++k) s += J[i][k] * dy[k];
+    dx[i] = s;
+    if (fabs(x[i]) > xmax) xmax = fabs(x[i]);
+    if (!(fabs(s) <= dmax)) dmax = fabs(s);       /* (a NaN sticks) */
+  }
+  if (!(dmax <= 1e-3 * xmax)) return;
+  for (int i = 0; i < n; ++i) x[i] += dx[i];
 }
 
 static int qp_solve_body(int n, int p, int m, const double* A, const double* bv, const double* H, const double* g, const double* C,
