@@ -369,7 +369,7 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          refine, so the parity margin on BASELINE configs[2] went from 5.7e-6 to 6.6e-8 against the 1e-5 tolerance,
  *                          profiles/r04_soak_long.txt). A correction larger than 1e-3 max(1, |x|) or non-finite is not applied. Cost on the benchmark: 5.5 % (profiles/r04_ab_refine.txt). Refined: the packed
  *                          sim3 kernel and its variants, the general kernel (full size and structural presolve), wbc_qp_solve_ls
- *                          (wbc_qp_solve can only use -(H x + g): no gain where H itself is the rounding). Not refined, because their
+ *                          (wbc_qp_solve, given H and g alone, could only use -(H x + g): no gain where H itself is the rounding — measured — so it does not refine). Not refined, because their
  *                          stacks are well conditioned (1e-8 .. 1e-10 without): the packed orth / box kernels and the orthonormal
  *                          presolve; and the one-instance compact kernel (path 1: no room at 168 VGPRs / 13 KB LDS) — with refine > 0
  *                          what it would take runs on the general kernel instead (refine = 0 brings it back).

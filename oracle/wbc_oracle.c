@@ -812,7 +812,7 @@ static int qp_solve_body(int n, int p, int m, const double* A, const double* bv,
     }
   }
 done:
-  if (status == WBC_QP_OPTIMAL)
+  if (status == WBC_QP_OPTIMAL && A && m > 0)        /* (H, g) alone: a residual from H gains nothing where H is the rounding (measured): not refined, like the device */
     for (int k = 0; k < g_refine_steps; ++k) qp_refine(n, q, m, A, bv, H, g, &Q, J, R, act, act_side, u, x);
   if (iters_out) *iters_out = iters;
   return status;

@@ -226,8 +226,9 @@ def test_kernel_refinement_step_restated_in_numpy():
 
 def test_refinement_on_the_qp_entry_points():
     """QP(A, b, ...) (QP_Wrapper.py:10-53 -> oracle.qp_solve_ls: least-squares residual) reaches the exact least-squares optimum on an
-    ill-conditioned random problem with active bounds and rows; QP(H, g) (oracle.qp_solve: the residual can only come from H) reaches the
-    exact optimum of ITS data no worse than the plain method; refinement never changes status or iteration count."""
+    ill-conditioned random problem with active bounds and rows; QP(H, g) (oracle.qp_solve) is not refined — its residual could only come from H,
+    whose rounding is the error (gi_variant's numpy model shows it: test_kernel_refinement_step_restated_in_numpy) — and stays at the plain method's
+    distance from the exact optimum of ITS data; refinement never changes status or iteration count."""
     rng = np.random.default_rng(3)
     n, m, p = 10, 14, 4
     worst_ls, worst_h, worst_plain = 0.0, 0.0, 0.0
