@@ -12,7 +12,10 @@
  *   - quaternion / Euler helpers: pinned against scipy.spatial.transform.Rotation (importable here).
  *   - task/constraint assembly and QP solutions: PARITY UNPINNED (no expected values exist anywhere in
  *     the reference). The QP restatement is certified by KKT residuals and scipy.optimize cross-solves;
- *     H > 0 makes the minimiser unique, hence solver independent.
+ *     H > 0 makes the minimiser unique, hence solver independent. Since round 4 the solve ends with one step of iterative
+ *     refinement (wrappers/QP_Wrapper.py:37 numRefinementSteps; qp_refine below) whose residual comes from the least-squares
+ *     data A, b — the answer is the exact optimum of min 1/2 |A x - b|^2 on the final working set to ~1e-13 (tests compare
+ *     with rational arithmetic), not the optimum of the rounded H = fl(A'A), which differs from it by ~1e-7 on the benchmark tick.
  *
  * Each function cites the reference file:line it follows (paths relative to /root/reference).
  * Third-party semantics restated: pinocchio (≈2.5–2.6, unpinned) forwardKinematics,
