@@ -513,6 +513,53 @@ def test_pivoted_elimination_and_second_pass_match_the_oracle(wx200, px100, tol_
     bt.close()
 
 
+def test_refinement_is_what_closes_the_gap_to_the_oracle(wx200, px100):
+    """Option `refine` (the analogue of QP_Wrapper.py:37 numRefinementSteps) on every path that carries the step — packed sim3 kernel, general kernel
+    with the structural presolve, general kernel at full size (contact rows as equalities), cold and hot-started — on a mixed-morphology batch of the
+    benchmark configuration: with it the path agrees with the (refining) oracle to 1e-7, without it to 1e-6 only; status, iteration count and the
+    final working set do not depend on it; and the two one-instance kernels, refined, land on the same point as the packed one."""
+    B = 1024
+    models = [wx200, px100]
+    cfgs = [common.config("c3", m) for m in models]
+    mid = (np.arange(B) % 2).astype(np.int32)
+    parts = [common.tick_inputs(m, c, B, seed=131 + i) for i, (m, c) in enumerate(zip(models, cfgs))]
+    d = {k: np.where(mid.reshape((B,) + (1,) * (parts[0][k].ndim - 1)) == 0, parts[0][k], parts[1][k]) for k in parts[0]}
+    d["model_id"] = mid
+    ref = oracle.tick(models, cfgs, d, DT, B, nthreads=8)
+    ok = ref["status"] == 0
+    bt = WbcBatch(models, B)
+    for i, c in enumerate(cfgs):
+        bt.configure(c, i)
+    refined = {}
+    for name, opts, path in (("packed", {}, 2), ("general + presolve", {"packed_kernel": 0}, 0), ("full size", {"packed_kernel": 0, "presolve": 0}, 0)):
+        for k, v in {"packed_kernel": 1, "presolve": 1}.items():
+            bt.set_option(k, v)
+        for k, v in opts.items():
+            bt.set_option(k, v)
+        got = {}
+        for rf in (1, 0):
+            bt.set_option("refine", rf)
+            if name == "general + presolve" and rf == 0:
+                bt.set_option("sim3_kernel", 0)          # (refine = 0 would bring the compact kernel back: keep the comparison on ONE kernel)
+            got[rf] = bt.tick(d, DT, want_working_set=(name != "full size"))
+            bt.set_option("sim3_kernel", 1)
+            assert bt.stat("last_path") == path, (name, rf, bt.stat("last_path"))
+            assert (got[rf]["status"] == ref["status"]).all(), (name, rf)
+        e1, e0 = np.abs(got[1]["qdot"] - ref["qdot"])[ok].max(), np.abs(got[0]["qdot"] - ref["qdot"])[ok].max()
+        print("%-20s refined %.2e, plain %.2e" % (name, e1, e0))
+        assert e1 < REFINED_TOL and e0 < QDOT_TOL and e0 > 5 * e1, (name, e1, e0)
+        assert (got[1]["iters"] == got[0]["iters"]).all()
+        if name != "full size":
+            assert (got[1]["working_set"] == got[0]["working_set"]).all()
+            bt.set_option("refine", 1)
+            warm = bt.tick(dict(d, working_set=got[1]["working_set"]), DT)          # hot-started with its own set: the WARM variants refine too
+            assert (warm["status"] == ref["status"]).all() and np.abs(warm["qdot"] - ref["qdot"])[ok].max() < REFINED_TOL, name
+        refined[name] = got[1]["qdot"]
+    for name in ("general + presolve", "full size"):
+        assert np.abs(refined[name] - refined["packed"])[ok].max() < REFINED_TOL
+    bt.close()
+
+
 def test_packed_orth_ineq_tail_hot_started_matches_cold(wx200):
     """an instance the packed orth kernel's INEQ variant leaves to its tail is redone on the general kernel's ORTH variant when the tick
     is cold and on its warm full-size path when a working set is passed — two numerical routes to one QP. Option orth_qr sends EVERY instance to
