@@ -20,12 +20,24 @@ namespace wbc {
 // QCON: the variant for a caller's (or wbc_posture_par_kernel's) posture target `posture_u` and constraint state `q_con` — qpJointb "MANI" / literal
 // "HYBRID" with sweeps that matter (Robot_Wrapper4.py:1220-1260): the tasks are formed at q, then the kinematics are redone at
 // q_con and the contact rows, the trunk box, the damper bounds and the integration see THAT state (a second FK pass, as in process_instance).
+#ifndef SIM3P_WAVES
+#define SIM3P_WAVES 2      // waves per SIMD the register allocation is made for (3: an experiment, tools/hot_path_spills.py with WBC_XFLAGS="-DSIM3P_WAVES=3 -DWBC_NO_TAIL")
+#endif
 template <bool WARM, bool TRUNK = false, bool QCON = false>
-__global__ void __launch_bounds__(64, 2) wbc_tick_sim3p_kernel(const KernelArgs A, const DevModel* __restrict__ models,
+#ifdef SIM3P_NUM_VGPR
+__attribute__((amdgpu_waves_per_eu(SIM3P_NUM_VGPR, SIM3P_NUM_VGPR)))
+#endif
+__global__ void __launch_bounds__(64, SIM3P_WAVES) wbc_tick_sim3p_kernel(const KernelArgs A, const DevModel* __restrict__ models,
                                                                const WbcConfig* __restrict__ cfgs, const DevPlan* __restrict__ plans) {
   // (the general kernel's layout shares the allocation: an instance this kernel cannot reduce — a stance-leg block of rank < 2 — is
   //  redone on the general path by the SAME wave at the end, see the tail; both layouts leave 8 waves per CU)
+#ifdef SIM3P_NUM_VGPR      // (compile-only experiment: with the LDS size unknown to the compiler the occupancy attribute alone decides the register budget)
+  extern __shared__ double dyn_lds_[];
+  union SUU { SmemP P; Smem G; };
+  SUU& SU = *reinterpret_cast<SUU*>(dyn_lds_);
+#else
   __shared__ union { SmemP P; Smem G; } SU;
+#endif
   static_assert(sizeof(Smem) <= 20480 && sizeof(SmemP) <= 20480, "8 waves per CU");
   SmemP& SP = SU.P;
   const int lane = threadIdx.x, r = lane >> 4, s = lane & 15, rbase = lane & 48;
