@@ -44,4 +44,12 @@ for name in names:
         err = np.abs(qd - ref["qdot"]).max(axis=1)[ok]
         print("%-16s %-55s path %d orth %d: status agree %.6f, qdot err max %.2e p99.9 %.2e p50 %.2e, %.3f ms" % (
             name, str(opts), bt.stat("last_path"), bt.stat("last_orth"), (ref["status"] == st).mean(), err.max(), np.quantile(err, 0.999), np.median(err), ms), flush=True)
+        if opts.get("refine") == 1 and len(opts) <= 2:      # the same tick hot-started with its own final working set (the WARM kernel variants)
+            cold = bt.tick(dev, 0.002, want_working_set=True)
+            warm = bt.tick(dict(dev, working_set=cold["working_set"]), 0.002)
+            stw, qw = warm["status"].cpu().numpy(), warm["qdot"].cpu().numpy()
+            okw = (ref["status"] == 0) & (stw == 0)
+            ew = np.abs(qw - ref["qdot"]).max(axis=1)[okw]
+            print("%-16s %-55s path %d       : status agree %.6f, qdot err max %.2e p99.9 %.2e p50 %.2e" % (
+                name, "  hot-started with its own set", bt.stat("last_path"), (ref["status"] == stw).mean(), ew.max(), np.quantile(ew, 0.999), np.median(ew)), flush=True)
     bt.close()
