@@ -21,3 +21,19 @@ for n,p in ((8,4),(14,8),(20,8),(26,12)):
     torch.cuda.synchronize(); dt=(time.perf_counter()-t)/10
     print("n=%d p=%d: %.3f ms  %.1f M QPs/s  optimal %.3f iters %.2f"%(n,p,dt*1e3,B/dt/1e6,(r["status"]==0).double().mean().item(), r["iters"].double().mean().item()))
     bt.close()
+
+# QP(A, b, ...) = wbc_qp_solve_ls at the tick's shape (m, n, p) = (32, 26, 16) on RANDOM dense data (boxes and two-sided rows, no equalities): the
+# number VERDICT r3 item 5 asks for; the tick's own data (12 equalities, 3 fixed variables): tools/time_qp_tick.py
+for m,n,p in ((32,26,16),(64,26,16)):
+    A=rng.normal(size=(B,m,n)); b=rng.normal(size=(B,m)); C=rng.normal(size=(B,p,n)); lb=-np.ones((B,n))*0.5; ub=-lb; cl=-np.ones((B,p)); cu=-cl
+    bt=WbcBatch(wbc_model.load_model("a1_wx200"),B)
+    d=[torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (A,b,C,lb,ub,cl,cu)]
+    for rf in (0,1):
+        bt.set_option("refine",rf)
+        for _ in range(3): r=bt.qp_solve_ls(*d)
+        r=dict(zip(("x","status","iters"), r))
+        torch.cuda.synchronize(); t=time.perf_counter()
+        for _ in range(10): bt.qp_solve_ls(*d)
+        torch.cuda.synchronize(); dt=(time.perf_counter()-t)/10
+        print("QP(A, b) random m=%d n=%d p=%d refine %d: %.3f ms  %.1f M QPs/s  optimal %.3f iters %.2f"%(m,n,p,rf,dt*1e3,B/dt/1e6,(r["status"]==0).double().mean().item(), r["iters"].double().mean().item()))
+    bt.close()
