@@ -256,6 +256,9 @@ __device__ __forceinline__ unsigned long long low_bits(unsigned long long m, int
 // RF: the caller's residual functor for the iterative refinement at the final working set (qp_refine below): rf(x) returns, on lane k < n,
 // entry k of -grad f(x) formed from the caller's UNFACTORED data (least-squares data where it has them); every lane calls it (it may reduce
 // over the wave) and it may use S.xv / S.yv / S.dv / S.npv. NoRefine: nothing is compiled in.
+// The refinement runs where it has something to repair: the plain dual method's error is ~cond(H) eps |x|, so a problem whose smallest Cholesky pivot
+// is above WBC_REFINE_COND x its largest diagonal entry (cond(H) < ~1e7: error < 1e-9) keeps the plain answer — the oracle refines always.
+constexpr double WBC_REFINE_COND = 1e-7;
 struct NoRefine {
   static constexpr bool enabled = false;
   __device__ NoRefine() {}
@@ -361,10 +364,10 @@ __device__ __forceinline__ double qp_refine(SM& S, const RF& rf, const double x_
 #pragma unroll
   for (int k = 0; k < NM; k += 2) { const double2a j2 = lds2(J + li * LDJ + k); const double2a w2 = lds2(S.dinv + k); da = fma(j2.x, w2.x, da); db = fma(j2.y, w2.y, db); }
   WSYNC();
-  // the correction is a rounding-level quantity (1e-6 here); one that is not — a working set on the edge of dependence — is not applied (oracle: same rule)
+  // the correction is small against x (1e-6 on the tick, up to 1e-3 on a cond-1e10 problem); one that is not (> 0.25 max(1, |x|)) or is non-finite — a working set on the edge of dependence — is not applied (oracle: same rule)
   const double dxl = (lane < n && !fixb) ? da + db : 0.0;
   const double dmax = -wmin(lane < 32 ? -fabs(dxl) : 0.0), xmax = fmax(1.0, -wmin(lane < 32 ? -fabs(lane < n ? x_in : 0.0) : 0.0));
-  const bool sane = __ballot(dxl != dxl) == 0 && dmax <= 1e-3 * xmax;
+  const bool sane = __ballot(dxl != dxl) == 0 && dmax <= 0.25 * xmax;
   return sane ? x_in + dxl : x_in;
 }
 
@@ -431,6 +434,14 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
 #pragma unroll
   for (int k = 0; k < NM; k += 2) { const double2a v = lds2(S.RA + li * LDJ + k); h[k] = v.x; h[k + 1] = v.y; }
   WSYNC();
+  // largest diagonal entry of H: with the smallest Cholesky pivot it tells whether the refinement has anything to repair (WBC_REFINE_COND)
+  double hmax = 0.0;
+  if (RF::enabled) {
+    double hd = 0.0;
+#pragma unroll
+    for (int k = 0; k < NM; ++k) hd = (k == li) ? h[k] : hd;
+    hmax = -wmin((lane < NM && lane < 32) ? -hd : 0.0);
+  }
 
   // ---- Cholesky H = L L', right-looking, ROTATING registers: at step j register r holds column j + r of the row,
   // so the body is the same for every j (a real loop, ~100 instructions) and the row never leaves the VGPRs.
@@ -944,7 +955,9 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   }
 done:
   if (RF::enabled) {
-    if (refine > 0 && res.status == WBC_QP_OPTIMAL) x = qp_refine<NM, SM, CS, RF>(S, rf, x, n, p, lane, q, a_code, fixb, lb, ub, clb, cub);
+    // (a well-conditioned problem — smallest pivot above WBC_REFINE_COND x the largest diagonal entry: the plain method is within ~1e-9 already — skips the step)
+    if (refine > 0 && res.status == WBC_QP_OPTIMAL && pmin < WBC_REFINE_COND * hmax)
+      x = qp_refine<NM, SM, CS, RF>(S, rf, x, n, p, lane, q, a_code, fixb, lb, ub, clb, cub);
   }
   STAMP(ts, T_INEQ);
   // a QP that was not solved returns x = 0 (the reference's xOpt on its first QP: qpOASES does not write the primal vector

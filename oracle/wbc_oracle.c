@@ -646,7 +646,7 @@ static void qp_refine(int n, int q, int m, const double* A, const double* bv, co
     dy[k] = s / R[k][k];
   }
   for (int k = q; k < n; ++k) { double s = 0; for (int i = 0; i < n; ++i) s += J[i][k] * r1[i]; dy[k] = s; }   /* dy2 = J2' r1 */
-  /* the correction is a rounding-level quantity (1e-6 here); one that is not — a working set on the edge of dependence, non-finite data —
+  /* the correction is small against x (1e-6 on the tick, up to 1e-3 on a cond-1e10 problem); one that is not (> 0.25 max(1, |x|)) or is non-finite — a working set on the edge of dependence —
    * is not applied: x keeps the dual method's answer (same rule on the device) */
   double dx[QN], xmax = 1.0, dmax = 0.0;
   for (int i = 0; i < n; ++i) {
@@ -656,7 +656,7 @@ static void qp_refine(int n, int q, int m, const double* A, const double* bv, co
     if (fabs(x[i]) > xmax) xmax = fabs(x[i]);
     if (!(fabs(s) <= dmax)) dmax = fabs(s);       /* (a NaN sticks) */
   }
-  if (!(dmax <= 1e-3 * xmax)) return;
+  if (!(dmax <= 0.25 * xmax)) return;
   for (int i = 0; i < n; ++i) x[i] += dx[i];
 }
 
