@@ -367,8 +367,8 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          1.5e-9 posture block with 1e-5 relative error, which is the whole 1e-6 the plain method is off by at
  *                          cond(H) ~ 3e9. One step lands within 1e-8 of the exact least-squares optimum (oracle: qp_refine; both sides
  *                          refine, so the parity margin on BASELINE configs[2] went from 5.7e-6 to 6.6e-8 against the 1e-5 tolerance,
- *                          profiles/r04_soak_long.txt). A correction larger than 0.25 max(1, |x|) or non-finite is not applied, and a problem whose
- *                          smallest Cholesky pivot is above 1e-7 x its largest diagonal entry (cond(H) < ~1e7: the plain answer is within 1e-9) skips the step. Cost on the benchmark: 5.5 % (profiles/r04_ab_refine.txt). Refined: the packed
+ *                          profiles/r04_soak_long.txt). A correction larger than 0.25 max(1, |x|) or non-finite is not applied; on wbc_qp_solve_ls (arbitrary
+ *                          problems) a QP whose smallest Cholesky pivot is above 1e-5 x its largest diagonal entry skips the step — the ticks refine always. Cost on the benchmark: 5.5 % (profiles/r04_ab_refine.txt). Refined: the packed
  *                          sim3 kernel and its variants, the general kernel (full size and structural presolve), wbc_qp_solve_ls
  *                          (wbc_qp_solve, given H and g alone, could only use -(H x + g): no gain where H itself is the rounding — measured — so it does not refine). Not refined, because their
  *                          stacks are well conditioned (1e-8 .. 1e-10 without): the packed orth / box kernels and the orthonormal

@@ -256,9 +256,12 @@ __device__ __forceinline__ unsigned long long low_bits(unsigned long long m, int
 // RF: the caller's residual functor for the iterative refinement at the final working set (qp_refine below): rf(x) returns, on lane k < n,
 // entry k of -grad f(x) formed from the caller's UNFACTORED data (least-squares data where it has them); every lane calls it (it may reduce
 // over the wave) and it may use S.xv / S.yv / S.dv / S.npv. NoRefine: nothing is compiled in.
-// The refinement runs where it has something to repair: the plain dual method's error is ~cond(H) eps |x|, so a problem whose smallest Cholesky pivot
-// is above WBC_REFINE_COND x its largest diagonal entry (cond(H) < ~1e7: error < 1e-9) keeps the plain answer — the oracle refines always.
-constexpr double WBC_REFINE_COND = 1e-7;
+// On the stand-alone QP boundary (arbitrary problems) the refinement runs where it has something to repair: the plain dual method's error is
+// ~cond(H) eps |x|, so a problem whose smallest Cholesky pivot is above WBC_REFINE_COND x its largest diagonal entry (cond(H) of ~1e5: error < 1e-9)
+// keeps the plain answer (`adaptive`). The tick kernels refine always: on their REDUCED problems the pivot ratio is no usable estimate — a stance
+// near a singular leg block inflates the base block through G'G while the posture-only directions stay at 1e-9 (soak: 2.3e-7 left unrepaired
+// with the test on, 4.7e-8 without). The oracle refines always.
+constexpr double WBC_REFINE_COND = 1e-5;
 struct NoRefine {
   static constexpr bool enabled = false;
   __device__ NoRefine() {}
@@ -375,7 +378,7 @@ template <int NM, class SM = Smem, int CS = LDJ, bool WARM = false, class RF = N
 __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const double lb_in, const double ub_in,
                                             const double clb_in, const double cub_in, const int n, const int p, const int lane,
                                             unsigned long long* ts, const int dbg_stop = 0, const int ws_b_in = 0, const int ws_r_in = 0,
-                                            const RF& rf = RF(), const int refine = 0) {
+                                            const RF& rf = RF(), const int refine = 0, const bool adaptive = false) {
   const int li = lane < NM ? lane : NM - 1;
   QpResult res;
   res.status = WBC_QP_OPTIMAL;
@@ -955,8 +958,8 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
   }
 done:
   if (RF::enabled) {
-    // (a well-conditioned problem — smallest pivot above WBC_REFINE_COND x the largest diagonal entry: the plain method is within ~1e-9 already — skips the step)
-    if (refine > 0 && res.status == WBC_QP_OPTIMAL && pmin < WBC_REFINE_COND * hmax)
+    // (`adaptive`: a well-conditioned problem — smallest pivot above WBC_REFINE_COND x the largest diagonal entry — skips the step)
+    if (refine > 0 && res.status == WBC_QP_OPTIMAL && (!adaptive || pmin < WBC_REFINE_COND * hmax))
       x = qp_refine<NM, SM, CS, RF>(S, rf, x, n, p, lane, q, a_code, fixb, lb, ub, clb, cub);
   }
   STAMP(ts, T_INEQ);

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_kernel(const QpArgs A) {
     };
     typedef Refine<decltype(resid)> RF_;
     const RF_ rf{resid};
-    const QpResult res = qp_core<NM, Smem, LDJ, WARM, RF_>(S, g, lb, ub, clb, cub, n, p, lane, ts, 0, sb == 3 ? 0 : sb, sr == 3 ? 0 : sr, rf, (m > 0) ? A.refine : 0);   // (H, g) alone: the residual
+    const QpResult res = qp_core<NM, Smem, LDJ, WARM, RF_>(S, g, lb, ub, clb, cub, n, p, lane, ts, 0, sb == 3 ? 0 : sb, sr == 3 ? 0 : sr, rf, (m > 0) ? A.refine : 0, true);   // (H, g) alone: the residual
     // could only come from H, whose rounding IS the error — measured: no gain (6.4e-7 stays 6.4e-7) for 23 % of the solve, so the step is skipped
     if (WARM && A.ws_out) {
       const unsigned long long o0 = (__ballot(res.ws_b == 1) & 0xFFFFFFFFull) | (__ballot(res.ws_b == 2) << 32);

@@ -742,13 +742,6 @@ __global__ void __launch_bounds__(64, SIM3P_WAVES) wbc_tick_sim3p_kernel(const K
 #pragma unroll
   for (int k = 0; k < PV; ++k) y[k] = (k == s) ? 1.0 : 0.0;
   double pmin = 1.0;
-  double hmax;                              // largest diagonal entry of H' (per row): with pmin it tells whether the refinement has anything to repair
-  {
-    double hd = 0.0;
-#pragma unroll
-    for (int k = 0; k < PV; ++k) hd = (k == s) ? h[k] : hd;
-    hmax = -rmin16(s < PV ? -hd : 0.0);
-  }
   // Two columns per trip: the raw columns j and j + 1 of every row go through LDS together and each lane redoes, for the rows below, the
   // one update that column j + 1 receives from step j — the same operations in the same order as two single steps (bit-identical), one LDS
   // round trip instead of two in the 12-step chain.
@@ -1165,10 +1158,7 @@ __global__ void __launch_bounds__(64, SIM3P_WAVES) wbc_tick_sim3p_kernel(const K
 #else
   const bool skip_refine_ = false;
 #endif
-  // (a row whose problem is well conditioned — smallest pivot above WBC_REFINE_COND x the largest diagonal entry, e.g. with the trunk task on: the
-  //  plain method is within 1e-9 already — keeps its answer; the block is skipped when no row of the wave needs it)
-  const bool need_refine = live && pmin < WBC_REFINE_COND * hmax;
-  if (A.refine > 0 && !skip_refine_ && __ballot(need_refine)) {
+  if (A.refine > 0 && !skip_refine_) {
     // r2 — the active constraints' own residual b_k - n_k'y — is formed on the WARM variant only (its iterate is rebuilt from the factors after the
     // seeds: refresh). On the cold path the dual method's steps keep the working set satisfied to rounding and the term changes nothing (same-box
     // check: 6.68e-9 worst with and without it).
@@ -1262,7 +1252,7 @@ __global__ void __launch_bounds__(64, SIM3P_WAVES) wbc_tick_sim3p_kernel(const K
     const double dxl = has_b ? da + db : 0.0;
     const double dmax = -rmin16(-fabs(dxl)), xmax = fmax(1.0, -rmin16(has_b ? -fabs(x) : 0.0));
     const bool nanr = ((__ballot(dxl != dxl) >> rbase) & 0xFFFFull) != 0;
-    if (has_b && need_refine && status == WBC_QP_OPTIMAL && !nanr && dmax <= 0.25 * xmax) x += dxl;
+    if (has_b && status == WBC_QP_OPTIMAL && !nanr && dmax <= 0.25 * xmax) x += dxl;
   }
   if (status == WBC_QP_OPTIMAL) {
     const unsigned long long bad = __ballot(has_b && !(fabs(x) <= 1.7976931348623157e308));
