@@ -63,6 +63,7 @@ struct WbcBatch {
   uint32_t tick_seq;
   int packed_update, last_update_packed;   // option: wbc_update_packed_kernel where every plan allows it [1]; what the last update ran on
   int last_orth;         // the last general-kernel tick ran the variant with the orthonormal contact presolve
+  int last_qp_path;      // problems per wavefront of the last wbc_qp_solve / wbc_qp_solve_ls: 1 (wbc_qp_kernel), 2 or 4 (wbc_qp_packed_kernel)
   int last_path;         // kernel the last wbc_tick / wbc_rollout tick ran on: 0 general, 1 sim3 (+ deferred pass), 2 packed sim3, 3 packed orth, 4 packed box
   int max_nj, max_nf;    // FK output strides: the largest model's joint / frame counts
   unsigned long long* d_prof;
@@ -644,6 +645,7 @@ extern "C" int wbc_batch_get_stat(WbcBatch* b, const char* name, void* stream, i
   if (!b || !name || !out) return fail(WBC_E_ARG, "wbc_batch_get_stat: null");
   HIP_TRY(hipSetDevice(b->device_id));
   if (!strcmp(name, "last_path")) { *out = b->last_path; return WBC_OK; }
+  if (!strcmp(name, "last_qp_path")) { *out = b->last_qp_path; return WBC_OK; }
   if (!strcmp(name, "last_update_packed")) { *out = b->last_update_packed; return WBC_OK; }
   if (!strcmp(name, "last_posture_par")) { *out = b->last_posture_par; return WBC_OK; }
   if (!strcmp(name, "last_orth")) { *out = (b->last_path == 0 || b->last_path == 3) ? b->last_orth : 0; return WBC_OK; }
@@ -1170,8 +1172,11 @@ static int qp_common(WbcBatch* b, int B, QpArgs& a, int mem, void* stream, const
   st.out(&a.x, N * n); st.out(&a.status, N); st.out(&a.iters, N); st.out(&a.H_out, N * n * n); st.out(&a.g_out, N * n);
   st.in(&a.ws_in, N * 2); st.out(&a.ws_out, N * 2);   // (host buffers are staged separately, so in and out may be the same host array)
   if ((rc = st.stage())) return rc;
-  a.refine = b->refine;
-  if (int e = launch_qp(a, grid_for(b, B), stream)) return fail(WBC_E_HIP, "qp kernel launch failed: %s", hipGetErrorString((hipError_t)e));
+  a.refine = b->refine; a.dbg_stop = b->dbg_stop;
+  // several problems per wavefront (wbc_k_qpp.hip) unless the call carries working sets (hot start) or option packed_kernel is 0
+  const int lanes = b->packed_kernel ? qp_packed_lanes(a) : 0;
+  b->last_qp_path = lanes ? lanes : 1;
+  if (int e = lanes ? launch_qp_packed(a, stream) : launch_qp(a, grid_for(b, B), stream)) return fail(WBC_E_HIP, "qp kernel launch failed: %s", hipGetErrorString((hipError_t)e));
   return st.finish();
 }
 

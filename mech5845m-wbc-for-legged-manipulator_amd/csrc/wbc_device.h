@@ -136,6 +136,7 @@ struct KernelArgs {
 
 struct QpArgs {
   int32_t B, n, p, m;               // m > 0: least-squares form (A, b given)
+  int32_t dbg_stop;                 // diagnostic (ablation build): the packed QP kernel returns after stage dbg_stop - 400 (0 = the whole solve)
   int32_t use_mfma, refine;         // refine: iterative-refinement steps at the final working set (option "refine", default 1)
   const double *H, *g, *A, *bvec, *C, *lb, *ub, *Clb, *Cub;
   double *x, *H_out, *g_out;
@@ -192,6 +193,8 @@ int sim3p_lds_bytes();
 int launch_tick_deferred(const KernelArgs& a, void* stream);   // general path for the instances the sim3 kernel deferred
 int sim3_lds_bytes();
 int launch_qp(const QpArgs& a, int grid, void* stream);
+int qp_packed_lanes(const QpArgs& a);           // wbc_k_qpp.hip: problems per wavefront the packed QP kernel takes this shape with (4 / 2), 0: not taken
+int launch_qp_packed(const QpArgs& a, void* stream);
 int launch_integrate(const IntegrateArgs& a, int grid, void* stream);
 int launch_posture(const PostureArgs& a, int grid, void* stream);
 int launch_posture_par(const PostureArgs& a, int grid, void* stream, int three);   // every finite-difference point on its own lane (DevPlan.mp_ok)

@@ -4,14 +4,14 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "mech5845m-wbc-for-legged-manipulator_amd")]
-import numpy as np, torch
+import numpy as np, torch, wbc_model
 from wbc_batch import WbcBatch
 rng=np.random.default_rng(0)
 B=32768
-for n,p in ((8,4),(14,8),(20,8),(26,12)):
+ONLY_LS = len(sys.argv) > 1 and sys.argv[1] == "ls"      # only the QP(A, b) case at (32, 26, 16): what tools/gpu_profile_qp.sh profiles
+for n,p in (() if ONLY_LS else ((8,4),(14,8),(20,8),(26,12))):
     A=rng.normal(size=(B,n+4,n)); H=np.einsum("bmi,bmj->bij",A,A)+1e-3*np.eye(n); g=rng.normal(size=(B,n))
     C=rng.normal(size=(B,p,n)); lb=-np.ones((B,n))*0.5; ub=-lb; cl=-np.ones((B,p)); cu=-cl
-    import wbc_model
     bt=WbcBatch(wbc_model.load_model("a1_wx200"),B)
     d=[torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (H,g,C,lb,ub,cl,cu)]
     for _ in range(3): r=bt.qp_solve(*d)
@@ -24,11 +24,11 @@ for n,p in ((8,4),(14,8),(20,8),(26,12)):
 
 # QP(A, b, ...) = wbc_qp_solve_ls at the tick's shape (m, n, p) = (32, 26, 16) on RANDOM dense data (boxes and two-sided rows, no equalities): the
 # number VERDICT r3 item 5 asks for; the tick's own data (12 equalities, 3 fixed variables): tools/time_qp_tick.py
-for m,n,p in ((32,26,16),(64,26,16)):
+for m,n,p in (((32,26,16),) if ONLY_LS else ((32,26,16),(64,26,16))):
     A=rng.normal(size=(B,m,n)); b=rng.normal(size=(B,m)); C=rng.normal(size=(B,p,n)); lb=-np.ones((B,n))*0.5; ub=-lb; cl=-np.ones((B,p)); cu=-cl
     bt=WbcBatch(wbc_model.load_model("a1_wx200"),B)
     d=[torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in (A,b,C,lb,ub,cl,cu)]
-    for rf in (0,1):
+    for rf in ((1,) if ONLY_LS else (0,1)):
         bt.set_option("refine",rf)
         for _ in range(3): r=bt.qp_solve_ls(*d)
         r=dict(zip(("x","status","iters"), r))
