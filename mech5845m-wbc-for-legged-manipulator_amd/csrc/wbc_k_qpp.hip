@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
         for (int i0 = 0; i0 < MCH; i0 += G) ev[i0 + s] = (i0 + s < mc) ? bb[r0 + i0 + s] : 0.0;
         WSYNC();
         QSTOP(1, Q[s] + ev[s & 15] + crow[0] + lb + ub + clb + cub);     // loads done, A / b staged, C in registers
-        if (has_b) {
+        if (G == 16 && has_b) {             // (G = 32: b rides as column 31 of the padded operand and A'b falls out of the same matrix products)
           double g2 = 0.0;
           int rr = 0;
           for (; rr + 1 < mc; rr += 2) { g = fma(-Q[rr * n + s], ev[rr], g); g2 = fma(-Q[(rr + 1) * n + s], ev[rr + 1], g2); }
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
             const double a0 = (row < mc && c0 < n) ? At[row * n + c0] : 0.0;
             acc[qq][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc[qq][0], 0, 0, 0);
             if (G == 32) {
-              const double a1 = (row < mc && 16 + c0 < n) ? At[row * n + 16 + c0] : 0.0;
+              const double a1 = (row < mc) ? ((16 + c0 < n) ? At[row * n + 16 + c0] : ((c0 == 15) ? At[(int)(ev - Q) + row] : 0.0)) : 0.0;
               acc[qq][NT > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, acc[qq][NT > 1 ? 1 : 0], 0, 0, 0);
               acc[qq][NT > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc[qq][NT > 2 ? 2 : 0], 0, 0, 0);
             }
@@ -183,9 +183,15 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
           if (G == 32) {
             if (16 + col < PV) { Hq[row * LD + 16 + col] = acc[qq][NT > 1 ? 1 : 0][t]; Hq[(16 + col) * LD + row] = acc[qq][NT > 1 ? 1 : 0][t]; }
             if (16 + row < PV && 16 + col < PV) Hq[(16 + row) * LD + 16 + col] = acc[qq][NT > 2 ? 2 : 0][t];
+            if (col == 15) {                // column 31: A'b
+              double* const tq = Hq + (int)(tv - Q);
+              tq[row] = -acc[qq][NT > 1 ? 1 : 0][t];
+              if (16 + row < PV) tq[16 + row] = -acc[qq][NT > 2 ? 2 : 0][t];
+            }
           }
         }
       }
+      if (G == 32) { WSYNC(); g = has_b ? tv[s] : 0.0; }
     } else {
 #pragma unroll
       for (int k = 0; k < PV; ++k) if (s < PV) Q[k * LD + s] = areg[k];
@@ -392,7 +398,9 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
     }
     WSYNC();
   };
-  // with d staged (dv = d, yv = d restricted to the slots >= q): z = J2 d2, r = T d1, and the add step's dq = d_q
+  // with d staged (dv = d, yv = d restricted to the slots >= q): z = J2 d2, r = T d1, and the add step's dq = d_q; row s of J stays in registers
+  // for the add step
+  double jr[PV];
   struct Zr { double z, rv, dq, jq; };
   auto products = [&](const bool want_r) -> Zr {
     Zr o;
@@ -403,6 +411,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
 #pragma unroll
     for (int k = 0; k < PV; k += 2) {
       const double2a j2 = lds2(J + sv * LD + k); const double2a v2 = lds2(yv + k);
+      jr[k] = j2.x; jr[k + 1] = j2.y;
       z = fma(j2.x, v2.x, z); zb = fma(j2.y, v2.y, zb);
     }
     z += zb;
@@ -424,7 +433,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
     if (add && has_b && vv > 0.0) {
       // J2 <- J2 - w v', v = d2 - delta e_q: the sweep runs on d2 alone (yv = d for k >= q, else 0), entry q is then stored with its own term
 #pragma unroll
-      for (int k = 0; k < PV; k += 2) { const double2a j2 = lds2(J + s * LD + k); const double2a v2 = lds2(yv + k); sts2(J + s * LD + k, fma(-w, v2.x, j2.x), fma(-w, v2.y, j2.y)); }
+      for (int k = 0; k < PV; k += 2) { const double2a v2 = lds2(yv + k); sts2(J + s * LD + k, fma(-w, v2.x, jr[k]), fma(-w, v2.y, jr[k + 1])); }
       J[s * LD + q] = fma(-w, zr.dq - delta, jq);
     }
     if (add) {
@@ -537,7 +546,8 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
         xv[s] = x;
         WSYNC();
         const double vrow = rowval();
-        const double v = is_row ? bperm(vrow, rbase + rr_) : bperm(x, rbase + (is_row ? 0 : ip));
+        const double v_r = bperm(vrow, rbase + rr_), v_b = bperm(x, rbase + (is_row ? 0 : ip));
+        const double v = is_row ? v_r : v_b;
         if (dr) { s_ip = sgn * v - b_ip; drop_l = -1; }
       }
       if (!__ballot(stepping)) break;
@@ -606,8 +616,13 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
       const double bl = bperm(lb, rbase + iv), bu = bperm(ub, rbase + iv), rl = bperm(clb, rbase + rr_), ru = bperm(cub, rbase + rr_);
       const double bnd = srow ? (sd ? ru : rl) : (sd ? bu : bl);
       const double vrow = rowval();                          // this lane's own row of C at x
-      const double val = srow ? bperm(vrow, rbase + rr_) : bperm(x, rbase + iv);
+      // (both fetched by every lane before the choice: a ds_bpermute under a divergent branch reads 0 from the lanes the branch switched off)
+      const double val_r = bperm(vrow, rbase + rr_), val_b = bperm(x, rbase + iv);
+      const double val = srow ? val_r : val_b;
       const double r2 = slot ? sgn * (bnd - val) : 0.0;
+#ifdef WBC_ABLATE
+      if (A.dbg_stop >= 410 && A.dbg_stop <= 414) { if (live && has_b) A.x[b * n + s] = A.dbg_stop == 410 ? r2 : A.dbg_stop == 411 ? val : A.dbg_stop == 412 ? bnd : A.dbg_stop == 413 ? (double)a_code : (double)q; return; }
+#endif
       WSYNC();
       tv[s] = gneg; dv[s] = r2;
       WSYNC();
@@ -623,6 +638,9 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
         const double t_ = TP[tri(s) + (i <= s ? i : 0)];
         dy1 = fma((slot && i <= s) ? t_ : 0.0, dv[i], dy1);
       }
+#ifdef WBC_ABLATE
+      if (A.dbg_stop == 406 || A.dbg_stop == 409) dy1 = 0.0;
+#endif
       WSYNC();
       yv[s] = slot ? w : 0.0;
       WSYNC();
@@ -634,8 +652,14 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
       if (slot && !srow) dv[iv] = us;
       WSYNC();
       double r1 = gneg + dv[s];
+#ifdef WBC_ABLATE
+      if (A.dbg_stop == 408 || A.dbg_stop == 409) r1 = gneg;
+#endif
 #pragma unroll 1
       for (int k = 0; k < PV; ++k) {
+#ifdef WBC_ABLATE
+        if (A.dbg_stop == 407 || A.dbg_stop == 409) break;
+#endif
         const bool on = k < q && ((bpermi(a_code, rbase + k) & 255) >= n);
         if (!__ballot(k < q)) break;
         if (!__ballot(on)) continue;

@@ -139,7 +139,7 @@ class WbcBatch:
 
     def stat(self, name, stream=None):
         """wbc_batch_get_stat: "last_path" (0 general, 1 compact sim3, 2 packed sim3, 3 packed orth — equality-only or INEQ variant —, 4 packed box), "last_orth", "last_posture_par",
-        "last_update_packed", "deferred_last", "pivoted_last", "sim3_lds_bytes", "tick_lds_bytes", "orthp_lds_bytes"."""
+        "last_update_packed", "last_qp_path" (problems per wavefront of the last stand-alone QP call: 1, 2 or 4), "deferred_last", "pivoted_last", "sim3_lds_bytes", "tick_lds_bytes", "orthp_lds_bytes"."""
         v = C.c_int64()
         capi.check(self.lib.wbc_batch_get_stat(self._h, name.encode(), stream, C.byref(v)), self.lib)
         return int(v.value)

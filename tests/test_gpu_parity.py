@@ -111,6 +111,40 @@ def test_qp_parity_random(wx200, n, p, n_eq):
     bt.close()
 
 
+@pytest.mark.parametrize("m,n,p,lanes,B", [(18, 14, 6, 4, 301), (40, 26, 16, 2, 301), (12, 8, 0, 4, 64), (40, 20, 20, 2, 65), (30, 20, 8, 2, 65), (24, 16, 6, 4, 130)])
+def test_qp_ls_packed_refined_matches_oracle(wx200, m, n, p, lanes, B):
+    """QP(A, b, ...) on the packed kernel (csrc/wbc_k_qpp.hip: four problems per wavefront for n, p <= 16, else two; B not a multiple of either),
+    ill-conditioned least-squares data (posture-like rows of 3e-5 under O(1) rows: the refinement has something to repair), rows active on both
+    sides, one equality row: same status and iteration count as the oracle, refined answers within 1e-8 of the oracle's refined answers, and the
+    one-per-wavefront kernel (option packed_kernel 0) agrees. The plain answer is off by more than 1e-6: the step is what closes the gap."""
+    rng = np.random.default_rng(40 + n + p)
+    A = np.concatenate([rng.normal(size=(B, m - n, n)), np.broadcast_to(3e-5 * np.eye(n), (B, n, n))], axis=1)
+    b = np.concatenate([rng.normal(size=(B, m - n)), 3e-5 * rng.normal(size=(B, n))], axis=1)
+    C = rng.normal(size=(B, p, n)) if p else None
+    lb, ub = -rng.uniform(0.5, 2.0, (B, n)), rng.uniform(0.5, 2.0, (B, n))
+    lb[:, -1] = ub[:, -1] = 0.03                     # one fixed variable
+    cl, cu = (-rng.uniform(0.1, 1.0, (B, p)), rng.uniform(0.1, 1.0, (B, p))) if p else (None, None)
+    if p:
+        cl[:, 0] = cu[:, 0] = 0.05                   # one equality row
+    xr, sr, ir = oracle.qp_solve_ls(A, b, C, lb, ub, cl, cu)
+    ok = sr == 0
+    assert ok.mean() > 0.9
+    bt = WbcBatch(wx200, B)
+    x, st, it = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu)
+    assert bt.stat("last_qp_path") == lanes
+    assert (st == sr).all() and (it[ok] == ir[ok]).all()
+    assert np.abs(x - xr)[ok].max() < 1e-8, np.abs(x - xr)[ok].max()
+    bt.set_option("refine", 0)
+    x0, st0, _ = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu)
+    assert (st0 == sr).all() and (2 * p > n or np.abs(x0 - xr)[ok].max() > 1e-6)      # (a vertex solution leaves the objective nothing to decide)
+    bt.set_option("refine", 1)
+    bt.set_option("packed_kernel", 0)
+    x1, st1, it1 = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu)
+    assert bt.stat("last_qp_path") == 1
+    assert (st1 == sr).all() and (it1[ok] == ir[ok]).all() and np.abs(x1 - xr)[ok].max() < 1e-8
+    bt.close()
+
+
 def test_qp_ls_forms_H_and_g(wx200):
     """QP(A, b, ...) boundary: H = A'A and g = -A'b formed on the device equal numpy's (QP_Wrapper.py:17-18)."""
     rng = np.random.default_rng(5)
