@@ -70,7 +70,12 @@ __device__ __forceinline__ constexpr int tri(const int k) { return k * (k + 1) /
 #define QSTOP(k, val) do { } while (0)
 #endif
 
-template <int G, int PV>
+// WARM: working sets in / out (QP.solveQPHotstart, QP_Wrapper.py:55-73; the words of wbc_qp_kernel: word 0 bit i / 32 + i = variable i at its lower /
+// upper bound, word 1 = constraint rows). The carried set's inequalities that the equalities-only minimiser violates or comes close to are taken by add
+// steps without a primal step; x and the multipliers are then read off the factors (x = J1 T'b - J2 J2'g, u = T (T'b + J1'g)); while a seeded
+// multiplier is negative its slot is dropped and both are read off again; the dual iterations start from the S-pair that leaves (qp_core's warm
+// start, tests/gi_variant.py solve_v3, with the rebuild after every drop instead of the incremental step).
+template <int G, int PV, bool WARM = false>
 __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
   typedef QppLayout<G, PV> L;
   constexpr int NQ = L::NQ, LD = L::LD, PC = L::PC, MCH = L::MCH, KL = L::KL, blk = L::BLOCK;
@@ -306,7 +311,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
   WSYNC();
 
   // ---- dual active-set state (per problem)
-  int actm = 0;                                            // bit 0: this lane's bound is in the working set, bit 1: its row
+  int actm = 0;                                            // bit 0: this lane's bound is in the working set, bit 1: its row; bits 2 / 3: at the upper side
   double u = 0.0;
   int a_code = 0, q = 0, iters = nfix;
   const int max_iter = 10 * (n + p) + 20;
@@ -359,7 +364,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
   auto drop_slot = [&](const bool dr, const int l_) {
     const int l = dr ? l_ : 0;
     const int lc = bpermi(a_code, rbase + l) & 255;
-    if (dr && s == ((lc >= n) ? lc - n : lc)) actm &= (lc >= n) ? ~2 : ~1;
+    if (dr && s == ((lc >= n) ? lc - n : lc)) actm &= (lc >= n) ? ~10 : ~5;
     WSYNC();
     yv[s] = u; xv[s] = (double)a_code;
     WSYNC();
@@ -440,7 +445,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
       const double idel = (zr.dq >= 0.0) ? -rsz : rsz;
       if (s < q) TP[tri(q) + s] = -zr.rv * idel;
       if (s == q) { TP[tri(q) + s] = idel; u = u_new; a_code = wc; }
-      if (s == (is_row ? rr_ : ip)) actm |= is_row ? 2 : 1;
+      if (s == (is_row ? rr_ : ip)) actm |= is_row ? (2 | ((wc >> 8) << 3)) : (1 | ((wc >> 8) << 2));
       ++q;
     }
     return delta;
@@ -492,6 +497,98 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
 #pragma unroll
     for (int k = 0; k < PV; k += 2) { const double2a j2 = lds2(J + sv * LD + k); const double2a v2 = lds2(dv + k); xa = fma(j2.x, v2.x, xa); xb = fma(j2.y, v2.y, xb); }
     x = has_b ? xa + xb : 0.0;
+  }
+
+  // ================================ warm start ======================================================
+  if (WARM && A.ws_in) {
+    const unsigned long long w0 = A.ws_in[2 * b], w1 = A.ws_in[2 * b + 1];
+    auto bits = [](const unsigned long long w, const int i) -> int { return (int)(((w >> (i & 31)) & 1ull) | (((w >> (32 + (i & 31))) & 1ull) << 1)); };
+    int sb = has_b ? bits(w0, s) : 0, sr = has_r ? bits(w1, s) : 0;
+    if (sb == 3) sb = 0;
+    if (sr == 3) sr = 0;
+    // a seed is taken only if the equalities-only minimiser violates it or comes close to it (within 0.25 max(1, |x|_inf): qp_core, solve_v3 `far`)
+    WSYNC();
+    xv[s] = x;
+    WSYNC();
+    const double near = 0.25 * fmax(1.0, -gmin<G>(has_b ? -fabs(x) : 0.0));
+    const double vr = rowval();
+    const double slb = (sb == 2) ? ub - x : x - lb, slr = (sr == 2) ? cub - vr : vr - clb;
+    bool pend_b = ok && has_b && ((sb == 1 && lb > -QP_INF) || (sb == 2 && ub < QP_INF)) && (slb <= near);     // (a fixed variable's bounds are infinite by now)
+    bool pend_r = ok && has_r && !eq_r && ((sr == 1 && clb > -QP_INF) || (sr == 2 && cub < QP_INF)) && (slr <= near);
+    bool seeded = false;
+#pragma unroll 1
+    for (;;) {                              // one seed per problem and pass: bounds first, then rows, lowest index first
+      const unsigned mb = gmask<G>(__ballot(pend_b), rbase), mr = gmask<G>(__ballot(pend_r), rbase);
+      const bool seeding = (mb | mr) != 0u;
+      if (!__ballot(seeding)) break;
+      const bool is_row = mb == 0u;
+      const int idx = seeding ? __ffs((int)(is_row ? mr : mb)) - 1 : 0;
+      if (seeding && s == idx) { if (is_row) pend_r = false; else pend_b = false; }
+      const int side_b = bpermi(sb, rbase + idx), side_r = bpermi(sr, rbase + idx);
+      const double n2r = bperm(cn2, rbase + idx);
+      const int c_side = ((is_row ? side_r : side_b) == 2) ? 256 : 0;
+      const int wc = (is_row ? n + idx : idx) | c_side;
+      const double np2 = is_row ? n2r : 1.0;
+      WSYNC();
+      const double d = normal_d(seeding, is_row, idx, idx, c_side ? -1.0 : 1.0);
+      WSYNC();
+      dv[s] = d; yv[s] = (s >= q) ? d : 0.0;
+      WSYNC();
+      const double zn = gsum<G>(s >= q ? d * d : 0.0);
+      const Zr zr = products(__ballot(seeding && q > 0) != 0);
+      const bool add = seeding && (zn > 100.0 * n * EPS2 * jf2 * np2);      // (a dependent seed is simply not taken)
+      if (__ballot(add)) {
+        add_step(add, zn, zr, wc, is_row, idx, idx, 0.0);
+        if (add) { seeded = true; ++iters; }
+      }
+    }
+    // x, u of the working set from the factors: b_k = the slots' right-hand sides,  y1 = T'b,  x = J1 y1 - J2 J2'g,  u = T (y1 + J1'g)
+    auto rebuild = [&](const bool on) {
+      const int cc = a_code & 255, sd = (a_code >> 8) & 1;
+      const bool slot = s < q, srow = slot && cc >= n;
+      const int rr_ = srow ? cc - n : 0, iv = (slot && !srow) ? cc : 0;
+      const double bl = bperm(lb, rbase + iv), bu = bperm(ub, rbase + iv), rl = bperm(clb, rbase + rr_), ru = bperm(cub, rbase + rr_);
+      const double bs = slot ? (srow ? (sd ? -ru : rl) : (sd ? -bu : bl)) : 0.0;
+      WSYNC();
+      dv[s] = bs;
+      WSYNC();
+      double y1n = 0.0;
+#pragma unroll 1
+      for (int i = 0; i < PV; ++i) {
+        if (!__ballot(slot && i <= s)) break;
+        const double t_ = TP[tri(s) + (i <= s ? i : 0)];
+        y1n = fma((slot && i <= s) ? t_ : 0.0, dv[i], y1n);
+      }
+      double jg = 0.0, jgb = 0.0;
+#pragma unroll
+      for (int i = 0; i < PV; i += 2) { const double2a g2 = lds2(tv + i); jg = fma(J[i * LD + sv], g2.x, jg); jgb = fma(J[(i + 1) * LD + sv], g2.y, jgb); }
+      jg += jgb;
+      WSYNC();
+      yv[s] = slot ? y1n : (has_b ? -jg : 0.0);
+      dv[s] = slot ? y1n + jg : 0.0;
+      WSYNC();
+      double xa = 0.0, xb = 0.0;
+#pragma unroll
+      for (int k = 0; k < PV; k += 2) { const double2a j2 = lds2(J + sv * LD + k); const double2a v2 = lds2(yv + k); xa = fma(j2.x, v2.x, xa); xb = fma(j2.y, v2.y, xb); }
+      const double un = t_row_times(dv);
+      if (on) { x = has_b ? xa + xb : 0.0; u = (s >= qe && s < q) ? un : 0.0; }
+    };
+    if (__ballot(seeded)) {
+      rebuild(seeded);
+      // RESTORATION: while a seeded multiplier is negative the most negative slot is dropped and x, u are read off the factors again
+      bool restoring = seeded;
+#pragma unroll 1
+      for (;;) {
+        const double um = gmin<G>((s >= qe && s < q) ? u : 0.0);
+        bool rest = restoring && (um < 0.0);
+        if (rest && ++iters > max_iter) { status = WBC_QP_MAX_ITER; rest = false; restoring = false; ok = false; }
+        if (!__ballot(rest)) break;
+        const unsigned lm = gmask<G>(__ballot(rest && s >= qe && s < q && u == um), rbase);
+        const int l = lm ? __ffs((int)lm) - 1 : 0;
+        drop_slot(rest, l);
+        rebuild(rest);
+      }
+    }
   }
 
   QSTOP(4, x);
@@ -697,6 +794,13 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
 
   // ---- outputs. A QP that was not solved returns x = 0 (QP_Wrapper.py:50, 71-73: qpOASES does not write the primal vector of an unsolved problem)
   if (status == WBC_QP_OPTIMAL && gmask<G>(__ballot(has_b && !(fabs(x) <= 1.7976931348623157e308)), rbase)) status = WBC_QP_NUMERICAL;
+  if (WARM && A.ws_out) {                  // the working set the next call is seeded with (an unsolved QP carries nothing; equalities are not carried)
+    const bool opt = status == WBC_QP_OPTIMAL;
+    const bool ab = opt && (actm & 1), ar = opt && (actm & 2) && !eq_r;
+    const unsigned long long o0 = (unsigned long long)gmask<G>(__ballot(ab && !(actm & 4)), rbase) | ((unsigned long long)gmask<G>(__ballot(ab && (actm & 4)), rbase) << 32);
+    const unsigned long long o1 = (unsigned long long)gmask<G>(__ballot(ar && !(actm & 8)), rbase) | ((unsigned long long)gmask<G>(__ballot(ar && (actm & 8)), rbase) << 32);
+    if (live && s == 0) { A.ws_out[2 * b] = o0; A.ws_out[2 * b + 1] = o1; }
+  }
   if (live) {
     if (has_b) A.x[b * n + s] = (status == WBC_QP_OPTIMAL) ? x : 0.0;
     if (s == 0) {
@@ -706,17 +810,29 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
   }
 }
 
+// One translation unit per PART (csrc/Makefile): part 0 holds the cold variants and the launcher, part 1 the hot-start variants.
+#ifndef QPP_PART
+#define QPP_PART -1
+#endif
+#if QPP_PART == 0
+extern template __global__ void wbc_qp_packed_kernel<16, 16, true>(const QpArgs);
+extern template __global__ void wbc_qp_packed_kernel<32, NV, true>(const QpArgs);
+#elif QPP_PART == 1
+template __global__ void wbc_qp_packed_kernel<16, 16, true>(const QpArgs);
+template __global__ void wbc_qp_packed_kernel<32, NV, true>(const QpArgs);
+#endif
+#if QPP_PART <= 0
 template <int G, int PV>
 static int launch_qpp(const QpArgs& a, hipStream_t s) {
   typedef QppLayout<G, PV> L;
   const int grid = (a.B + L::NQ - 1) / L::NQ;
-  hipLaunchKernelGGL((wbc_qp_packed_kernel<G, PV>), dim3(grid), dim3(64), 0, s, a);
+  if (a.ws_in || a.ws_out) hipLaunchKernelGGL((wbc_qp_packed_kernel<G, PV, true>), dim3(grid), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((wbc_qp_packed_kernel<G, PV, false>), dim3(grid), dim3(64), 0, s, a);
   return check_launch("qp packed");
 }
 
-// 4: four problems per wavefront, 2: two; 0: the shape is not taken (hot start: the one-per-wavefront kernel carries the working sets)
+// 4: four problems per wavefront, 2: two
 int qp_packed_lanes(const QpArgs& a) {
-  if (a.ws_in || a.ws_out) return 0;
   if (a.n <= 16 && a.p <= 16) return 4;
   return 2;
 }
@@ -725,5 +841,6 @@ int launch_qp_packed(const QpArgs& a, void* stream) {
   if (qp_packed_lanes(a) == 4) return launch_qpp<16, 16>(a, s);
   return launch_qpp<32, NV>(a, s);
 }
+#endif
 
 }  // namespace wbc

@@ -1611,6 +1611,47 @@ def test_qp_entry_points_take_and_return_working_sets():
     bt.close()
 
 
+@pytest.mark.parametrize("m,n,p,lanes", [(32, 26, 16, 2), (20, 14, 9, 4)])
+def test_qp_hot_start_on_the_packed_kernel(m, n, p, lanes):
+    """QP.solveQPHotstart (QP_Wrapper.py:55-73) on the packed kernel's WARM variant (csrc/wbc_k_qpp.hip): seeded with its own final set the problem
+    comes back with the same answer, the same set and no more working-set changes than cold; with the set of a perturbed problem ("previous tick")
+    or garbage the answer is the oracle's; the one-per-wavefront kernel (option packed_kernel 0) returns the same sets bit for bit."""
+    rng = np.random.default_rng(70 + n)
+    B = 257
+    A = rng.normal(size=(B, m, n))
+    b = rng.normal(size=(B, m)) * 3
+    C = rng.normal(size=(B, p, n))
+    lb, ub = -rng.uniform(0.05, 0.6, (B, n)), rng.uniform(0.05, 0.6, (B, n))
+    lb[:, 2] = ub[:, 2] = 0.01                                      # a fixed variable: presolved, never in a carried set
+    cl, cu = -rng.uniform(0.05, 0.6, (B, p)), rng.uniform(0.05, 0.6, (B, p))
+    cl[:, 1] = cu[:, 1] = 0.02                                      # an equality row: always in, never carried
+    xr, sr, ir = oracle.qp_solve_ls(A, b, C, lb, ub, cl, cu)
+    ok = sr == 0
+    assert ok.mean() > 0.9
+    bt = WbcBatch([], B)
+    x0, s0, i0, ws0 = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu, want_working_set=True)
+    assert bt.stat("last_qp_path") == lanes
+    assert (s0 == sr).all() and np.abs(x0 - xr)[ok].max() < 1e-8 and (i0 == ir)[ok].all()
+    assert (ws0[~ok] == 0).all() and (ws0[ok] != 0).any()
+    assert ((ws0[:, 0] >> 2) & 1 == 0).all() and ((ws0[:, 0] >> 34) & 1 == 0).all() and ((ws0[:, 1] >> 1) & 1 == 0).all() and ((ws0[:, 1] >> 33) & 1 == 0).all()
+    x1, s1, i1, ws1 = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu, working_set=ws0, want_working_set=True)
+    assert bt.stat("last_qp_path") == lanes
+    assert (s1 == sr).all() and np.abs(x1 - xr)[ok].max() < 1e-8 and (ws1 == ws0)[ok].all()
+    assert i1[ok].mean() <= i0[ok].mean(), (i1[ok].mean(), i0[ok].mean())
+    _, _, _, wsp = bt.qp_solve_ls(A, b + rng.normal(size=(B, m)) * 0.1, C, lb, ub, cl, cu, want_working_set=True)
+    x2, s2, i2, ws2 = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu, working_set=wsp, want_working_set=True)
+    assert (s2 == sr).all() and np.abs(x2 - xr)[ok].max() < 1e-7 and (ws2 == ws0)[ok].all()
+    junk = rng.integers(-2 ** 62, 2 ** 62, (B, 2), dtype=np.int64)
+    x3, s3, _ = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu, working_set=junk)
+    assert (s3 == sr).all() and np.abs(x3 - xr)[ok].max() < 1e-7
+    print("working-set changes per QP: cold %.2f, own set %.2f, previous problem's set %.2f" % (i0[ok].mean(), i1[ok].mean(), i2[ok].mean()))
+    bt.set_option("packed_kernel", 0)
+    x4, s4, i4, ws4 = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu, working_set=wsp, want_working_set=True)
+    assert bt.stat("last_qp_path") == 1
+    assert (s4 == sr).all() and (ws4 == ws2)[ok].all() and np.abs(x4 - x2)[ok].max() < 1e-8
+    bt.close()
+
+
 @pytest.mark.parametrize("cfg_name", ["c3", "everything", "c2", "full"])
 def test_warm_started_tick_reaches_the_cold_optimum(wx200, px100, cfg_name):
     """SURVEY.md §8 f2 (QP_Wrapper.py:55-73, Robot_Wrapper4.py:1389-1394): a tick seeded with a working set — the previous

@@ -36,4 +36,14 @@ for m,n,p in (((32,26,16),) if ONLY_LS else ((32,26,16),(64,26,16))):
         for _ in range(10): bt.qp_solve_ls(*d)
         torch.cuda.synchronize(); dt=(time.perf_counter()-t)/10
         print("QP(A, b) random m=%d n=%d p=%d refine %d: %.3f ms  %.1f M QPs/s  optimal %.3f iters %.2f"%(m,n,p,rf,dt*1e3,B/dt/1e6,(r["status"]==0).double().mean().item(), r["iters"].double().mean().item()))
+    if not ONLY_LS:
+        # hot start (QP.solveQPHotstart): working sets in and out, seeded with the set of a perturbed right-hand side (the "previous tick") and with its own
+        ws=torch.zeros((B,2),dtype=torch.int64,device="cuda")
+        for what,bb in (("previous problem's set", d[1]+0.05*torch.randn_like(d[1])),("its own set", d[1])):
+            r=bt.qp_solve_ls(d[0],bb,*d[2:],want_working_set=True); ws=r[3]
+            for _ in range(3): r=bt.qp_solve_ls(*d,working_set=ws,want_working_set=True)
+            torch.cuda.synchronize(); t=time.perf_counter()
+            for _ in range(10): bt.qp_solve_ls(*d,working_set=ws,want_working_set=True)
+            torch.cuda.synchronize(); dt=(time.perf_counter()-t)/10
+            print("QP(A, b) random m=%d n=%d p=%d hot start, %s: %.3f ms  %.1f M QPs/s  optimal %.3f iters %.2f  (path %d)"%(m,n,p,what,dt*1e3,B/dt/1e6,(r[1]==0).double().mean().item(), r[2].double().mean().item(), bt.stat("last_qp_path")))
     bt.close()
