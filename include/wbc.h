@@ -227,15 +227,20 @@ int wbc_assemble(WbcBatch* b, int B, const WbcTickIn* in, double dt, int mem, co
  * Hot start (solveQPHotstart, QP_Wrapper.py:55-73: qpOASES keeps its working set between calls): working_set_in / working_set_out,
  * [B][2] words in the QP's own indexing — word 0: bit i = variable i at its lower bound, bit 32 + i = at its upper bound; word 1: the
  * same for constraint row i. Either may be NULL (cold start / nothing returned); they may be the same buffer. A seed is only a hint:
- * the answer is the cold solve's (H > 0), wrong seeds are dropped again. An unsolved QP returns an empty set. */
+ * the answer is the cold solve's (H > 0), wrong seeds are dropped again. An unsolved QP returns an empty set.
+ * Kernel: several problems per wavefront (csrc/wbc_k_qpp.hip: four when n <= 16 and p <= 16, else two; statistic "last_qp_path" = 4 / 2),
+ * cold and hot start alike; option "packed_kernel" 0 keeps one problem per wavefront (csrc/wbc_k_misc.hip, "last_qp_path" = 1). Same status,
+ * iteration count and working set from both; answers equal to rounding. */
 int wbc_qp_solve(WbcBatch* b, int B, int n, int p, const double* H, const double* g, const double* C,
                  const double* lb, const double* ub, const double* Clb, const double* Cub, int mem,
                  double* x, int32_t* status, int32_t* iters, const uint64_t* working_set_in, uint64_t* working_set_out,
                  void* stream);
 
 /* replaces QP(A, b, ...) + solveQP(): forms H = A'A, g = -A'b on the device (QP_Wrapper.py:17-18)
- * and solves. A is [B][m][n]. H_out/g_out optional. use_mfma: 1 = fp64 MFMA contraction, 0 = VALU, -1 = MFMA from
- * WBC_MFMA_AUTO_ROWS rows on (measured 1.3x at m = 32, 1.8x at m = 64 and 96 on the whole call).
+ * and solves. A is [B][m][n], m <= WBC_MAX_M. H_out/g_out optional. The packed kernel (see wbc_qp_solve) forms A'A on the fp64 matrix cores
+ * always; use_mfma chooses inside the one-per-wavefront kernel only: 1 = fp64 MFMA contraction, 0 = VALU, -1 = MFMA from WBC_MFMA_AUTO_ROWS rows on.
+ * With option "refine" (default 1) the answer gets one step of iterative refinement from A, b themselves where the problem's pivot ratio asks
+ * for it (csrc/wbc_common.h WBC_REFINE_COND; QP_Wrapper.py:37 numRefinementSteps); wbc_qp_solve (H, g alone) is never refined.
  * working_set_in / working_set_out: as in wbc_qp_solve (QP.solveQPHotstart passes the previous call's set). */
 int wbc_qp_solve_ls(WbcBatch* b, int B, int m, int n, int p, const double* A, const double* bvec, const double* C,
                     const double* lb, const double* ub, const double* Clb, const double* Cub, int mem, int use_mfma,
@@ -387,6 +392,7 @@ int wbc_batch_set_option(WbcBatch* b, const char* name, int value);
 /* Read-only statistics of a handle: "last_path" (kernel the last tick ran on: 0 general, 1 compact sim3 + second pass, 2 packed
  * compact sim3 — four instances per wavefront, one kernel —, 3 packed orth kernel, 4 packed box kernel), "last_orth" (1: that tick ran with the
  * orthonormal contact presolve, option "presolve_orth": the general kernel's ORTH variant or the packed orth kernel),
+ * "last_qp_path" (problems per wavefront of the last wbc_qp_solve / wbc_qp_solve_ls call: 4, 2 or 1),
  * "last_update_packed" (1: the last state update ran on the packed kernel), "last_posture_par" (1 / 2: the last MANI / HYBRID posture target
  * ran on the parallel posture kernel, one / three instances per wavefront), "deferred_last" (instances the last tick's kernel could not reduce itself: redone in the packed kernels'
  * tail or left to the one-instance kernel's second pass; waits for `stream`), "pivoted_last" (instances that took the pivoted
