@@ -438,41 +438,9 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_boxp_kernel(const KernelArgs A
   double y[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) y[k] = (k == s) ? 1.0 : 0.0;
-  double pmin = 1.0;
-#pragma unroll 1
-  for (int j = 0; j < 16; j += 2) {
-    WSYNC();
-    cl[s] = h[0]; yv[s] = h[1];
-    WSYNC();
-    const double* c0 = cl + j;
-    const double* c1 = yv + j;
-    double cm0[16], cm1[16];
-#pragma unroll
-    for (int rr = 0; rr < 16; rr += 2) {
-      const double2a v0 = lds2(c0 + rr), v1 = lds2(c1 + rr);
-      cm0[rr] = v0.x; cm0[rr + 1] = v0.y; cm1[rr] = v1.x; cm1[rr + 1] = v1.y;
-    }
-    const double pj = cm0[0];
-    pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;
-    const double rinv = rsqrt(pj), ipj = rinv * rinv;
-    const double th = h[0] * ipj, ty = y[0] * ipj, yk = y[0] * rinv;
-    const double h1 = fma(-th, cm0[1], h[1]), y1 = fma(-ty, cm0[1], y[1]);
-    const double a = cm0[1];
-#pragma unroll
-    for (int rr = 1; rr < 16; ++rr) cm1[rr] = fma(-(cm0[rr] * ipj), a, cm1[rr]);
-    const double pj2 = cm1[1];
-    pmin = (pj2 > 0.0) ? fmin(pmin, pj2) : -1.0;
-    const double rinv2 = rsqrt(pj2), ipj2 = rinv2 * rinv2;
-    const double th2 = h1 * ipj2, ty2 = y1 * ipj2, yk2 = y1 * rinv2;
-#pragma unroll
-    for (int rr = 2; rr < 16; ++rr) h[rr - 2] = fma(-th2, cm1[rr], fma(-th, cm0[rr], h[rr]));
-#pragma unroll
-    for (int rr = 2; rr < 16; ++rr) y[rr - 2] = fma(-ty2, cm1[rr], fma(-ty, cm0[rr], y[rr]));
-    y[14] = fma(-ty2, 0.0, yk); y[15] = yk2;
-    h[14] = 0.0; h[15] = 0.0;
-  }
+  const double pmin = chol_sweep2<16>(h, y, cl, yv, s, true);      // (wbc_packed.h)
   if (live && !(pmin > 0.0)) { status = WBC_QP_NUMERICAL; live = false; }
-  XSTOP(6, y[0] + y[15] + h[0]);
+  XSTOP(6, y[0] + y[15] + h[15]);
   // y = row s of J0 = L^-T.  jf2 = |J0|_F^2 per instance
   double sq = 0.0;
 #pragma unroll

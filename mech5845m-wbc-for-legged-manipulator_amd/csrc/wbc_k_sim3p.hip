@@ -741,43 +741,7 @@ __global__ void __launch_bounds__(64, SIM3P_WAVES) wbc_tick_sim3p_kernel(const K
   double y[PV];
 #pragma unroll
   for (int k = 0; k < PV; ++k) y[k] = (k == s) ? 1.0 : 0.0;
-  double pmin = 1.0;
-  // Two columns per trip: the raw columns j and j + 1 of every row go through LDS together and each lane redoes, for the rows below, the
-  // one update that column j + 1 receives from step j — the same operations in the same order as two single steps (bit-identical), one LDS
-  // round trip instead of two in the 12-step chain. Fully unrolled on fixed registers (round 4): trip j reads and updates the entries k >= j
-  // only — 42 b128 reads and 156 multiply-adds over the sweep instead of the 72 and 306 of the rotating-register loop it replaces (same results:
-  // the loop did the rest on zeros).
-#pragma unroll
-  for (int j = 0; j < PV; j += 2) {
-    WSYNC();
-    if (s < PV) { V.cl[s] = h[j]; V.yv[s] = h[j + 1]; }
-    WSYNC();
-    double cm0[PV], cm1[PV];
-#pragma unroll
-    for (int k = j; k < PV; k += 2) {
-      const double2a v0 = lds2(V.cl + k), v1 = lds2(V.yv + k);
-      cm0[k] = v0.x; cm0[k + 1] = v0.y; cm1[k] = v1.x; cm1[k + 1] = v1.y;
-    }
-    const double pj = cm0[j];
-    pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;
-    const double rinv = rsqrt(pj), ipj = rinv * rinv;
-    // step j on this row
-    const double th = h[j] * ipj, ty = y[j] * ipj, yk = y[j] * rinv;
-    const double h1 = fma(-th, cm0[j + 1], h[j + 1]), y1 = fma(-ty, cm0[j + 1], y[j + 1]);
-    // step j as it acts on column j + 1 of the rows below (what their own lanes compute for themselves)
-    const double a = cm0[j + 1];
-#pragma unroll
-    for (int k = j + 1; k < PV; ++k) cm1[k] = fma(-(cm0[k] * ipj), a, cm1[k]);
-    const double pj2 = cm1[j + 1];
-    pmin = (pj2 > 0.0) ? fmin(pmin, pj2) : -1.0;
-    const double rinv2 = rsqrt(pj2), ipj2 = rinv2 * rinv2;
-    const double th2 = h1 * ipj2, ty2 = y1 * ipj2, yk2 = y1 * rinv2;
-#pragma unroll
-    for (int k = j + 2; k < PV; ++k) h[k] = fma(-th2, cm1[k], fma(-th, cm0[k], h[k]));
-#pragma unroll
-    for (int k = j + 2; k < PV; ++k) y[k] = fma(-ty2, cm1[k], fma(-ty, cm0[k], y[k]));
-    y[j] = fma(-ty2, 0.0, yk); y[j + 1] = yk2;
-  }
+  const double pmin = chol_sweep2<PV>(h, y, V.cl, V.yv, s, s < PV);      // (wbc_packed.h)
   if (live && !(pmin > 0.0)) { status = WBC_QP_NUMERICAL; live = false; }
   PSTOP(4, y[0] + y[11] + h[11]);
   // y = row s of J0 = L^-T.  jf2 = |J0|_F^2 per instance

@@ -77,6 +77,49 @@ __device__ __forceinline__ unsigned long long ror16(unsigned long long v) {   //
   return v;
 }
 
+// The packed kernels' Cholesky sweep H' = L L' fused with the forward substitution L y = rhs (y comes in holding the lane's right-hand side: e_s, or g'
+// on a padding lane), two columns per trip: the raw columns j and j + 1 of every row go through the LDS vectors c0v / c1v together and each lane redoes,
+// for the rows below, the one update that column j + 1 receives from step j — the same operations in the same order as two single steps, one LDS round
+// trip instead of two. Fully unrolled on fixed registers (round 4): trip j reads and updates the entries k >= j only — for N = 12: 42 b128 reads and
+// 156 multiply-adds over the sweep instead of the 72 and 306 of the rotating-register loop this replaces (which did the rest on zeros: same results
+// bit for bit); N = 16: 72 / 288 instead of 128 / 568. `wr`: this lane carries a row (s < N). Returns the smallest pivot (-1: not positive / NaN).
+template <int N>
+__device__ __forceinline__ double chol_sweep2(double (&h)[N], double (&y)[N], double* const c0v, double* const c1v, const int s, const bool wr) {
+  double pmin = 1.0;
+#pragma unroll
+  for (int j = 0; j < N; j += 2) {
+    WSYNC();
+    if (wr) { c0v[s] = h[j]; c1v[s] = h[j + 1]; }
+    WSYNC();
+    double cm0[N], cm1[N];
+#pragma unroll
+    for (int k = j; k < N; k += 2) {
+      const double2a v0 = lds2(c0v + k), v1 = lds2(c1v + k);
+      cm0[k] = v0.x; cm0[k + 1] = v0.y; cm1[k] = v1.x; cm1[k + 1] = v1.y;
+    }
+    const double pj = cm0[j];
+    pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;
+    const double rinv = rsqrt(pj), ipj = rinv * rinv;
+    // step j on this row
+    const double th = h[j] * ipj, ty = y[j] * ipj, yk = y[j] * rinv;
+    const double h1 = fma(-th, cm0[j + 1], h[j + 1]), y1 = fma(-ty, cm0[j + 1], y[j + 1]);
+    // step j as it acts on column j + 1 of the rows below (what their own lanes compute for themselves)
+    const double a = cm0[j + 1];
+#pragma unroll
+    for (int k = j + 1; k < N; ++k) cm1[k] = fma(-(cm0[k] * ipj), a, cm1[k]);
+    const double pj2 = cm1[j + 1];
+    pmin = (pj2 > 0.0) ? fmin(pmin, pj2) : -1.0;
+    const double rinv2 = rsqrt(pj2), ipj2 = rinv2 * rinv2;
+    const double th2 = h1 * ipj2, ty2 = y1 * ipj2, yk2 = y1 * rinv2;
+#pragma unroll
+    for (int k = j + 2; k < N; ++k) h[k] = fma(-th2, cm1[k], fma(-th, cm0[k], h[k]));
+#pragma unroll
+    for (int k = j + 2; k < N; ++k) y[k] = fma(-ty2, cm1[k], fma(-ty, cm0[k], y[k]));
+    y[j] = fma(-ty2, 0.0, yk); y[j + 1] = yk2;
+  }
+  return pmin;
+}
+
 // shared by the packed orth and box kernels: FK levels of their whole-tree schedule (DevPlan.q_fk) and the staged weights image wt [96]
 constexpr int QLEV = 6;
 static_assert(offsetof(WbcConfig, joint_w) - offsetof(WbcConfig, ee_W) == 84 * sizeof(double), "ee_W [30] ee_w [5] ee_gain [30] trunk [13] com_W [3] com_gain [3] joint_w");
