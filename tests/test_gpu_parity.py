@@ -1014,6 +1014,57 @@ def test_api_misuse_is_refused_with_a_message(wx200, px100):
     b2.close()
 
 
+def test_qp_packed_edge_cases_agree_with_the_oracle_and_the_one_per_wavefront_kernel():
+    """The packed stand-alone QP kernel (csrc/wbc_k_qpp.hip) on the problems a plug-in boundary has to survive, mixed in one batch so that the two or four
+    problems of a wavefront differ in fate: infeasible rows, contradictory and redundant equality rows, more equality rows than unknowns, H not positive
+    definite, a NaN bound, no inequality active at all — and the extreme shapes (n = 1; n = 26 with p = 24 rows and m = 96 task rows; no box, no rows).
+    Status from the oracle, x = 0 where unsolved, the neighbours' answers untouched; the one-per-wavefront kernel says the same."""
+    rng = np.random.default_rng(314)
+    for n, p, m in ((14, 9, 20), (26, 24, 96), (1, 0, 1), (5, 8, 7)):
+        B = 67
+        A = rng.normal(size=(B, m, n))
+        b = rng.normal(size=(B, m))
+        C = rng.normal(size=(B, p, n)) if p else None
+        lb, ub = -rng.uniform(0.3, 1.0, (B, n)), rng.uniform(0.3, 1.0, (B, n))
+        cl, cu = (-rng.uniform(0.3, 1.0, (B, p)), rng.uniform(0.3, 1.0, (B, p))) if p else (None, None)
+        if m < n:
+            A = np.concatenate([A, np.broadcast_to(0.1 * np.eye(n), (B, n, n))], axis=1)
+            b = np.concatenate([b, np.zeros((B, n))], axis=1)
+        kinds = np.arange(B) % 8
+        if p:
+            cl[kinds == 1, 0], cu[kinds == 1, 0] = 50.0, 60.0                                  # infeasible against the box
+            if p >= 2:
+                C[kinds == 2, 1] = C[kinds == 2, 0]                                            # contradictory equalities
+                cl[kinds == 2, 0] = cu[kinds == 2, 0] = 0.1
+                cl[kinds == 2, 1] = cu[kinds == 2, 1] = -0.1
+                C[kinds == 3, 1] = 2.0 * C[kinds == 3, 0]                                      # a redundant equality (consistent)
+                cl[kinds == 3, 0] = cu[kinds == 3, 0] = 0.05
+                cl[kinds == 3, 1] = cu[kinds == 3, 1] = 0.1
+            if p > n:
+                cl[kinds == 4] = cu[kinds == 4] = 0.0                                          # more equality rows than unknowns, all through the origin: consistent
+        A[kinds == 5] = 0.0                                                                    # H = 0: not positive definite
+        lb[kinds == 6, 0] = np.nan
+        lb[kinds == 7], ub[kinds == 7] = -1e3, 1e3                                             # nothing active but (perhaps) rows
+        xr, sr, ir = oracle.qp_solve_ls(A, b, C, lb, ub, cl, cu)
+        bt = WbcBatch([], B)
+        x, st, it = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu)
+        assert bt.stat("last_qp_path") == (4 if (n <= 16 and p <= 16) else 2)
+        assert (st == sr).all(), (n, p, np.nonzero(st != sr), st[st != sr], sr[st != sr])
+        assert len(set(sr.tolist())) >= 2 and (x[sr != 0] == 0).all()
+        ok = sr == 0
+        assert np.abs(x - xr)[ok].max() < 1e-8 and (it[ok] == ir[ok]).all()
+        bt.set_option("packed_kernel", 0)
+        x1, st1, it1 = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu)
+        assert (st1 == sr).all() and np.abs(x1 - x)[ok].max() < 1e-8
+        # no box and no rows at all: the unconstrained minimiser
+        bt.set_option("packed_kernel", 1)
+        x2, st2, it2 = bt.qp_solve_ls(A[kinds != 5], b[kinds != 5])
+        assert (st2 == 0).all() and (it2 == 0).all()
+        xs = np.stack([np.linalg.lstsq(A_, b_, rcond=None)[0] for A_, b_ in zip(A[kinds != 5], b[kinds != 5])])
+        assert np.abs(x2 - xs).max() < 1e-9
+        bt.close()
+
+
 def test_infeasible_and_degenerate_instances_agree_with_the_oracle(wx200):
     """Instances the QP cannot satisfy (trunk far outside its box: the box rows contradict the bounds) must be flagged
     exactly like the oracle flags them, and must not disturb their neighbours in the batch."""
