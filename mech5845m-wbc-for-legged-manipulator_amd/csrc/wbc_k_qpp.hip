@@ -75,7 +75,10 @@ __device__ __forceinline__ constexpr int tri(const int k) { return k * (k + 1) /
 // steps without a primal step; x and the multipliers are then read off the factors (x = J1 T'b - J2 J2'g, u = T (T'b + J1'g)); while a seeded
 // multiplier is negative its slot is dropped and both are read off again; the dual iterations start from the S-pair that leaves (qp_core's warm
 // start, tests/gi_variant.py solve_v3, with the rebuild after every drop instead of the incremental step).
-template <int G, int PV, bool WARM = false>
+// HALF (G = 32, p <= 16): a row of C is split over the two 16-lane halves of its problem — lane s keeps columns 0..13 of row s & 15 when s < 16, columns
+// 14..25 when s >= 16 — 28 VGPRs instead of 52, at the register wall of this kernel; a row's value is the two halves' partial sums added across the
+// halves (one v_permlane16_swap), each half reads only its part of the broadcast vector.
+template <int G, int PV, bool WARM = false, bool HALF = false>
 __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
   typedef QppLayout<G, PV> L;
   constexpr int NQ = L::NQ, LD = L::LD, PC = L::PC, MCH = L::MCH, KL = L::KL, blk = L::BLOCK;
@@ -104,7 +107,11 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
   double clb = has_r ? A.Clb[b * p + s] : 0.0;
   double cub = has_r ? A.Cub[b * p + s] : 0.0;
   double g = 0.0;
-  double crow[PV];                                         // row s of C (zero for s >= p)
+  constexpr int NCR = HALF ? 14 : PV;                      // columns of C this lane keeps
+  const int crw = HALF ? (s & 15) : s;                     // ... of which row
+  const int c0 = (HALF && s >= 16) ? 14 : 0;               // ... from which column on
+  const bool c_on = crw < p;
+  double crow[NCR];                                        // (zero for rows >= p and beyond column PV - 1)
   {
     double creg[PC];
 #pragma unroll
@@ -127,7 +134,11 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
     for (int k = 0; k < PC; ++k) if (k < p && s < PV) Q[k * LD + s] = creg[k];
     WSYNC();
 #pragma unroll
-    for (int k = 0; k < PV; k += 2) { const double2a v = lds2(Q + (has_r ? s : 0) * LD + k); crow[k] = has_r ? v.x : 0.0; crow[k + 1] = has_r ? v.y : 0.0; }
+    for (int k = 0; k < NCR; k += 2) {
+      const bool in = c_on && (c0 + k < PV);
+      const double2a v = lds2(Q + (in ? crw * LD + c0 + k : 0));
+      crow[k] = in ? v.x : 0.0; crow[k + 1] = in ? v.y : 0.0;
+    }
     WSYNC();
     if (m > 0) {
       // ---- H = A'A, g = -A'b (QP_Wrapper.py:17-18): A staged MCH rows at a time, dense (row stride n), over the matrix blocks
@@ -232,14 +243,14 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
     WSYNC();
     double gs = 0.0, cs = 0.0;
 #pragma unroll
-    for (int k = 0; k < PV; k += 2) {
-      const double2a f2 = lds2(yv + k);
-      gs = fma(h[k], f2.x, fma(h[k + 1], f2.y, gs)); cs = fma(crow[k], f2.x, fma(crow[k + 1], f2.y, cs));
-    }
+    for (int k = 0; k < PV; k += 2) { const double2a f2 = lds2(yv + k); gs = fma(h[k], f2.x, fma(h[k + 1], f2.y, gs)); }
+#pragma unroll
+    for (int k = 0; k < NCR; k += 2) { const double2a f2 = lds2(yv + c0 + k); cs = fma(crow[k], f2.x, fma(crow[k + 1], f2.y, cs)); }   // (yv has G = 32 entries: c0 + k < 28)
+    if (HALF) cs = rowpair_sum(cs);
     g += gs;
     if (has_r) { clb -= cs; cub -= cs; }
 #pragma unroll
-    for (int k = 0; k < PV; ++k) crow[k] = ((fixm >> k) & 1u) ? 0.0 : crow[k];
+    for (int k = 0; k < NCR; ++k) crow[k] = ((fixm >> (c0 + k)) & 1u) ? 0.0 : crow[k];
     if (fixb) { g = -fv; lb = -1e30; ub = 1e30; }          // no longer a constraint
   }
   {
@@ -258,9 +269,9 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
   // y ends as row s of J0 = L^-T
   if (PV > 16) {                                           // the rows of C wait in the (free) J block while h, y and the column fill the registers
     WSYNC();
-    if (has_r) {
+    if (HALF || has_r) {
 #pragma unroll
-      for (int k = 0; k < PV; k += 2) sts2(Q + s * LD + k, crow[k], crow[k + 1]);
+      for (int k = 0; k < NCR; k += 2) sts2(Q + s * LD + k, crow[k], crow[k + 1]);
     }
   }
   double y[PV];
@@ -293,7 +304,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
   WSYNC();
   if (PV > 16) {
 #pragma unroll
-    for (int k = 0; k < PV; k += 2) { const double2a v = lds2(Q + (has_r ? s : 0) * LD + k); crow[k] = has_r ? v.x : 0.0; crow[k + 1] = has_r ? v.y : 0.0; }
+    for (int k = 0; k < NCR; k += 2) { const bool in = HALF || has_r; const double2a v = lds2(Q + (in ? s : 0) * LD + k); crow[k] = in ? v.x : 0.0; crow[k + 1] = in ? v.y : 0.0; }
     WSYNC();
   }
   if (s < PV) {
@@ -305,8 +316,9 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
   {
     double c2b = 0.0;
 #pragma unroll
-    for (int k = 0; k < PV; k += 2) { cn2 = fma(crow[k], crow[k], cn2); c2b = fma(crow[k + 1], crow[k + 1], c2b); }
+    for (int k = 0; k < NCR; k += 2) { cn2 = fma(crow[k], crow[k], cn2); c2b = fma(crow[k + 1], crow[k + 1], c2b); }
     cn2 += c2b;
+    if (HALF) cn2 = rowpair_sum(cn2);
   }
   WSYNC();
 
@@ -320,9 +332,9 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
     double d;
     if (__ballot(on && is_row)) {
       WSYNC();
-      if (on && is_row && s == rr_) {
+      if (on && is_row && crw == rr_) {
 #pragma unroll
-        for (int k = 0; k < PV; k += 2) sts2(ev + k, crow[k], crow[k + 1]);
+        for (int k = 0; k < NCR; k += 2) sts2(ev + c0 + k, crow[k], crow[k + 1]);
       }
       WSYNC();
     }
@@ -341,8 +353,8 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
   auto rowval = [&]() -> double {
     double v = 0.0, vb = 0.0;
 #pragma unroll
-    for (int k = 0; k < PV; k += 2) { const double2a x2 = lds2(xv + k); v = fma(crow[k], x2.x, v); vb = fma(crow[k + 1], x2.y, vb); }
-    return v + vb;
+    for (int k = 0; k < NCR; k += 2) { const double2a x2 = lds2(xv + c0 + k); v = fma(crow[k], x2.x, v); vb = fma(crow[k + 1], x2.y, vb); }
+    return HALF ? rowpair_sum(v + vb) : v + vb;
   };
   // r = T d1 on the slots (dv = d staged): row s of T against d over the columns s .. q - 1; the loop runs to the wave's largest working set
   auto t_row_times = [&](const double* const vec) -> double {
@@ -763,9 +775,9 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
         const int rk = on ? (bpermi(a_code, rbase + k) & 255) - n : 0;
         const double uk = bperm(us, rbase + k);
         WSYNC();
-        if (on && s == rk) {
+        if (on && crw == rk) {
 #pragma unroll
-          for (int i = 0; i < PV; i += 2) sts2(ev + i, crow[i], crow[i + 1]);
+          for (int i = 0; i < NCR; i += 2) sts2(ev + c0 + i, crow[i], crow[i + 1]);
         }
         WSYNC();
         if (on) r1 = fma(uk, ev[sv], r1);
@@ -815,19 +827,28 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
 #define QPP_PART -1
 #endif
 #if QPP_PART == 0
-extern template __global__ void wbc_qp_packed_kernel<16, 16, true>(const QpArgs);
-extern template __global__ void wbc_qp_packed_kernel<32, NV, true>(const QpArgs);
+extern template __global__ void wbc_qp_packed_kernel<16, 16, true, false>(const QpArgs);
+extern template __global__ void wbc_qp_packed_kernel<32, NV, true, false>(const QpArgs);
+extern template __global__ void wbc_qp_packed_kernel<32, NV, false, true>(const QpArgs);
+extern template __global__ void wbc_qp_packed_kernel<32, NV, true, true>(const QpArgs);
 #elif QPP_PART == 1
-template __global__ void wbc_qp_packed_kernel<16, 16, true>(const QpArgs);
-template __global__ void wbc_qp_packed_kernel<32, NV, true>(const QpArgs);
+template __global__ void wbc_qp_packed_kernel<16, 16, true, false>(const QpArgs);
+template __global__ void wbc_qp_packed_kernel<32, NV, true, false>(const QpArgs);
+#elif QPP_PART == 2
+template __global__ void wbc_qp_packed_kernel<32, NV, false, true>(const QpArgs);
+template __global__ void wbc_qp_packed_kernel<32, NV, true, true>(const QpArgs);
 #endif
 #if QPP_PART <= 0
 template <int G, int PV>
 static int launch_qpp(const QpArgs& a, hipStream_t s) {
   typedef QppLayout<G, PV> L;
   const int grid = (a.B + L::NQ - 1) / L::NQ;
-  if (a.ws_in || a.ws_out) hipLaunchKernelGGL((wbc_qp_packed_kernel<G, PV, true>), dim3(grid), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((wbc_qp_packed_kernel<G, PV, false>), dim3(grid), dim3(64), 0, s, a);
+  const bool warm = a.ws_in || a.ws_out;
+  if (G == 32 && a.p <= 16) {              // rows of C split over the two halves of a problem
+    if (warm) hipLaunchKernelGGL((wbc_qp_packed_kernel<G, PV, true, (G == 32)>), dim3(grid), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((wbc_qp_packed_kernel<G, PV, false, (G == 32)>), dim3(grid), dim3(64), 0, s, a);
+  } else if (warm) hipLaunchKernelGGL((wbc_qp_packed_kernel<G, PV, true, false>), dim3(grid), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((wbc_qp_packed_kernel<G, PV, false, false>), dim3(grid), dim3(64), 0, s, a);
   return check_launch("qp packed");
 }
 
