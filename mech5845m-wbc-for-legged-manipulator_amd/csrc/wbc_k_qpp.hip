@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
   };
   // with d staged (dv = d, yv = d restricted to the slots >= q): z = J2 d2, r = T d1, and the add step's dq = d_q; row s of J stays in registers
   // for the add step
-  double jr[PV];
+  double jr[PV], v2r[HALF ? PV : 2];               // (HALF: the staged d2 stays too)
   struct Zr { double z, rv, dq, jq; };
   auto products = [&](const bool want_r) -> Zr {
     Zr o;
@@ -429,6 +429,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
     for (int k = 0; k < PV; k += 2) {
       const double2a j2 = lds2(J + sv * LD + k); const double2a v2 = lds2(yv + k);
       jr[k] = j2.x; jr[k + 1] = j2.y;
+      if (HALF) { v2r[HALF ? k : 0] = v2.x; v2r[HALF ? k + 1 : 0] = v2.y; }
       z = fma(j2.x, v2.x, z); zb = fma(j2.y, v2.y, zb);
     }
     z += zb;
@@ -450,7 +451,11 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
     if (add && has_b && vv > 0.0) {
       // J2 <- J2 - w v', v = d2 - delta e_q: the sweep runs on d2 alone (yv = d for k >= q, else 0), entry q is then stored with its own term
 #pragma unroll
-      for (int k = 0; k < PV; k += 2) { const double2a v2 = lds2(yv + k); sts2(J + s * LD + k, fma(-w, v2.x, jr[k]), fma(-w, v2.y, jr[k + 1])); }
+      for (int k = 0; k < PV; k += 2) {
+        double2a v2;
+        if (HALF) { v2.x = v2r[HALF ? k : 0]; v2.y = v2r[HALF ? k + 1 : 0]; } else v2 = lds2(yv + k);
+        sts2(J + s * LD + k, fma(-w, v2.x, jr[k]), fma(-w, v2.y, jr[k + 1]));
+      }
       J[s * LD + q] = fma(-w, zr.dq - delta, jq);
     }
     if (add) {
