@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Soak of the stand-alone QP entry points on the packed kernel (csrc/wbc_k_qpp.hip) against the oracle: random problems over the shapes the boundary
+sees — well- and ill-conditioned least-squares data, boxes, two-sided rows, equality rows, fixed variables, a share of infeasible / not positive
+definite / NaN problems — cold and hot-started with a perturbed problem's working set. Per shape: status agreement, iteration-count agreement,
+worst |x - x_oracle| over the solved problems. python tools/soak_qp.py [problems per shape] [seeds]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "mech5845m-wbc-for-legged-manipulator_amd")]
+import numpy as np, oracle
+from wbc_batch import WbcBatch
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+threads = min(32, len(os.sched_getaffinity(0)))
+bt = WbcBatch([], B)
+worst = 0.0
+total = 0
+for seed in range(seeds):
+    rng = np.random.default_rng(1000 + seed)
+    for (m, n, p) in ((32, 26, 16), (40, 26, 24), (20, 14, 9), (12, 8, 4), (60, 20, 12), (9, 3, 2), (96, 26, 0)):
+        ill = m - n < n
+        if ill:   # a few O(1) rows over posture-like rows of 3e-5: cond(H) ~ 1e9, the refinement's case
+            k = max(1, min(m - n, n // 2))
+            A = np.concatenate([rng.normal(size=(B, k, n)), np.broadcast_to(3e-5 * np.eye(n), (B, n, n)), np.zeros((B, m - k - n, n))], axis=1)
+            b = np.concatenate([rng.normal(size=(B, k)), 3e-5 * rng.normal(size=(B, n)), np.zeros((B, m - k - n))], axis=1)
+        else:
+            A = rng.normal(size=(B, m, n)); b = rng.normal(size=(B, m)) * 2
+        C = rng.normal(size=(B, p, n)) if p else None
+        lb, ub = -rng.uniform(0.05, 1.5, (B, n)), rng.uniform(0.05, 1.5, (B, n))
+        lb[:, -1] = ub[:, -1] = 0.02
+        cl, cu = (-rng.uniform(0.05, 1.0, (B, p)), rng.uniform(0.05, 1.0, (B, p))) if p else (None, None)
+        kinds = rng.integers(0, 40, B)
+        if p:
+            cl[:, 0] = cu[:, 0] = 0.03
+            cl[kinds == 1, p - 1], cu[kinds == 1, p - 1] = 40.0, 50.0          # infeasible
+        A[kinds == 2] = 0.0                                                   # not positive definite
+        ub[kinds == 3, 0] = np.nan
+        xr, sr, ir = oracle.qp_solve_ls(A, b, C, lb, ub, cl, cu, nthreads=threads)
+        ok = sr == 0
+        x, st, it, ws = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu, want_working_set=True)
+        e0 = np.abs(x - xr)[ok].max()
+        _, _, _, wsp = bt.qp_solve_ls(A, b + 0.05 * rng.normal(size=b.shape), C, lb, ub, cl, cu, want_working_set=True)
+        x1, st1, it1, ws1 = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu, working_set=wsp, want_working_set=True)
+        e1 = np.abs(x1 - xr)[ok].max()
+        print("seed %d (m, n, p) = (%2d, %2d, %2d) %s path %d: optimal %.4f  status agree cold %.6f hot %.6f  iters equal (cold) %.6f  worst |x - oracle| cold %.2e hot %.2e  same final set hot / cold %.4f"
+              % (seed, m, n, p, "ill " if ill else "well", bt.stat("last_qp_path"), ok.mean(), (st == sr).mean(), (st1 == sr).mean(), (it == ir)[ok].mean(), e0, e1, (ws1 == ws)[ok].all(axis=1).mean()), flush=True)
+        assert (st == sr).all() and (st1 == sr).all() and (x[~ok] == 0).all() and (x1[~ok] == 0).all()
+        worst = max(worst, e0, e1); total += 2 * B
+print("problems solved on the device: %d, status identical on every one; worst |x - oracle| over all optimal problems: %.3e" % (total, worst))
+bt.close()
