@@ -1662,7 +1662,7 @@ def test_qp_entry_points_take_and_return_working_sets():
     bt.close()
 
 
-@pytest.mark.parametrize("m,n,p,lanes", [(32, 26, 16, 2), (20, 14, 9, 4)])
+@pytest.mark.parametrize("m,n,p,lanes", [(32, 26, 16, 2), (20, 14, 9, 4), (36, 26, 20, 2)])      # (split rows of C; four per wavefront; whole rows: p > 16)
 def test_qp_hot_start_on_the_packed_kernel(m, n, p, lanes):
     """QP.solveQPHotstart (QP_Wrapper.py:55-73) on the packed kernel's WARM variant (csrc/wbc_k_qpp.hip): seeded with its own final set the problem
     comes back with the same answer, the same set and no more working-set changes than cold; with the set of a perturbed problem ("previous tick")
