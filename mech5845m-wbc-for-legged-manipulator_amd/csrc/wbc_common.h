@@ -475,33 +475,30 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
     if (rl >= 0 && rl < p) S.yv[rl & 31] = sqn;         // |C_r|^2 (p <= 24 < 32)
   }
   WSYNC();
-#pragma unroll 1
+#pragma unroll
   for (int j = 0; j < NM; ++j) {
-    // (skipping the FMAs of the padded steps j >= n — their column of L is e_j — and only rotating the registers measured 2 % SLOWER:
-    //  the 2 x 15 register moves cost more than the LDS round trip they avoid; same-box A/B, tools/ab_bench.sh)
-    const double pj = rdl(h[0], j);
+    const double pj = rdl(h[j], j);
     pmin = (pj > 0.0) ? fmin(pmin, pj) : -1.0;            // (a NaN pivot must fail the test below; fmin would drop it)
     const double rinv = rsqrt(pj);
-    const double l = h[0] * rinv;
+    const double l = h[j] * rinv;
+    WSYNC();
     if (lane < NM) S.cl[lane] = l;
     WSYNC();
-    const double* cj = S.cl + j;
     double cm[NM];
 #pragma unroll
-    for (int r = 1; r < NM; ++r) cm[r] = cj[r];
+    for (int k = (j + 1) & ~1; k < NM; k += 2) { const double2a v = lds2(S.cl + k); cm[k] = v.x; cm[k + 1] = v.y; }
+    const double yk = y[j] * rinv;
 #pragma unroll
-    for (int r = 1; r < NM; ++r) h[r - 1] = fma(-l, cm[r], h[r]);
-    const double yk = y[0] * rinv;
+    for (int k = j + 1; k < NM; ++k) { h[k] = fma(-l, cm[k], h[k]); y[k] = fma(-cm[k], yk, y[k]); }
+    y[j] = yk;
+    // every value of the step is pinned to a register here: left free, the scheduler spreads the unrolled steps over each other and the
+    // allocator pays with hundreds of spills
 #pragma unroll
-    for (int r = 1; r < NM; ++r) y[r - 1] = fma(-cm[r], yk, y[r]);
-    y[NM - 1] = yk;
-    LDS_THEN_VALU(NM - 1, 2 * NM - 1);
-    h[NM - 1] = 0.0;
-    WSYNC();
+    for (int k = j + 1; k < NM; ++k) asm volatile("" : "+v"(h[k]), "+v"(y[k]));
   }
   STAMP(ts, T_CHOL);
   if (!(pmin > 0.0)) { res.status = WBC_QP_NUMERICAL; return res; }
-  if (dbg_stop == 6) { res.x = y[0] + h[0]; return res; }      // ablation timing: fused Cholesky / substitution sweep done
+  if (dbg_stop == 6) { res.x = y[0] + h[NM - 1]; return res; }      // ablation timing: fused Cholesky / substitution sweep done
 
   // ---- constraint bookkeeping
   const bool has_b = lane < n, has_r = lane < p;
