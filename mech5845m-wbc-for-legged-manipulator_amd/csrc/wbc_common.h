@@ -446,11 +446,10 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
     hmax = -wmin((lane < NM && lane < 32) ? -hd : 0.0);
   }
 
-  // ---- Cholesky H = L L', right-looking, ROTATING registers: at step j register r holds column j + r of the row,
-  // so the body is the same for every j (a real loop, ~100 instructions) and the row never leaves the VGPRs.
-  // Column j is broadcast through S.cl (zero above entry NM - 1); L itself is never stored (the substitutions ride along).
+  // ---- Cholesky H = L L', right-looking, the row in registers; column j is broadcast through S.cl; L itself is never stored (the
+  // substitutions ride along).
   double pmin = 1.0;
-  // Forward substitutions L y = rhs, one right-hand side per lane, ROTATING registers (same trick):
+  // Forward substitutions L y = rhs, one right-hand side per lane:
   //   lane c < NM        : e_c        -> y = column c of L^-1 = row c of J0 = L^-T
   //   lane NM + r, r < p : C_r'       -> y = L^-1 C_r'   (column of B = J0' N for constraint row r)
   //   lane NM + p        : g          -> y = L^-1 g
@@ -492,7 +491,7 @@ __device__ __forceinline__ QpResult qp_core(SM& S, const double g_in, const doub
     for (int k = j + 1; k < NM; ++k) { h[k] = fma(-l, cm[k], h[k]); y[k] = fma(-cm[k], yk, y[k]); }
     y[j] = yk;
     // every value of the step is pinned to a register here: left free, the scheduler spreads the unrolled steps over each other and the
-    // allocator pays with hundreds of spills
+    // allocator pays with 600-1300 spilled VGPRs (the packed kernels' sweeps, the same code shape, allocate cleanly without)
 #pragma unroll
     for (int k = j + 1; k < NM; ++k) asm volatile("" : "+v"(h[k]), "+v"(y[k]));
   }

@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(64, 2) wbc_tick_kernel(const KernelArgs A, con
 #else
   const unsigned long long t_entry = 0;
 #endif
-  S.cl[lane] = 0.0;                            // zero padding the rotating loops rely on (never written above entry 25)
+  S.cl[lane] = 0.0;                            // zero padding (never written above entry 25)
   const bool has2 = A.in.trunk_target || A.in.prev_trunk_target || A.in.trunk_ref_euler || A.in.trunk_prev_rot ||
                     A.in.com_target || A.in.com_target_vel;
   const bool has3 = A.in.ee_ref_rot != nullptr;

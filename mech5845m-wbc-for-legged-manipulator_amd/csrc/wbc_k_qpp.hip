@@ -9,7 +9,7 @@
 //              back: the constraint a step works on broadcasts its row through a staging vector;
 //   H = A'A    on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), operands straight from the staged A; g = -A'b beside it;
 //   presolve   variables with lb == ub leave the problem (qp_core's rule: H_kk = 1, g_k = -value; their columns of C are zeroed);
-//   factor     Cholesky fused with L y = e_s on rotating registers, the pivot column broadcast through a per-problem LDS vector -> J = L^-T;
+//   factor     Cholesky fused with L y = e_s, unrolled on fixed registers, the pivot column broadcast through a per-problem LDS vector -> J = L^-T;
 //   equalities rows with Clb == Cub enter first, in index order, by the add step of the dual method (Householder on J2; never droppable); the
 //              right-hand sides ride along as R'y1 = b_e and x_eq = J1 y1 - J2 J2'g comes from the factors (qp_core's formula);
 //   dual loop  Goldfarb-Idnani with per-problem state — the loop of the packed tick kernels (wbc_k_sim3p.hip) on general rows: reductions are
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
   const double hmax = -gmin<G>(s < PV ? -hd : 0.0);
 
   // ---- Cholesky H = L L' fused with the substitution L y = e_s, fully unrolled: step j broadcasts the raw column j of every row through cl and
-  // touches the entries k > j only (half the multiply-adds and a quarter of the LDS reads of the rotating-register loop the other kernels keep);
+  // touches the entries k > j only (half the multiply-adds and a quarter of the LDS reads of a rotating-register loop; qp_core has the same form now);
   // y ends as row s of J0 = L^-T
   if (PV > 16) {                                           // the rows of C wait in the (free) J block while h, y and the column fill the registers
     WSYNC();

@@ -734,7 +734,7 @@ __global__ void __launch_bounds__(64, SIM3P_WAVES) wbc_tick_sim3p_kernel(const K
     const unsigned long long nb = __ballot(status != WBC_QP_OPTIMAL);
     if ((nb >> rbase) & 0xFFFFull) { status = WBC_QP_NUMERICAL; live = false; }
   }
-  // ---- Cholesky H' = L L' fused with the substitution L y = e_s (rotating registers; column broadcast through V.cl)
+  // ---- Cholesky H' = L L' fused with the substitution L y = e_s (two columns per trip on fixed registers; columns broadcast through V.cl / V.yv)
   WSYNC();
   V.cl[s] = 0.0; V.cl[16 + s] = 0.0;        // (the row bounds were staged there)
   V.yv[s] = 0.0; V.tv[s] = 0.0;             // second column vector of the blocked sweep: yv | tv, 32 contiguous entries, zero tail
