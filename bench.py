@@ -261,6 +261,39 @@ class GpuEngine:
                                                         "wbc_tick_boxp_kernel (packed: four instances per wavefront)" if path == 4 else
                                                         ("wbc_tick_kernel<MODE_TICK, ORTH>" if bt.stat("last_orth") else "wbc_tick_kernel<MODE_TICK>")}
             bt.close()
+        # the reference's own plug-in boundary, QP(A, b, C, lb, ub, Clb, Cub).solveQP() = wbc_qp_solve_ls (QP_Wrapper.py:10-53), on the headline
+        # workload's OWN problems (the first 32768 instances' A, b, C, bounds as wbc_assemble forms them on the device) — the packed QP kernel
+        Bq = min(32768, int(self.dev_in["q"].shape[0]))
+        bq = WbcBatch(self.model, Bq, device_id=self.dev.index)
+        bq.configure(self.cfg)
+        sub = {k: v[:Bq] for k, v in self.dev_in.items()}
+        asm = bq.assemble(sub, DT)
+        qp_in = [asm[k] if t.is_tensor(asm[k]) else t.from_numpy(np.ascontiguousarray(asm[k])).to(self.dev) for k in ("A", "b", "C", "lb", "ub", "Clb", "Cub")]
+        for _ in range(3):
+            res = bq.qp_solve_ls(*qp_in)
+        self.sync()
+        ev0, ev1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(10):
+            res = bq.qp_solve_ls(*qp_in)
+        ev1.record()
+        self.sync()
+        ms = ev0.elapsed_time(ev1) / 10
+        acc = {"gated": False}
+        xq, sq = (res[0].cpu().numpy(), res[1].cpu().numpy()) if t.is_tensor(res[0]) else (res[0], res[1])
+        if check:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle
+            nchk = min(Bq, 2048)
+            hst = [v[:nchk].cpu().numpy() for v in qp_in]
+            xr, sr, _ = oracle.qp_solve_ls(*hst, nthreads=min(32, len(os.sched_getaffinity(0))))
+            okc = (sr == 0) & (sq[:nchk] == 0)
+            acc = {"gated": True, "instances_checked": int(nchk), "status_agree_frac": float((sr == sq[:nchk]).mean()),
+                   "qdot_max_abs_err_vs_cpu": float(np.abs(xq[:nchk] - xr)[okc].max()) if okc.any() else None}
+        out["qp_boundary_B%d" % Bq] = {"qps_per_s": Bq / ms * 1e3, "ms_per_step": ms, "m_n_p": [int(qp_in[0].shape[1]), int(qp_in[0].shape[2]), int(qp_in[2].shape[1])],
+                                       "optimal_frac": float((sq == 0).mean()), "accuracy": acc, "problems_per_wavefront": bq.stat("last_qp_path"),
+                                       "kernel_path": "wbc_qp_packed_kernel (stand-alone QP: wbc_qp_solve_ls on the headline workload's own A, b, C, bounds)"}
+        bq.close()
         return out
 
     def close(self):
