@@ -734,9 +734,6 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
       const double val_r = bperm(vrow, rbase + rr_), val_b = bperm(x, rbase + iv);
       const double val = srow ? val_r : val_b;
       const double r2 = slot ? sgn * (bnd - val) : 0.0;
-#ifdef WBC_ABLATE
-      if (A.dbg_stop >= 410 && A.dbg_stop <= 414) { if (live && has_b) A.x[b * n + s] = A.dbg_stop == 410 ? r2 : A.dbg_stop == 411 ? val : A.dbg_stop == 412 ? bnd : A.dbg_stop == 413 ? (double)a_code : (double)q; return; }
-#endif
       WSYNC();
       tv[s] = gneg; dv[s] = r2;
       WSYNC();
@@ -752,9 +749,6 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
         const double t_ = TP[tri(s) + (i <= s ? i : 0)];
         dy1 = fma((slot && i <= s) ? t_ : 0.0, dv[i], dy1);
       }
-#ifdef WBC_ABLATE
-      if (A.dbg_stop == 406 || A.dbg_stop == 409) dy1 = 0.0;
-#endif
       WSYNC();
       yv[s] = slot ? w : 0.0;
       WSYNC();
@@ -766,14 +760,8 @@ __global__ void __launch_bounds__(64, 2) wbc_qp_packed_kernel(const QpArgs A) {
       if (slot && !srow) dv[iv] = us;
       WSYNC();
       double r1 = gneg + dv[s];
-#ifdef WBC_ABLATE
-      if (A.dbg_stop == 408 || A.dbg_stop == 409) r1 = gneg;
-#endif
 #pragma unroll 1
       for (int k = 0; k < PV; ++k) {
-#ifdef WBC_ABLATE
-        if (A.dbg_stop == 407 || A.dbg_stop == 409) break;
-#endif
         const bool on = k < q && ((bpermi(a_code, rbase + k) & 255) >= n);
         if (!__ballot(k < q)) break;
         if (!__ballot(on)) continue;
