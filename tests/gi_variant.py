@@ -734,3 +734,227 @@ def solve_v4(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, seeds=(), max_i
                 break
             drop(l)
             s_ip = (-1.0 if side else 1.0) * value(ip, x) - b_ip
+
+
+def solve_v5(H, g, C=None, lb=None, ub=None, Clb=None, Cub=None, seeds=(), max_iter=None, far=0.25):
+    """The PACKED STAND-ALONE QP kernel's flow (csrc/wbc_k_qpp.hip wbc_qp_packed_kernel) in plain numpy — a general problem, cold or
+    hot-started:
+      0. variables with lb == ub are presolved out (H_kk = 1, g_k = -value; their columns leave H and C, the value moves into g and the row bounds);
+      1. equality rows (Clb == Cub) enter first, in index order, through the dual method's ADD step alone (never droppable); their right-hand sides
+         ride along as R'y1 = b_e (y1_q = (b_e - d1'y1) / delta), a dependent row is skipped if consistent and is INFEASIBLE otherwise;
+         x_eq = J1 y1 - J2 J2'g comes from the factors;
+      2. hot start: a carried inequality is taken (add step, no primal step) only if x_eq violates it or comes within far * max(1, |x_eq|_inf) of it;
+         x and u are then read off the factors: b = the slots' right-hand sides, y1 = T'b, x = J1 y1 - J2 J2'g, u = T (y1 + J1'g);
+         while a seeded multiplier is negative its slot is dropped and x, u are read off again;
+      3. the dual iterations; only the inequality slots (>= qe) can block.
+    T = R^-1 covers every slot (the kernel keeps it packed). Returns (x, status, iters, final working set [(constraint, side)] of INEQUALITIES)."""
+    n = len(g)
+    p = 0 if C is None else C.shape[0]
+    ncon = n + p
+    H = np.array(H, dtype=float)
+    g = np.array(g, dtype=float)
+    C = np.zeros((0, n)) if C is None else np.array(C, dtype=float)
+    lo_b = np.full(n, -1e30) if lb is None else np.array(lb, dtype=float)
+    hi_b = np.full(n, 1e30) if ub is None else np.array(ub, dtype=float)
+    lo_r = np.zeros(0) if Clb is None else np.array(Clb, dtype=float)
+    hi_r = np.zeros(0) if Cub is None else np.array(Cub, dtype=float)
+    if np.isnan(lo_b).any() or np.isnan(hi_b).any() or np.isnan(lo_r).any() or np.isnan(hi_r).any():
+        return np.zeros(n), 3, 0, []
+    # ---- 0: presolve
+    fix = (lo_b == hi_b) & (np.abs(lo_b) < INF)
+    iters = int(fix.sum())
+    if fix.any():
+        fv = np.where(fix, lo_b, 0.0)
+        g = g + H @ fv
+        cs = C @ fv
+        lo_r, hi_r = lo_r - cs, hi_r - cs
+        H[fix, :] = 0.0
+        H[:, fix] = 0.0
+        C[:, fix] = 0.0
+        for k in np.nonzero(fix)[0]:
+            H[k, k] = 1.0
+            g[k] = -fv[k]
+        lo_b, hi_b = np.where(fix, -1e30, lo_b), np.where(fix, 1e30, hi_b)
+
+    def lo(c):
+        return lo_b[c] if c < n else lo_r[c - n]
+
+    def hi(c):
+        return hi_b[c] if c < n else hi_r[c - n]
+
+    def normal(c, side):
+        sgn = -1.0 if side else 1.0
+        if c < n:
+            e = np.zeros(n)
+            e[c] = sgn
+            return e
+        return sgn * C[c - n]
+
+    def value(c, x):
+        return x[c] if c < n else C[c - n] @ x
+
+    try:
+        L = np.linalg.cholesky(H)
+    except np.linalg.LinAlgError:
+        return np.zeros(n), 3, 0, []
+    J = np.linalg.inv(L).T.copy()
+    jf2 = (J * J).sum()
+    T = np.zeros((n, n))
+    u = np.zeros(n + 1)
+    act, active = [], np.zeros(ncon, bool)
+    q = 0
+    max_iter = max_iter or 10 * (n + p) + 20
+
+    def add(c, side, d, zn, z, r, u_new):
+        nonlocal q
+        dq = d[q]
+        delta = -np.sqrt(zn) if dq >= 0 else np.sqrt(zn)
+        v = d[q:].copy()
+        v[0] -= delta
+        vv = 2.0 * (zn - delta * dq)
+        if vv > 0:
+            w = z - delta * J[:, q]
+            J[:, q:] -= np.outer(w, (2.0 / vv) * v)
+        T[:q, q] = -r / delta
+        T[q, q] = 1.0 / delta
+        u[q] = u_new
+        act.append((c, side))
+        active[c] = True
+        q += 1
+        return delta
+
+    def drop(l):
+        nonlocal q
+        trow = T[l, l:q].copy()
+        active[act[l][0]] = False
+        del act[l]
+        u[l:q - 1] = u[l + 1:q].copy()
+        u[q - 1] = 0.0
+        Tt = np.delete(T[:q, :q], l, axis=0)
+        h = trow[0]
+        for k in range(l, q - 1):
+            a_, b_ = h, trow[k - l + 1]
+            rho = np.hypot(a_, b_)
+            c_, s_ = (b_ / rho, -a_ / rho) if rho > 0 else (1.0, 0.0)
+            h = rho
+            ck, ck1 = Tt[:, k].copy(), Tt[:, k + 1].copy()
+            Tt[:, k], Tt[:, k + 1] = c_ * ck + s_ * ck1, -s_ * ck + c_ * ck1
+            jk, jk1 = J[:, k].copy(), J[:, k + 1].copy()
+            J[:, k], J[:, k + 1] = c_ * jk + s_ * jk1, -s_ * jk + c_ * jk1
+        T[:, :] = 0
+        T[:q - 1, :q - 1] = np.triu(Tt[:, :q - 1])
+        q -= 1
+
+    # ---- 1: equality rows
+    eq_r = [(lo_r[r_] == hi_r[r_]) and abs(lo_r[r_]) < INF for r_ in range(p)]
+    y1 = np.zeros(n)
+    for r_ in range(p):
+        if not eq_r[r_]:
+            continue
+        iters += 1
+        npv = normal(n + r_, 0)
+        d = J.T @ npv
+        zn = d[q:] @ d[q:]
+        dy = d[:q] @ y1[:q]
+        b_e = lo_r[r_]
+        if zn > 100.0 * n * EPS2 * jf2 * (npv @ npv):
+            qold = q
+            delta = add(n + r_, 0, d, zn, J[:, q:] @ d[q:], T[:q, :q] @ d[:q], 0.0)
+            y1[qold] = (b_e - dy) / delta
+        elif not abs(dy - b_e) <= 1e-9 * max(1.0, abs(b_e)):
+            return np.zeros(n), 2, iters, []
+    qe = q
+    x = J[:, :q] @ y1[:q] - J[:, q:] @ (J[:, q:].T @ g)
+
+    def rebuild():
+        nonlocal x
+        b = np.array([lo(c) if sd == 0 else -hi(c) for c, sd in act])
+        y = T[:q, :q].T @ b
+        jg = J.T @ g
+        x = J[:, :q] @ y - J[:, q:] @ jg[q:]
+        u[:q] = T[:q, :q] @ (y + jg[:q])
+        u[:qe] = 0.0
+
+    # ---- 2: hot start
+    if len(seeds):
+        near = far * max(1.0, np.abs(x).max())
+        seen = {}
+        for c, side in seeds:
+            if 0 <= c < ncon:
+                seen[c] = None if (c in seen and seen[c] != side) else side
+        x_eq = x.copy()
+        seeded = False
+        for c in sorted(seen):
+            side = seen[c]
+            if side is None or (c >= n and eq_r[c - n]):
+                continue
+            if not ((side == 0 and lo(c) > -INF) or (side == 1 and hi(c) < INF)):
+                continue
+            slack = value(c, x_eq) - lo(c) if side == 0 else hi(c) - value(c, x_eq)
+            if not slack <= near:
+                continue
+            npv = normal(c, side)
+            d = J.T @ npv
+            zn = d[q:] @ d[q:]
+            if not zn > 100.0 * n * EPS2 * jf2 * (npv @ npv):
+                continue
+            iters += 1
+            add(c, side, d, zn, J[:, q:] @ d[q:], T[:q, :q] @ d[:q], 0.0)
+            seeded = True
+        if seeded:
+            rebuild()
+            while q > qe and u[qe:q].min() < 0.0:
+                iters += 1
+                if iters > max_iter:
+                    return np.zeros(n), 1, iters, []
+                drop(qe + int(np.argmin(u[qe:q])))
+                rebuild()
+    # ---- 3: dual iterations
+    while True:
+        worst, ip = 0.0, -1
+        for c in range(ncon):
+            if active[c] or (c >= n and eq_r[c - n]):
+                continue
+            v = value(c, x)
+            if lo(c) > -INF:
+                s = v - lo(c)
+                if s < -1e-9 * max(1.0, abs(lo(c))) and s < worst:
+                    worst, ip, side, b_ip = s, c, 0, lo(c)
+            if hi(c) < INF:
+                s = hi(c) - v
+                if s < -1e-9 * max(1.0, abs(hi(c))) and s < worst:
+                    worst, ip, side, b_ip = s, c, 1, -hi(c)
+        if ip < 0:
+            if not np.isfinite(x).all():
+                return np.zeros(n), 3, iters, []
+            return x, 0, iters, [a for a in act[qe:]]
+        s_ip = worst
+        npv = normal(ip, side)
+        np2 = npv @ npv
+        u_ip = 0.0
+        while True:
+            iters += 1
+            if iters > max_iter:
+                return np.zeros(n), 1, iters, []
+            d = J.T @ npv
+            zn = d[q:] @ d[q:]
+            z = J[:, q:] @ d[q:]
+            r = T[:q, :q] @ d[:q]
+            have_step = zn > 100.0 * n * EPS2 * jf2 * np2
+            t1, l = np.inf, -1
+            for k in range(qe, q):
+                if r[k] > 0 and u[k] / r[k] < t1:
+                    t1, l = u[k] / r[k], k
+            t2 = -s_ip / zn if have_step else np.inf
+            t = min(t1, t2)
+            if not np.isfinite(t):
+                return np.zeros(n), 2, iters, []
+            if have_step:
+                x = x + t * z
+            u[:q] -= t * r
+            u_ip += t
+            if have_step and t == t2:
+                add(ip, side, d, zn, z, r, u_ip)
+                break
+            drop(l)
+            s_ip = (-1.0 if side else 1.0) * value(ip, x) - b_ip

@@ -307,6 +307,60 @@ def test_warm_started_variant_reaches_the_same_optimum():
     print("working-set changes: cold %d, seeded with the own set %d, with the previous tick's set %+d vs cold" % (cold_it, warm_it, warm_prev_it))
 
 
+def test_packed_qp_kernel_flow_restated_in_numpy():
+    """tests/gi_variant.py solve_v5 — the packed stand-alone QP kernel's flow (csrc/wbc_k_qpp.hip): fixed variables presolved,
+    equality rows through the add step with R'y1 = b_e riding along and x_eq from the factors, seeds by add steps with x / u read off the factors and
+    restoration by drop + rebuild, dual iterations in which only inequality slots block — against the oracle's textbook loop: same status, same
+    iteration count cold, same optimum cold and hot-started (own set: nothing but one step per seed; a perturbed problem's set; garbage; the opposite
+    sides), contradictory equality rows infeasible, a redundant one skipped."""
+    rng = np.random.default_rng(505)
+    n, p = 12, 9
+    cold_it = own_it = 0
+    for trial in range(60):
+        A = rng.normal(size=(n + 3, n))
+        H = A.T @ A + 1e-3 * np.eye(n)
+        g = rng.normal(size=n) * 4
+        C = rng.normal(size=(p, n))
+        lb, ub = -rng.uniform(0.02, 0.6, n), rng.uniform(0.02, 0.6, n)
+        lb[3] = ub[3] = 0.04                                      # a fixed variable with a non-zero value
+        cl, cu = -rng.uniform(0.02, 0.6, p), rng.uniform(0.02, 0.6, p)
+        cl[1] = cu[1] = 0.05                                      # an equality row
+        kind = trial % 6
+        if kind == 1:
+            C[4] = C[1]; cl[4] = cu[4] = -0.2                     # contradicts row 1: infeasible
+        if kind == 2:
+            C[4] = 3.0 * C[1]; cl[4] = cu[4] = 0.15               # redundant with row 1: skipped
+        if kind == 3:
+            cl[6], cu[6] = 30.0, 40.0                             # out of the box's reach: infeasible through the dual iterations
+        xr, sr, ir = oracle.qp_solve(H[None], g[None], C[None], lb[None], ub[None], cl[None], cu[None])
+        xr, sr, ir = xr[0], int(sr[0]), int(ir[0])
+        x0, s0, it0, ws0 = gi_variant.solve_v5(H, g, C, lb, ub, cl, cu)
+        assert s0 == sr, (trial, kind, s0, sr)
+        if sr != 0:
+            assert kind in (1, 3) and (x0 == 0).all()
+            continue
+        assert np.abs(x0 - xr).max() < 1e-9 and it0 == ir, (trial, it0, ir)
+        assert all(c != 3 and c != n + 1 for c, _ in ws0)         # neither the fixed variable nor the equality row is carried
+        cold_it += it0
+        x1, s1, it1, ws1 = gi_variant.solve_v5(H, g, C, lb, ub, cl, cu, seeds=ws0)
+        assert s1 == 0 and np.abs(x1 - xr).max() < 1e-9 and sorted(ws1) == sorted(ws0)
+        x1n, s1n, it1n, _ = gi_variant.solve_v5(H, g, C, lb, ub, cl, cu, seeds=ws0, far=np.inf)
+        n_eq = 2 if kind == 2 else 1                              # (the redundant row still counts as a working-set change)
+        assert s1n == 0 and np.abs(x1n - xr).max() < 1e-9 and it1n == 1 + n_eq + len(ws0)
+        own_it += it1
+        xp, sp, _, wsp = gi_variant.solve_v5(H, g + rng.normal(size=n) * 0.15, C, lb, ub, cl, cu)
+        if sp == 0:
+            x2, s2, _, ws2 = gi_variant.solve_v5(H, g, C, lb, ub, cl, cu, seeds=wsp)
+            assert s2 == 0 and np.abs(x2 - xr).max() < 1e-9 and sorted(ws2) == sorted(ws0)
+        junk = [(int(rng.integers(-2, n + p + 2)), int(rng.integers(0, 2))) for _ in range(rng.integers(1, 12))]
+        x3, s3, _, _ = gi_variant.solve_v5(H, g, C, lb, ub, cl, cu, seeds=junk)
+        assert s3 == 0 and np.abs(x3 - xr).max() < 1e-8, (trial, junk)
+        x4, s4, _, ws4 = gi_variant.solve_v5(H, g, C, lb, ub, cl, cu, seeds=[(c, 1 - s) for c, s in ws0])
+        assert s4 == 0 and np.abs(x4 - xr).max() < 1e-8 and sorted(ws4) == sorted(ws0)
+    assert cold_it > 0 and own_it <= cold_it
+    print("working-set changes: cold %d, seeded with the own set %d" % (cold_it, own_it))
+
+
 def _householder_null_basis_leg_first(E_base, K_blocks):
     """The device's construction (contact_presolve_orth) restated: Householder QR of E' with the coordinates ordered
     [leg 0, .., leg f-1, base]; every vector carried as (its entries at the CURRENT leg's coordinates, its base part) only — what a
