@@ -325,7 +325,8 @@ int wbc_rollout(WbcBatch* b, int B, const WbcTickIn* in0, double dt, const WbcRo
  *                          honoured; working sets in and out are taken: the WARM variant) run FOUR instances per wavefront
  *                          (wbc_tick_sim3p_kernel: ONE kernel per tick — an instance it cannot reduce, a stance-leg block of rank < 2, is
  *                          redone by its own wave on the general path at the end of the same kernel); 0: one instance per wavefront
- *                          (wbc_tick_sim3_kernel + second pass). Also gates "packed_orth".
+ *                          (wbc_tick_sim3_kernel + second pass). Also gates "packed_orth", "packed_box" and the packed QP kernel of
+ *                          wbc_qp_solve / wbc_qp_solve_ls (0: one problem per wavefront there too).
  *   "packed_orth"      [1] the equality-only task problems (BASELINE configs[1]: EE tasks + CoM task + posture Tikhonov / PREV, foot
  *                          contacts the only constraints, no velocity box) run FOUR instances per wavefront on wbc_tick_orthp_kernel
  *                          (orthonormal contact presolve, unconstrained reduced problem) from 4608 instances on — below that one round
