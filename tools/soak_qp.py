@@ -2,7 +2,9 @@
 """Soak of the stand-alone QP entry points on the packed kernel (csrc/wbc_k_qpp.hip) against the oracle: random problems over the shapes the boundary
 sees — well- and ill-conditioned least-squares data, boxes, two-sided rows, equality rows, fixed variables, a share of infeasible / not positive
 definite / NaN problems — cold and hot-started with a perturbed problem's working set. Per shape: status agreement, iteration-count agreement,
-worst |x - x_oracle| over the solved problems. python tools/soak_qp.py [problems per shape] [seeds]"""
+worst |x - x_oracle| over the solved problems — and, because on the ill-conditioned shapes (curvature 9e-10 along the weak directions) a row violated by
+about the scan's 1e-9 feasibility tolerance is taken by one implementation and not by the other, which moves x by up to 1e-3 along a direction the
+objective does not see: the answer's own constraint violation and its objective excess over the oracle's. python tools/soak_qp.py [problems per shape] [seeds]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "mech5845m-wbc-for-legged-manipulator_amd")]
@@ -41,8 +43,18 @@ for seed in range(seeds):
         _, _, _, wsp = bt.qp_solve_ls(A, b + 0.05 * rng.normal(size=b.shape), C, lb, ub, cl, cu, want_working_set=True)
         x1, st1, it1, ws1 = bt.qp_solve_ls(A, b, C, lb, ub, cl, cu, working_set=wsp, want_working_set=True)
         e1 = np.abs(x1 - xr)[ok].max()
-        print("seed %d (m, n, p) = (%2d, %2d, %2d) %s path %d: optimal %.4f  status agree cold %.6f hot %.6f  iters equal (cold) %.6f  worst |x - oracle| cold %.2e hot %.2e  same final set hot / cold %.4f"
-              % (seed, m, n, p, "ill " if ill else "well", bt.stat("last_qp_path"), ok.mean(), (st == sr).mean(), (st1 == sr).mean(), (it == ir)[ok].mean(), e0, e1, (ws1 == ws)[ok].all(axis=1).mean()), flush=True)
+
+        def quality(xx):     # what the answer is worth by itself: constraint violation and objective excess over the oracle's answer
+            viol = np.maximum(np.nanmax(lb - xx, axis=1), np.nanmax(xx - ub, axis=1))
+            if p:
+                v = np.einsum("bpn,bn->bp", C, xx)
+                viol = np.maximum(viol, np.maximum((cl - v).max(axis=1), (v - cu).max(axis=1)))
+            f = lambda z: 0.5 * ((np.einsum("bmn,bn->bm", A, z) - b) ** 2).sum(axis=1)
+            return viol[ok].max(), ((f(xx) - f(xr)) / np.maximum(f(xr), 1e-300))[ok].max()
+        v0, f0 = quality(x)
+        n_far = int((np.abs(x - xr).max(axis=1)[ok] > 1e-6).sum())
+        print("seed %d (m, n, p) = (%2d, %2d, %2d) %s path %d: optimal %.4f  status agree cold %.6f hot %.6f  iters equal (cold) %.6f  worst |x - oracle| cold %.2e hot %.2e (%d problems beyond 1e-6: max violation %.1e, max objective excess over the oracle's %.1e relative)  same final set hot / cold %.4f"
+              % (seed, m, n, p, "ill " if ill else "well", bt.stat("last_qp_path"), ok.mean(), (st == sr).mean(), (st1 == sr).mean(), (it == ir)[ok].mean(), e0, e1, n_far, v0, f0, (ws1 == ws)[ok].all(axis=1).mean()), flush=True)
         assert (st == sr).all() and (st1 == sr).all() and (x[~ok] == 0).all() and (x1[~ok] == 0).all()
         worst = max(worst, e0, e1); total += 2 * B
 print("problems solved on the device: %d, status identical on every one; worst |x - oracle| over all optimal problems: %.3e" % (total, worst))
